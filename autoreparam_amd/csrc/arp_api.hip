@@ -1,0 +1,234 @@
+// C ABI of the engine (include/autoreparam.h): model handles, sufficient
+// statistics, launcher selection.  No torch types, no callbacks.
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <memory>
+#include "host_common.h"
+
+namespace arp {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+static const double kHalfLog2Pi = 0.9189385332046727;
+
+// pick the instantiation: requested lanes-per-chain (or a default from the chain
+// count) and the smallest slice size that covers `groups`.
+static const LaneOps* pick(const std::vector<LaneOps>& ops, int groups, int K_req, int C) {
+  auto best_for = [&](int K) -> const LaneOps* {
+    const LaneOps* best = nullptr;
+    for (const auto& o : ops)
+      if (o.K == K && (long long)o.NL * K >= groups && (!best || o.NL < best->NL)) best = &o;
+    return best;
+  };
+  if (K_req > 0) return best_for(K_req);
+  // default: the fewest lanes per chain that still give every SIMD of the 256 CUs
+  // two waves (256 CU x 4 SIMD x 2 waves x 64 lanes = 131072 lanes)
+  std::vector<int> Ks;
+  for (const auto& o : ops) if (std::find(Ks.begin(), Ks.end(), o.K) == Ks.end()) Ks.push_back(o.K);
+  std::sort(Ks.begin(), Ks.end());
+  const LaneOps* last = nullptr;
+  for (int K : Ks) {
+    const LaneOps* o = best_for(K);
+    if (!o) continue;
+    last = o;
+    if ((long long)C * K >= 131072) return o;
+  }
+  return last;
+}
+
+static const std::vector<LaneOps>* family(const arp_model* m) {
+  switch (m->model) {
+    case ARP_MODEL_RADON: return &radon_ops();
+    default: return nullptr;
+  }
+}
+static const void* family_args(const arp_model* m) {
+  switch (m->model) {
+    case ARP_MODEL_RADON: return &m->radon;
+    default: return nullptr;
+  }
+}
+
+static int build_radon(arp_model* m, const arp_dataset* d) {
+  const int J = d->n_groups, N = d->n_obs;
+  if (!d->group_host || !d->u_host || !d->x_host || !d->y_host || J <= 0 || N <= 0) {
+    set_error("radon: group/u/x/y and n_groups/n_obs are required");
+    return 1;
+  }
+  std::vector<double> n(J, 0.0), sx(J, 0.0), sy(J, 0.0);
+  double sxy = 0, sxx = 0, syy = 0;
+  for (int i = 0; i < N; ++i) {
+    int j = d->group_host[i];
+    double x = d->x_host[i], y = d->y_host[i];
+    sxy += x * y; sxx += x * x; syy += y * y;
+    // tf.one_hot gives an all-zero row for an out-of-range county: such an
+    // observation sees no county effect and only informs b2 (models.py:834-836)
+    if (j < 0 || j >= J) continue;
+    n[j] += 1; sx[j] += x; sy[j] += y;
+  }
+  m->D = 3 + J;
+  m->n_groups = J;
+  m->host_tables.resize(4 * (size_t)J);
+  for (int j = 0; j < J; ++j) {
+    m->host_tables[j] = (float)n[j];
+    m->host_tables[J + j] = (float)sx[j];
+    m->host_tables[2 * J + j] = (float)sy[j];
+    m->host_tables[3 * J + j] = d->u_host[j];
+  }
+  ARP_HIP_OK(hipMalloc(&m->dev_tables, m->host_tables.size() * sizeof(float)));
+  ARP_HIP_OK(hipMemcpy(m->dev_tables, m->host_tables.data(), m->host_tables.size() * sizeof(float),
+                       hipMemcpyHostToDevice));
+  m->radon.n = m->dev_tables;
+  m->radon.sx = m->dev_tables + J;
+  m->radon.sy = m->dev_tables + 2 * J;
+  m->radon.u = m->dev_tables + 3 * J;
+  m->radon.sxy = (float)sxy;
+  m->radon.sxx = (float)sxx;
+  m->radon.J = J;
+  // every Normal has unit scale under every (a,b): const = -(3+J+N) 0.5 log 2pi - 0.5 Syy
+  double c = -(3.0 + J + N) * kHalfLog2Pi - 0.5 * syy;
+  m->logp_const[0] = m->logp_const[1] = c;
+  return 0;
+}
+
+}  // namespace arp
+
+using namespace arp;
+
+extern "C" {
+
+int arp_version(void) { return ARP_ABI_VERSION; }
+const char* arp_last_error(void) { return g_err.c_str(); }
+
+int arp_model_create(const arp_dataset* data, arp_model** out) {
+  if (!data || !out) { set_error("arp_model_create: null argument"); return 1; }
+  std::unique_ptr<arp_model> m(new arp_model());
+  m->model = data->model;
+  ARP_HIP_OK(hipGetDevice(&m->device));
+  int rc;
+  switch (data->model) {
+    case ARP_MODEL_RADON: rc = build_radon(m.get(), data); break;
+    default: set_error("arp_model_create: unknown model id"); return 1;
+  }
+  if (rc) return rc;
+  for (int w = 0; w < 2; ++w) ARP_HIP_OK(hipMalloc(&m->dev_ab[w], 2 * (size_t)m->D * sizeof(float)));
+  // default parameterisations: 0 = CP (a=b=1), 1 = NCP (a=b=0)
+  std::vector<float> ones(m->D, 1.0f), zeros(m->D, 0.0f);
+  *out = m.release();
+  if (arp_model_set_param(*out, 0, ones.data(), ones.data())) return 1;
+  if (arp_model_set_param(*out, 1, zeros.data(), zeros.data())) return 1;
+  return 0;
+}
+
+int arp_model_destroy(arp_model* m) {
+  if (!m) return 0;
+  if (m->dev_tables) (void)hipFree(m->dev_tables);
+  for (int w = 0; w < 2; ++w) if (m->dev_ab[w]) (void)hipFree(m->dev_ab[w]);
+  delete m;
+  return 0;
+}
+
+int arp_model_dim(const arp_model* m) { return m ? m->D : -1; }
+
+double arp_model_logp_const(const arp_model* m, int which) {
+  return (m && which >= 0 && which < 2) ? m->logp_const[which] : NAN;
+}
+
+int arp_model_set_param(arp_model* m, int which, const float* a_host, const float* b_host) {
+  if (!m || which < 0 || which > 1 || !a_host || !b_host) { set_error("arp_model_set_param: bad argument"); return 1; }
+  ARP_HIP_OK(hipMemcpy(m->dev_ab[which], a_host, m->D * sizeof(float), hipMemcpyHostToDevice));
+  ARP_HIP_OK(hipMemcpy(m->dev_ab[which] + m->D, b_host, m->D * sizeof(float), hipMemcpyHostToDevice));
+  m->has_param[which] = true;
+  return 0;
+}
+
+static const LaneOps* select_ops(arp_model* m, int K_req, int C) {
+  const auto* fam = family(m);
+  if (!fam) { set_error("model family has no kernels"); return nullptr; }
+  if (K_req != 0 && K_req != 1 && K_req != 2 && K_req != 4 && K_req != 8 && K_req != 16) {
+    set_error("lanes_per_chain must be 0,1,2,4,8 or 16");
+    return nullptr;
+  }
+  const LaneOps* o = pick(*fam, m->n_groups, K_req, C);
+  if (!o) set_error("no kernel instantiation covers this (lanes_per_chain, group count)");
+  return o;
+}
+
+int arp_logp_grad(arp_model* m, int which, const float* x, int n_chains, float* logp, float* grad,
+                  int lanes_per_chain, void* stream) {
+  if (!m || which < 0 || which > 1 || !x || !logp || !grad || n_chains <= 0) { set_error("arp_logp_grad: bad argument"); return 1; }
+  const LaneOps* o = select_ops(m, lanes_per_chain, n_chains);
+  if (!o) return 1;
+  o->logp_grad(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, x, n_chains, m->D, logp, grad,
+               (hipStream_t)stream);
+  ARP_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int arp_transform(arp_model* m, int which, int dir, const float* in, int n_chains, float* out, void* stream) {
+  if (!m || which < 0 || which > 1 || !in || !out || n_chains <= 0 || (dir != 0 && dir != 1)) { set_error("arp_transform: bad argument"); return 1; }
+  const LaneOps* o = select_ops(m, 0, n_chains);
+  if (!o) return 1;
+  o->transform(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, dir, in, n_chains, m->D, out,
+               (hipStream_t)stream);
+  ARP_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int arp_hmc_run(arp_model* m, int which, const arp_hmc_config* cfg, const arp_hmc_io* io, void* stream) {
+  if (!m || !cfg || !io || which < 0 || which > 1) { set_error("arp_hmc_run: null argument"); return 1; }
+  if (cfg->n_chains <= 0 || cfg->n_leapfrog <= 0 || cfg->n_steps < 0 || cfg->thin <= 0 || cfg->step_base < 0) {
+    set_error("arp_hmc_run: n_chains, n_leapfrog, thin must be positive and n_steps, step_base non-negative");
+    return 1;
+  }
+  if (!io->q || !io->grad || !io->logp || !io->adapt || !io->rng || !io->accept_count || !io->eps0) {
+    set_error("arp_hmc_run: q, grad, logp, adapt, rng, accept_count and eps0 are required");
+    return 1;
+  }
+  if (cfg->adapt_kind < ARP_ADAPT_NONE || cfg->adapt_kind > ARP_ADAPT_SIMPLE) { set_error("arp_hmc_run: bad adapt_kind"); return 1; }
+  if (cfg->n_steps == 0) return 0;
+  const LaneOps* o = select_ops(m, cfg->lanes_per_chain, cfg->n_chains);
+  if (!o) return 1;
+  HmcParams P;
+  P.C = cfg->n_chains; P.L = cfg->n_leapfrog; P.n_steps = cfg->n_steps;
+  P.step_base = cfg->step_base; P.chain_offset = cfg->chain_offset; P.seed = cfg->seed;
+  P.adapt_kind = cfg->adapt_kind; P.n_adapt = cfg->n_adapt;
+  P.adapt_target = cfg->adapt_target; P.adapt_rate = cfg->adapt_rate;
+  P.n_burnin = cfg->n_burnin; P.thin = cfg->thin;
+  P.n_samples = (io->trace || io->trace_accept) ? cfg->n_samples : 0;
+  P.trace_centered = cfg->trace_centered;
+  {
+    // result r is taken after transition n = 1 + burnin + r*thin (1-based, global);
+    // in-launch step s completes transition step_base + s + 1
+    long long first_n = 1 + (long long)cfg->n_burnin;
+    long long r0 = 0;
+    if (cfg->step_base + 1 > first_n) {
+      r0 = (cfg->step_base + 1 - first_n + cfg->thin - 1) / cfg->thin;
+      first_n += r0 * cfg->thin;
+    }
+    long long s0 = first_n - cfg->step_base - 1;
+    P.rec_step = s0 < cfg->n_steps ? (int)s0 : -1;
+    P.rec_row = (int)(r0 < 0x7fffffff ? r0 : 0x7fffffff);
+  }
+  P.D = m->D;
+  P.q = io->q; P.grad = io->grad; P.logp = io->logp; P.adapt = io->adapt;
+  P.rng = io->rng; P.accept_count = io->accept_count; P.eps0 = io->eps0;
+  P.trace = io->trace; P.trace_accept = io->trace_accept; P.moments = io->moments;
+  o->hmc(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, (hipStream_t)stream);
+  ARP_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int arp_interleaved_run(arp_model*, const arp_hmc_config*, int, const arp_interleaved_io*, void*) {
+  set_error("arp_interleaved_run: not built yet");
+  return 1;
+}
+
+int arp_vi_run(arp_model*, int, const arp_vi_config*, const arp_vi_io*, void*) {
+  set_error("arp_vi_run: not built yet");
+  return 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+// Device-side building blocks for the gfx950 (CDNA4, wave64) sampling kernels:
+// sub-wave group reductions on DPP, the per-slot RNG and the normal generator.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ARP_DEV __device__ __forceinline__
+
+namespace arp {
+
+// ---------------------------------------------------------------------------
+// Cross-lane helpers.  A chain is spread over K consecutive lanes (K | 16), so a
+// chain never straddles a DPP row of 16 lanes; all exchanges are VALU DPP
+// modifiers (no LDS traffic).
+// ---------------------------------------------------------------------------
+template <int CTRL>
+ARP_DEV float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over the K lanes of a chain; every lane receives the bitwise identical
+// total (butterfly of commutative adds: quad xor 1, quad xor 2, half-row mirror,
+// row mirror).
+template <int K>
+ARP_DEV float group_sum(float v) {
+  if (K >= 2) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (K >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (K >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror
+  if (K >= 16) v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
+
+// Value held by slot 0 of the chain, broadcast to all of its K lanes.
+template <int K>
+ARP_DEV float group_bcast0(float v, int slot) {
+  if (K == 1) return v;
+  return group_sum<K>(slot == 0 ? v : 0.0f);
+}
+
+// ---------------------------------------------------------------------------
+// RNG.  Each (chain, slot) owns one xoshiro128++ stream (Blackman & Vigna,
+// public domain algorithm) whose 128-bit state is seeded once per run by
+// Philox4x32-10 (Salmon et al., SC'11) keyed on the user seed with counter
+// (global chain id, slot, lanes_per_chain).  The stream therefore depends on the
+// global chain id only, never on which GPU or workgroup runs the chain.
+// ---------------------------------------------------------------------------
+struct Rng {
+  uint32_t s0, s1, s2, s3;
+};
+
+ARP_DEV uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+
+ARP_DEV uint32_t rng_next(Rng& r) {
+  uint32_t result = rotl32(r.s0 + r.s3, 7) + r.s0;
+  uint32_t t = r.s1 << 9;
+  r.s2 ^= r.s0;
+  r.s3 ^= r.s1;
+  r.s1 ^= r.s2;
+  r.s0 ^= r.s3;
+  r.s2 ^= t;
+  r.s3 = rotl32(r.s3, 11);
+  return result;
+}
+
+ARP_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                           uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+ARP_DEV Rng rng_seed(uint64_t seed, uint64_t chain, uint32_t slot, uint32_t lanes) {
+  uint32_t o[4];
+  philox4x32_10((uint32_t)chain, (uint32_t)(chain >> 32), slot, lanes,
+                (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  Rng r{o[0], o[1], o[2], o[3]};
+  if ((r.s0 | r.s1 | r.s2 | r.s3) == 0u) r.s0 = 1u;  // the all-zero state is absorbing
+  return r;
+}
+
+// uniform in (0,1] with 24 random bits
+ARP_DEV float u01_open0(uint32_t w) { return (float)((w >> 8) + 1u) * 5.9604644775390625e-08f; }
+
+// Two standard normals from two 32-bit words (Box-Muller on the hardware
+// transcendental units: v_log_f32 is log2, v_sin/v_cos take revolutions).
+ARP_DEV void normal_pair(uint32_t w0, uint32_t w1, float& z0, float& z1) {
+  float u = u01_open0(w0);
+  float rev = (float)(w1 >> 8) * 5.9604644775390625e-08f;  // [0,1) revolutions
+  // r = sqrt(-2 ln u) = sqrt(-2 ln2 * log2 u)
+  float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));
+  z0 = r * __builtin_amdgcn_cosf(rev);
+  z1 = r * __builtin_amdgcn_sinf(rev);
+}
+
+// Numerically careful pieces shared by the Bernoulli-logit models.
+ARP_DEV float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+ARP_DEV float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+ARP_DEV float sigmoidf_(float x) {
+  // 1/(1+e^-x), no overflow for large |x|
+  float e = fast_exp(-fabsf(x));
+  float s = __builtin_amdgcn_rcpf(1.0f + e);
+  return x >= 0.0f ? s : e * s;
+}
+ARP_DEV float softplusf_(float x) {
+  // log(1+e^x) = max(x,0) + log1p(e^-|x|)
+  float e = fast_exp(-fabsf(x));
+  return fmaxf(x, 0.0f) + fast_log(1.0f + e);
+}
+
+}  // namespace arp

@@ -1,0 +1,71 @@
+// Host-side plumbing shared by the API translation units: the opaque model
+// handle, error reporting and the per-model launcher tables.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/autoreparam.h"
+#include "kernels.h"
+#include "model_radon.h"
+
+namespace arp {
+
+void set_error(const std::string& msg);
+
+#define ARP_HIP_OK(expr)                                                          \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      ::arp::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));        \
+      return 1;                                                                   \
+    }                                                                             \
+  } while (0)
+
+// Launchers a model family exports for one (lanes-per-chain, slice-size) pair.
+struct LaneOps {
+  int K, NL;
+  void (*logp_grad)(const void* args, const float* a, const float* b, const float* x, int C, int D,
+                    float* logp, float* grad, hipStream_t s);
+  void (*transform)(const void* args, const float* a, const float* b, int dir, const float* in,
+                    int C, int D, float* out, hipStream_t s);
+  void (*hmc)(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s);
+};
+
+template <class Lane>
+struct Launch {
+  static int blocks(int C) { return (int)(((long long)C * Lane::K + kBlock - 1) / kBlock); }
+  static void logp_grad(const void* args, const float* a, const float* b, const float* x, int C, int D,
+                        float* logp, float* grad, hipStream_t s) {
+    hipLaunchKernelGGL(logp_grad_kernel<Lane>, dim3(blocks(C)), dim3(kBlock), 0, s,
+                       *(const typename Lane::Args*)args, a, b, x, C, D, logp, grad);
+  }
+  static void transform(const void* args, const float* a, const float* b, int dir, const float* in,
+                        int C, int D, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(transform_kernel<Lane>, dim3(blocks(C)), dim3(kBlock), 0, s,
+                       *(const typename Lane::Args*)args, a, b, dir, in, C, D, out);
+  }
+  static void hmc(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s) {
+    hipLaunchKernelGGL(hmc_kernel<Lane>, dim3(blocks(P.C)), dim3(kBlock), 0, s,
+                       *(const typename Lane::Args*)args, a, b, P);
+  }
+  static LaneOps ops() { return LaneOps{Lane::K, Lane::NL, &logp_grad, &transform, &hmc}; }
+};
+
+// per-family tables (defined in inst_*.hip)
+const std::vector<LaneOps>& radon_ops();
+
+}  // namespace arp
+
+struct arp_model {
+  int model = -1;
+  int D = 0;
+  int device = 0;
+  int n_groups = 0;          // slice axis length (radon J, election 52, schools 8)
+  float* dev_tables = nullptr;   // one allocation holding all frozen tables
+  float* dev_ab[2] = {nullptr, nullptr};  // [2][D]: a then b, per parameterisation
+  bool has_param[2] = {false, false};
+  double logp_const[2] = {0.0, 0.0};
+  arp::RadonArgs radon{};
+  std::vector<float> host_tables;
+};

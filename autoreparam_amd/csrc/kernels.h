@@ -1,0 +1,282 @@
+// Generic chain kernels, templated on a lane model (model_*.h).  A chain is
+// spread over Lane::K consecutive lanes of a wave64; each lane keeps its slice of
+// the state, momentum, gradient and sufficient statistics in VGPRs for the whole
+// launch, so an HMC segment of n_steps transitions touches HBM only to load and
+// store the chain state once and to append trace rows.
+#pragma once
+#include "arp_device.h"
+#include "../../include/autoreparam.h"
+
+namespace arp {
+
+constexpr int kBlock = 256;      // 4 waves per workgroup
+constexpr int kRngSlots = 16;    // rng buffer stride per chain (max lanes per chain)
+
+struct HmcParams {
+  int C, L, n_steps;
+  long long step_base;
+  long long chain_offset;
+  unsigned long long seed;
+  int adapt_kind, n_adapt;
+  float adapt_target, adapt_rate;
+  int n_burnin, thin, n_samples, trace_centered;
+  int rec_step, rec_row;   // first in-launch step (0-based) that records, and its trace row
+  int D;
+  float* q; float* grad; float* logp; float* adapt;
+  uint32_t* rng; uint32_t* accept_count;
+  const float* eps0;
+  float* trace; uint8_t* trace_accept; float* moments;
+};
+
+
+// ---------------------------------------------------------------------------
+// Row I/O in the reference layout [C][D].  Lane `slot` of a chain owns the
+// replicated globals (flattened index Lane::gg(i)) and the slices
+// LBASE + slot + K*i, i < nloc: one 64-bit base per row, compile-time offsets.
+// ---------------------------------------------------------------------------
+template <class Lane>
+ARP_DEV void load_row(const Lane& M, const float* __restrict__ row, float (&v)[Lane::ND]) {
+#pragma unroll
+  for (int i = 0; i < Lane::NG; ++i) v[i] = row[Lane::gg(i)];
+  const float* lb = row + Lane::LBASE + M.slot;
+#pragma unroll
+  for (int i = 0; i < Lane::NL; ++i) v[Lane::NG + i] = (i < M.nloc) ? lb[Lane::K * i] : 0.0f;
+}
+template <class Lane>
+ARP_DEV void store_row(const Lane& M, float* __restrict__ row, const float (&v)[Lane::ND], bool live) {
+  if (live && M.slot == 0) {
+#pragma unroll
+    for (int i = 0; i < Lane::NG; ++i) row[Lane::gg(i)] = v[i];
+  }
+  float* lb = row + Lane::LBASE + M.slot;
+#pragma unroll
+  for (int i = 0; i < Lane::NL; ++i)
+    if (live && i < M.nloc) lb[Lane::K * i] = v[Lane::NG + i];
+}
+
+// ---------------------------------------------------------------------------
+// logp + grad for a batch of states (test hook and bootstrap of the cached
+// gradient; reference: vectorized target + tf.gradients, inference.py:172-195)
+// ---------------------------------------------------------------------------
+template <class Lane>
+__global__ __launch_bounds__(kBlock) void logp_grad_kernel(
+    typename Lane::Args A, const float* __restrict__ av, const float* __restrict__ bv,
+    const float* __restrict__ x, int C, int D, float* __restrict__ logp, float* __restrict__ grad) {
+  constexpr int K = Lane::K, ND = Lane::ND;
+  long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+  int slot = (int)(t % K);
+  long long c = t / K;
+  bool live = c < C;
+  long long cc = live ? c : (long long)C - 1;  // dead lanes shadow the last chain (keeps DPP groups uniform)
+  Lane M;
+  M.init(A, av, bv, slot);
+  float q[ND], g[ND];
+  load_row(M, x + cc * D, q);
+  float lp = M.template grad<true>(q, g);
+  store_row(M, grad + cc * D, g, live);
+  if (live && slot == 0) logp[c] = lp;
+}
+
+// dir 0: reparameterised -> centred; dir 1: centred -> reparameterised
+template <class Lane>
+__global__ __launch_bounds__(kBlock) void transform_kernel(
+    typename Lane::Args A, const float* __restrict__ av, const float* __restrict__ bv,
+    int dir, const float* __restrict__ in, int C, int D, float* __restrict__ out) {
+  constexpr int K = Lane::K, ND = Lane::ND;
+  long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+  int slot = (int)(t % K);
+  long long c = t / K;
+  bool live = c < C;
+  long long cc = live ? c : (long long)C - 1;
+  Lane M;
+  M.init(A, av, bv, slot);
+  float a[ND], b[ND];
+  load_row(M, in + cc * D, a);
+  if (dir == 0) M.to_centered(a, b); else M.from_centered(a, b);
+  store_row(M, out + cc * D, b, live);
+}
+
+// ---------------------------------------------------------------------------
+// One HMC transition on the lane slice (mcmc.HamiltonianMonteCarlo.one_step as
+// wired at inference.py:218-222): momentum draw, L leapfrog steps with the two
+// half kicks of consecutive steps merged, Metropolis test.  Returns the log
+// acceptance ratio; q/g/lp are replaced in place when the proposal is accepted.
+// ---------------------------------------------------------------------------
+template <class Lane>
+ARP_DEV float hmc_transition(const Lane& M, Rng& rng, int L, const float (&eps)[Lane::ND],
+                             float (&q)[Lane::ND], float (&g)[Lane::ND], float& lp,
+                             bool& accepted) {
+  constexpr int K = Lane::K, ND = Lane::ND, NG = Lane::NG;
+  float p[ND], q1[ND], g1[ND];
+  // momenta: every lane draws ND normals from its own stream; the replicated
+  // globals take slot 0's draw, padding slots get none.
+#pragma unroll
+  for (int i = 0; i < ND; i += 2) {
+    float z0 = 0.0f, z1 = 0.0f;
+    if (i < M.ndraw) {  // wave-uniform: slices beyond ceil(groups/K) draw nothing
+      uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
+      normal_pair(w0, w1, z0, z1);
+    }
+    p[i] = z0;
+    if (i + 1 < ND) p[i + 1] = z1;
+  }
+  float u = u01_open0(rng_next(rng));
+  u = group_bcast0<K>(u, M.slot);
+  float ke0 = 0.0f, keg0 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    if (i < NG) {
+      p[i] = group_bcast0<K>(p[i], M.slot);
+      keg0 = fmaf(p[i], p[i], keg0);
+    } else {
+      p[i] = (i - NG) < M.nloc ? p[i] : 0.0f;
+      ke0 = fmaf(p[i], p[i], ke0);
+    }
+  }
+  ke0 = 0.5f * (group_sum<K>(ke0) + keg0);
+
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    q1[i] = q[i];
+    p[i] = fmaf(0.5f * eps[i], g[i], p[i]);
+  }
+  // L-1 full steps, then the last position update with the closing half kick
+  for (int l = 1; l < L; ++l) {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) q1[i] = fmaf(eps[i], p[i], q1[i]);
+    M.template grad<false>(q1, g1);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) p[i] = fmaf(eps[i], g1[i], p[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < ND; ++i) q1[i] = fmaf(eps[i], p[i], q1[i]);
+  const float lp1 = M.template grad<true>(q1, g1);
+#pragma unroll
+  for (int i = 0; i < ND; ++i) p[i] = fmaf(0.5f * eps[i], g1[i], p[i]);
+  float ke1 = 0.0f, keg1 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    if (i < NG) keg1 = fmaf(p[i], p[i], keg1); else ke1 = fmaf(p[i], p[i], ke1);
+  }
+  ke1 = 0.5f * (group_sum<K>(ke1) + keg1);
+
+  // log accept ratio; any non-finite energy error rejects (TFP safe_sum semantics)
+  float la = (lp1 - lp) + (ke0 - ke1);
+  if (!(fabsf(la) <= 3.0e38f)) la = -INFINITY;
+  accepted = fast_log(u) < la;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    q[i] = accepted ? q1[i] : q[i];
+    g[i] = accepted ? g1[i] : g[i];
+  }
+  lp = accepted ? lp1 : lp;
+  return la;
+}
+
+// Step-size multiplier update after a transition whose 1-based index is n.
+// kappa scales the per-element base step eps0 (all elements of a chain see the
+// same acceptance probability, so the reference's per-element adaptation state
+// collapses to one scalar per chain).
+ARP_DEV void adapt_update(int kind, long long n, int n_adapt, float target, float rate, float la,
+                          float& kappa, float& esum, float& logavg) {
+  if (kind == ARP_ADAPT_NONE) return;
+  float lacc = fminf(la, 0.0f);
+  if (kind == ARP_ADAPT_DUAL) {
+    if (n <= n_adapt) {
+      float t = (float)n;
+      esum += target - fast_exp(lacc);
+      // log(10 eps0) - esum sqrt(t) / ((t + 10) * 0.05), relative to log eps0
+      float ls = 2.302585092994046f - esum * __builtin_amdgcn_sqrtf(t) * __builtin_amdgcn_rcpf((t + 10.0f) * 0.05f);
+      float eta = __builtin_amdgcn_exp2f(-0.75f * __builtin_amdgcn_logf(t));
+      logavg = eta * ls + (1.0f - eta) * logavg;
+      kappa = fast_exp(ls);
+    } else if (n_adapt > 0) {
+      kappa = fast_exp(logavg);
+    }
+  } else {  // ARP_ADAPT_SIMPLE
+    if (n <= n_adapt) {
+      float opr = 1.0f + rate;
+      kappa *= lacc > fast_log(target) ? opr : __builtin_amdgcn_rcpf(opr);
+    }
+  }
+}
+
+template <class Lane>
+__global__ __launch_bounds__(kBlock) void hmc_kernel(
+    typename Lane::Args A, const float* __restrict__ av, const float* __restrict__ bv, HmcParams P) {
+  constexpr int K = Lane::K, ND = Lane::ND, NG = Lane::NG;
+  long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const int slot = (int)(t % K);
+  long long c = t / K;
+  const bool live = c < P.C;
+  if (!live) c = P.C - 1;  // shadow lanes compute on the last chain but never store
+  const int D = P.D;
+  Lane M;
+  M.init(A, av, bv, slot);
+
+  float q[ND], g[ND], eps[ND];
+  float* qrow = P.q + c * D;
+  float* grow = P.grad + c * D;
+  load_row(M, qrow, q);
+  float lp;
+  if (P.step_base == 0) {
+    lp = M.template grad<true>(q, g);
+  } else {
+    load_row(M, grow, g);
+    lp = P.logp[c];
+  }
+  float kappa, esum, logavg;
+  Rng rng;
+  uint32_t* rs = P.rng + ((size_t)c * kRngSlots + slot) * 4;
+  if (P.step_base == 0) {
+    kappa = 1.0f; esum = 0.0f; logavg = 0.0f;
+    rng = rng_seed(P.seed, (unsigned long long)(P.chain_offset + c), (uint32_t)slot, (uint32_t)K);
+  } else {
+    kappa = P.adapt[c * 4 + 0]; esum = P.adapt[c * 4 + 1]; logavg = P.adapt[c * 4 + 2];
+    rng = Rng{rs[0], rs[1], rs[2], rs[3]};
+  }
+  uint32_t nacc = (P.step_base == 0) ? 0u : P.accept_count[c];
+
+  int next_rec = P.rec_step, rec_row = P.rec_row;
+  for (int s = 0; s < P.n_steps; ++s) {
+    // eps0 is re-read (L1/L2 resident, [D] floats) instead of living in VGPRs
+    load_row(M, P.eps0, eps);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) eps[i] *= kappa;
+    bool acc;
+    float la = hmc_transition<Lane>(M, rng, P.L, eps, q, g, lp, acc);
+    nacc += acc ? 1u : 0u;
+    const long long n = P.step_base + s + 1;
+    adapt_update(P.adapt_kind, n, P.n_adapt, P.adapt_target, P.adapt_rate, la, kappa, esum, logavg);
+
+    // sample_chain schedule: result r is the state after transition 1 + burnin + r*thin
+    if (s == next_rec && rec_row < P.n_samples) {
+      if (P.trace) {
+        float* row = P.trace + ((size_t)rec_row * P.C + c) * D;
+        if (P.trace_centered) {
+          float x[ND];
+          M.to_centered(q, x);
+          store_row(M, row, x, live);
+        } else {
+          store_row(M, row, q, live);
+        }
+      }
+      if (P.trace_accept && live && slot == 0) P.trace_accept[(size_t)rec_row * P.C + c] = acc ? 1 : 0;
+      next_rec += P.thin;
+      rec_row += 1;
+    }
+  }
+
+  store_row(M, qrow, q, live);
+  store_row(M, grow, g, live);
+  if (live) {
+    rs[0] = rng.s0; rs[1] = rng.s1; rs[2] = rng.s2; rs[3] = rng.s3;
+    if (slot == 0) {
+      P.logp[c] = lp;
+      P.adapt[c * 4 + 0] = kappa; P.adapt[c * 4 + 1] = esum; P.adapt[c * 4 + 2] = logavg;
+      P.accept_count[c] = nacc;
+    }
+  }
+}
+
+}  // namespace arp

@@ -1,0 +1,125 @@
+// Radon hierarchical regression (reference models.py:809-857), collapsed to
+// per-county sufficient statistics and evaluated under the general VIP
+// parameterisation (program_transformations.py:555-600).
+//
+//   mua, b1, b2 ~ N(0,1)                      (top level: VIP map is the identity)
+//   m_j ~ N(mu_j, 1),  mu_j = mua + u_j b1    (sigma = 1, so only `a` matters)
+//   y_i ~ N(m_{c_i} + x_i b2, 1)
+//
+// State holds mt_j with mt_j ~ N(a_j mu_j, 1), m_j = mt_j + (1 - a_j) mu_j.
+// With r_j = mt_j - a_j mu_j,  l_j = Sy_j - b2 Sx_j - n_j m_j:
+//   d/dmt_j = l_j - r_j =: g_j         h_j := d/dmu_j = l_j - a_j g_j
+//   d/dmua = -mua + sum h_j            d/db1 = -b1 + sum u_j h_j
+//   d/db2  = -b2 + Sxy - b2 Sxx - sum m_j Sx_j
+// (checked against float64 autograd in tests/).
+#pragma once
+#include "arp_device.h"
+
+namespace arp {
+
+struct RadonArgs {
+  const float* n;    // [J] observations per county
+  const float* sx;   // [J] sum of floor indicators
+  const float* sy;   // [J] sum of log radon
+  const float* u;    // [J] log uranium
+  float sxy, sxx;    // totals over all observations
+  int J;
+};
+
+template <int K_, int NL_>
+struct RadonLane {
+  static constexpr int K = K_;
+  static constexpr int NG = 3;   // mua, b1, b2 replicated in every lane of the chain
+  static constexpr int NL = NL_; // counties owned by this lane: j = slot + K*i
+  static constexpr int ND = NG + NL;
+  using Args = RadonArgs;
+
+  static constexpr int LBASE = 3; // flattened index of m_0 (parts: mua, b1, b2, m[J])
+
+  float n[NL], sx[NL], sy[NL], u[NL], a[NL];
+  float sxy, sxx;
+  int nloc, slot;                // nloc: slices of this lane that map to a real county
+  int ndraw;                     // NG + ceil(J/K): normals every RNG slot draws per transition
+
+  // flattened index of replicated global i
+  static ARP_DEV int gg(int i) { return i; }
+
+  ARP_DEV void init(const Args& A, const float* av, const float* /*bv*/, int slot_) {
+    slot = slot_;
+    const int J = A.J;
+    nloc = (J - slot + K - 1) / K;
+    ndraw = NG + (J + K - 1) / K;
+    sxy = A.sxy;
+    sxx = A.sxx;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      int j = slot + K * i;
+      bool ok = j < J;
+      n[i] = ok ? A.n[j] : 0.0f;
+      sx[i] = ok ? A.sx[j] : 0.0f;
+      sy[i] = ok ? A.sy[j] : 0.0f;
+      u[i] = ok ? A.u[j] : 0.0f;
+      a[i] = ok ? av[NG + j] : 0.0f;
+    }
+  }
+
+  // Gradient of the log joint at q (and the log joint itself, additive
+  // constants dropped, when LOGP).  Padding slots (j >= J) keep q = g = 0.
+  template <bool LOGP>
+  ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const {
+    const float mua = q[0], b1 = q[1], b2 = q[2];
+    float acc_h = 0.0f, acc_uh = 0.0f, acc_ms = 0.0f, lp = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float mt = q[NG + i];
+      float mu = fmaf(u[i], b1, mua);
+      float r = fmaf(-a[i], mu, mt);
+      float m = r + mu;
+      float t = fmaf(-b2, sx[i], sy[i]);
+      float l = fmaf(-n[i], m, t);
+      float gm = l - r;
+      g[NG + i] = gm;
+      float h = fmaf(-a[i], gm, l);
+      acc_h += h;
+      acc_uh = fmaf(u[i], h, acc_uh);
+      acc_ms = fmaf(m, sx[i], acc_ms);
+      if (LOGP) {
+        lp = fmaf(-0.5f * r, r, lp);
+        lp = fmaf(-0.5f * m, fmaf(n[i], m, -2.0f * t), lp);
+      }
+    }
+    acc_h = group_sum<K>(acc_h);
+    acc_uh = group_sum<K>(acc_uh);
+    acc_ms = group_sum<K>(acc_ms);
+    g[0] = acc_h - mua;
+    g[1] = acc_uh - b1;
+    g[2] = fmaf(-b2, sxx, sxy) - acc_ms - b2;
+    if (LOGP) {
+      lp = group_sum<K>(lp);
+      lp += -0.5f * (mua * mua + b1 * b1 + b2 * b2) + b2 * (sxy - 0.5f * b2 * sxx);
+    }
+    return lp;
+  }
+
+  // reparameterised -> centred coordinates
+  ARP_DEV void to_centered(const float (&q)[ND], float (&x)[ND]) const {
+    x[0] = q[0]; x[1] = q[1]; x[2] = q[2];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float mu = fmaf(u[i], q[1], q[0]);
+      x[NG + i] = fmaf(-a[i], mu, q[NG + i]) + mu;
+    }
+  }
+  // centred -> reparameterised coordinates
+  ARP_DEV void from_centered(const float (&x)[ND], float (&q)[ND]) const {
+    q[0] = x[0]; q[1] = x[1]; q[2] = x[2];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float mu = fmaf(u[i], x[1], x[0]);
+      // mt = m - (1-a) mu ; padding slots (a = 0, x = 0 on input) must stay 0
+      q[NG + i] = (i < nloc) ? x[NG + i] - (1.0f - a[i]) * mu : 0.0f;
+    }
+  }
+};
+
+}  // namespace arp

@@ -1,0 +1,169 @@
+"""Device-side handle around the C ABI: one Engine per (process, GPU, model).
+
+torch is used only for device memory and streams; every number on the hot path is
+produced by the HIP kernels in libautoreparam_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class ChainState(object):
+    """Per-chain persistent state of a run (the reference's kernel_results)."""
+
+    def __init__(self, q):
+        C_, D = q.shape
+        dev = q.device
+        self.q = q.contiguous().clone()
+        self.grad = torch.zeros_like(self.q)
+        self.logp = torch.zeros(C_, dtype=torch.float32, device=dev)
+        self.adapt = torch.zeros(C_, 4, dtype=torch.float32, device=dev)
+        self.rng = torch.zeros(C_, _lib.RNG_SLOTS, 4, dtype=torch.int32, device=dev)
+        self.accept_count = torch.zeros(C_, dtype=torch.int32, device=dev)
+        self.step = 0  # transitions done
+
+
+class Engine(object):
+    def __init__(self, spec, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("autoreparam_amd.Engine needs a GPU (gfx950); there is no CPU fallback")
+        self.spec = spec
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self._L = _lib.lib()
+        self._h = C.c_void_p(0)
+        ds, keep = spec.dataset()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.arp_model_create(C.byref(ds), C.byref(self._h)))
+        del keep
+        self.D = self._L.arp_model_dim(self._h)
+        assert self.D == spec.D, (self.D, spec.D)
+        self._ab = [None, None]
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.arp_model_destroy(self._h)
+                self._h = C.c_void_p(0)
+        except Exception:
+            pass
+
+    # -- parameterisations ------------------------------------------------
+    def set_param(self, which, reparam):
+        """reparam: 'CP', 'NCP', a dict of ``<rv>_a``/``<rv>_b`` values, or an (a, b) pair of [D] arrays."""
+        if isinstance(reparam, tuple):
+            a, b = (np.ascontiguousarray(v, np.float32) for v in reparam)
+        else:
+            a, b = self.spec.ab_from_reparam(reparam)
+        assert a.shape == (self.D,) and b.shape == (self.D,)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.arp_model_set_param(self._h, which, a.ctypes.data_as(_lib._f32p),
+                                                   b.ctypes.data_as(_lib._f32p)))
+        self._ab[which] = (a, b)
+
+    def logp_const(self, which=0):
+        return self._L.arp_model_logp_const(self._h, which)
+
+    # -- density / converters --------------------------------------------
+    def _dev(self, x):
+        t = torch.as_tensor(x, dtype=torch.float32)
+        return t.to(self.device).contiguous()
+
+    def logp_grad(self, x, which=0, lanes=0):
+        x = self._dev(x)
+        n = x.shape[0]
+        logp = torch.empty(n, dtype=torch.float32, device=self.device)
+        grad = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.arp_logp_grad(self._h, which, _ptr(x), n, _ptr(logp), _ptr(grad), lanes, _stream()))
+        return logp, grad
+
+    def transform(self, x, which=0, to_centered=True):
+        x = self._dev(x)
+        out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.arp_transform(self._h, which, 0 if to_centered else 1, _ptr(x), x.shape[0],
+                                             _ptr(out), _stream()))
+        return out
+
+    # -- HMC ----------------------------------------------------------------
+    def hmc_run(self, state, eps0, n_leapfrog, n_steps, which=0, seed=0, chain_offset=0,
+                adapt_kind=_lib.ADAPT_NONE, n_adapt=0, adapt_target=0.75, adapt_rate=0.05,
+                n_burnin=0, thin=1, trace=None, trace_accept=None, trace_centered=True, lanes=0):
+        """Advance `state` by n_steps transitions (one kernel launch)."""
+        cfg = _lib.HmcConfig()
+        cfg.n_chains = state.q.shape[0]
+        cfg.n_leapfrog = int(n_leapfrog)
+        cfg.n_steps = int(n_steps)
+        cfg.step_base = int(state.step)
+        cfg.chain_offset = int(chain_offset)
+        cfg.seed = int(seed)
+        cfg.adapt_kind = int(adapt_kind)
+        cfg.n_adapt = int(n_adapt)
+        cfg.adapt_target = float(adapt_target)
+        cfg.adapt_rate = float(adapt_rate)
+        cfg.n_burnin = int(n_burnin)
+        cfg.thin = int(thin)
+        cfg.n_samples = int(trace.shape[0]) if trace is not None else (
+            int(trace_accept.shape[0]) if trace_accept is not None else 0)
+        cfg.trace_centered = 1 if trace_centered else 0
+        cfg.lanes_per_chain = int(lanes)
+        io = _lib.HmcIO()
+        io.q, io.grad, io.logp = _ptr(state.q), _ptr(state.grad), _ptr(state.logp)
+        io.adapt, io.rng, io.accept_count = _ptr(state.adapt), _ptr(state.rng), _ptr(state.accept_count)
+        self._eps0 = self._dev(eps0)
+        io.eps0 = _ptr(self._eps0)
+        io.trace, io.trace_accept, io.moments = _ptr(trace), _ptr(trace_accept), C.c_void_p(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.arp_hmc_run(self._h, which, C.byref(cfg), C.byref(io), _stream()))
+        state.step += int(n_steps)
+        return state
+
+
+# ---------------------------------------------------------------------------
+# State converters with the reference's calling convention (models.py:56-128):
+# callables on lists of [C, *event] arrays, evaluated on the device.
+# ---------------------------------------------------------------------------
+_engines = {}
+
+
+def engine_for(spec, device=None):
+    key = (id(spec), str(device))
+    if key not in _engines:
+        _engines[key] = Engine(spec, device)
+    return _engines[key]
+
+
+def _convert(spec, reparam, to_centered):
+    def fn(state_parts):
+        eng = engine_for(spec)
+        eng.set_param(1, reparam)
+        flat = spec.pack([np.asarray(p, np.float32).reshape(1, *np.shape(p)) if np.ndim(p) == len(s) else p
+                          for p, s in zip(state_parts, spec.part_shapes)])
+        single = all(np.ndim(p) == len(s) for p, s in zip(state_parts, spec.part_shapes))
+        out = eng.transform(flat, which=1, to_centered=to_centered).cpu().numpy()
+        parts = spec.unpack(out)
+        return [p[0] for p in parts] if single else parts
+    return fn
+
+
+def build_make_to_centered(spec):
+    def make_to_centered(**centering_kwargs):
+        return _convert(spec, centering_kwargs, True)
+    return make_to_centered
+
+
+def build_make_to_partially_noncentered(spec):
+    def make_to_partially_noncentered(**centering_kwargs):
+        return _convert(spec, centering_kwargs, False)
+    return make_to_partially_noncentered

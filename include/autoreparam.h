@@ -1,0 +1,171 @@
+/*
+ * autoreparam.h -- C ABI of the MI355X-native HMC / mean-field-VI engine.
+ *
+ * This is the drop-in boundary for the hot path of mgorinova/autoreparam.  The
+ * reference has NO native interface for this path (it is pure Python on
+ * TensorFlow-Probability); each entry point below names the
+ * reference call it replaces so a maintainer can bind it with ctypes
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C types only; every array pointer is a DEVICE pointer (HBM, gfx950)
+ *     unless the parameter name ends in `_host`;
+ *   - the caller owns every buffer; the library never frees caller memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     calls only enqueue work, they never synchronise;
+ *   - every function returns 0 on success, non-zero on failure, and
+ *     arp_last_error() then returns a human readable message (thread local);
+ *   - chain states use the reference layout: the model's latent parts,
+ *     flattened and concatenated in trace order, one row per chain,
+ *     row-major float32 `[C][D]`  (reference: list of `[C,*event]` tensors,
+ *     inference.py:207-216).
+ */
+#ifndef AUTOREPARAM_H_
+#define AUTOREPARAM_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARP_ABI_VERSION 1
+
+/* Models on the hot path (reference models.py:131-166, 809-857, 884-923, 967-1008). */
+enum {
+  ARP_MODEL_EIGHT_SCHOOLS = 0,
+  ARP_MODEL_RADON = 1,
+  ARP_MODEL_GERMAN_CREDIT = 2, /* german_credit_lognormalcentered */
+  ARP_MODEL_ELECTION = 3
+};
+
+/* Step-size adaptation wrapped around the HMC transition. */
+enum {
+  ARP_ADAPT_NONE = 0,   /* fixed step (parity runs) */
+  ARP_ADAPT_DUAL = 1,   /* tfp.mcmc.DualAveragingStepSizeAdaptation defaults, inference.py:224-226 */
+  ARP_ADAPT_SIMPLE = 2  /* tfp.mcmc.SimpleStepSizeAdaptation(rate, target), inference.py:288-306 */
+};
+
+/* Raw model inputs exactly as the reference's `model_args` / `observed_data`
+ * hold them (HOST pointers; copied at create time).  Unused fields are NULL/0. */
+typedef struct arp_dataset {
+  int32_t model;        /* ARP_MODEL_* */
+  int32_t n_obs;        /* N */
+  int32_t n_groups;     /* radon: J counties; election: n_state; schools: 8 */
+  int32_t n_features;   /* german: 62 */
+  const int32_t* group_host;   /* [N] radon county (0-based) / election state (1-based, as the reference feeds tf.one_hot) */
+  const float* u_host;         /* radon: [J] log uranium; schools: [8] treatment stddevs */
+  const float* x_host;         /* radon: [N] floor; election: [N] female */
+  const float* x2_host;        /* election: [N] black */
+  const float* y_host;         /* [N] observations (Bernoulli outcomes as 0/1 floats); schools: [8] effects */
+  const float* X_host;         /* german: [N][n_features] row-major design matrix */
+} arp_dataset;
+
+typedef struct arp_model arp_model; /* opaque: frozen data + sufficient statistics, on one device */
+
+/* One segment of `n_steps` HMC transitions over `n_chains` chains (replaces one
+ * stretch of tfp.mcmc.sample_chain's while-loop, inference.py:228-236). */
+typedef struct arp_hmc_config {
+  int32_t n_chains;          /* C on this device */
+  int32_t n_leapfrog;        /* L */
+  int32_t n_steps;           /* transitions in this call */
+  int64_t step_base;         /* transitions already done for these chains (0 on the first call) */
+  int64_t chain_offset;      /* global id of chain 0 on this device (RNG keying; multi-GPU sharding) */
+  uint64_t seed;
+  int32_t adapt_kind;        /* ARP_ADAPT_* */
+  int32_t n_adapt;           /* num_adaptation_steps */
+  float adapt_target;        /* target accept prob (0.75) */
+  float adapt_rate;          /* SIMPLE: adaptation_rate (0.05) */
+  /* trace schedule, sample_chain semantics: result s is taken after transition
+   * 1 + n_burnin + s*thin (thin = 1 + num_steps_between_results). */
+  int32_t n_burnin;
+  int32_t thin;
+  int32_t n_samples;         /* S: capacity of the trace buffers (rows) */
+  int32_t trace_centered;    /* 1: trace rows are mapped to centred coordinates (inference.py:238-239) */
+  int32_t lanes_per_chain;   /* 0 = library default; otherwise 1,2,4,8,16 (also partitions the RNG streams) */
+  int32_t reserved;
+} arp_hmc_config;
+
+/* Per-chain persistent state ("kernel results") + outputs.  All DEVICE pointers. */
+typedef struct arp_hmc_io {
+  float* q;                  /* [C][D] in/out current state (reparameterised coordinates) */
+  float* grad;               /* [C][D] in/out cached gradient at q (ignored when step_base == 0) */
+  float* logp;               /* [C]    in/out cached log-density at q (additive constants dropped) */
+  float* adapt;              /* [C][4] in/out {step multiplier kappa, error sum, log-averaged multiplier, unused} */
+  uint32_t* rng;             /* [C][16][4] in/out xoshiro128++ states, one per RNG slot */
+  uint32_t* accept_count;    /* [C] in/out accepted transitions */
+  const float* eps0;         /* [D] base step size per element (VI posterior std / (L/4)^2, inference.py:212-216) */
+  float* trace;              /* [S][C][D] or NULL */
+  uint8_t* trace_accept;     /* [S][C] is_accepted of recorded transitions, or NULL */
+  float* moments;            /* [C][2][D] running sum / sum of squares of centred post-burn-in states, or NULL */
+} arp_hmc_io;
+
+int arp_version(void);
+const char* arp_last_error(void);
+
+/* Build a model handle on the current HIP device: copies the data, derives the
+ * per-group sufficient statistics and uploads them. */
+int arp_model_create(const arp_dataset* data, arp_model** out);
+int arp_model_destroy(arp_model* m);
+int arp_model_dim(const arp_model* m);                 /* D */
+/* Additive constant dropped from logp for parameterisation `which` (so callers can
+ * report the reference-valued target_log_prob / ELBO): logp_ref = logp + const. */
+double arp_model_logp_const(const arp_model* m, int which);
+
+/* Set the parameterisation `which` (0 = primary, 1 = secondary, used by the
+ * interleaved kernel): per-element VIP parameters a,b (HOST, [D]).  a=b=1 is CP,
+ * a=b=0 is NCP (program_transformations.py:555-600). */
+int arp_model_set_param(arp_model* m, int which, const float* a_host, const float* b_host);
+
+/* target_log_prob_fn + its gradient for a batch of chains
+ * (vectorize_log_joint_fn, inference.py:172-195 + tf.gradients inside TFP). */
+int arp_logp_grad(arp_model* m, int which, const float* x, int n_chains,
+                  float* logp, float* grad, int lanes_per_chain, void* stream);
+
+/* State converters (models.py:56-128): dir 0: parameterisation `which` -> centred,
+ * dir 1: centred -> parameterisation `which`. */
+int arp_transform(arp_model* m, int which, int dir, const float* in, int n_chains,
+                  float* out, void* stream);
+
+/* HMC segment (mcmc.HamiltonianMonteCarlo + step-size adaptation + sample_chain). */
+int arp_hmc_run(arp_model* m, int which, const arp_hmc_config* cfg,
+                const arp_hmc_io* io, void* stream);
+
+/* Interleaved CP/NCP segment (interleaved.Interleaved.one_step, interleaved.py:113-155):
+ * parameterisation 0 then 1 per step, each with its own leapfrog count, base
+ * step sizes and adaptation state; `q` is kept in parameterisation-0 coordinates. */
+typedef struct arp_interleaved_io {
+  arp_hmc_io k0;             /* q/rng/trace live here; grad/logp unused (re-bootstrapped every step) */
+  float* adapt1;             /* [C][4] adaptation state of kernel 1 */
+  uint32_t* accept_count1;   /* [C] */
+  const float* eps0_1;       /* [D] */
+  uint8_t* trace_accept1;    /* [S][C] or NULL */
+} arp_interleaved_io;
+int arp_interleaved_run(arp_model* m, const arp_hmc_config* cfg, int n_leapfrog_1,
+                        const arp_interleaved_io* io, void* stream);
+
+/* Mean-field VI (find_best_learning_rate, inference.py:26-154 on top of
+ * util.get_mean_field_elbo, util.py:232-268): runs `n_lr` independent Adam
+ * optimisations (one workgroup each) of `n_steps` steps in ONE launch. */
+typedef struct arp_vi_config {
+  int32_t n_lr;              /* number of learning rates */
+  int32_t n_steps;           /* num_optimization_steps */
+  int32_t n_mc;              /* num_mc_samples (<= 1024) */
+  int32_t learn_a;           /* 1: also optimise the VIP parameter a = sigmoid(w) (cVIP) */
+  int32_t tied_b;            /* 1: b := a in the density (tied_pparams as intended); 0: b fixed from set_param */
+  int32_t reserved;
+  uint64_t seed;
+} arp_vi_config;
+typedef struct arp_vi_io {
+  const float* lr;           /* [n_lr] base learning rates */
+  float* loc;                /* [n_lr][D] in: initial loc, out: final */
+  float* rho;                /* [n_lr][D] in: initial pre-softplus scale, out: final */
+  float* w;                  /* [n_lr][D] in/out unconstrained a (only if learn_a) */
+  float* elbo;               /* [n_lr][n_steps] ELBO estimate per step (reference-valued, constants included) */
+} arp_vi_io;
+int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_io* io, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUTOREPARAM_H_ */

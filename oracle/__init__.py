@@ -1,0 +1,118 @@
+"""CPU oracle: ctypes front end of oracle/liboracle.so (plain C restatement of the
+hot path) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+package; nothing under autoreparam_amd/ does.  PARITY UNPINNED: see oracle.c.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+class HmcCfg(C.Structure):
+    _fields_ = [("n_chains", C.c_int), ("n_leapfrog", C.c_int), ("n_steps", C.c_int),
+                ("step_base", C.c_longlong), ("chain_offset", C.c_longlong), ("seed", C.c_uint64),
+                ("adapt_kind", C.c_int), ("n_adapt", C.c_int),
+                ("adapt_target", C.c_float), ("adapt_rate", C.c_float),
+                ("n_burnin", C.c_int), ("thin", C.c_int), ("n_samples", C.c_int),
+                ("trace_centered", C.c_int), ("lanes", C.c_int)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.orc_radon_create.restype = C.c_void_p
+        _lib.orc_model_dim.argtypes = [C.c_void_p]
+        _lib.orc_model_destroy.argtypes = [C.c_void_p]
+        _lib.orc_model_logp_const.argtypes = [C.c_void_p]
+        _lib.orc_model_logp_const.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
+
+
+class OracleModel(object):
+    """One model in the C oracle, built from the same raw inputs as the engine."""
+
+    def __init__(self, spec):
+        L = lib()
+        self.spec = spec
+        r = spec.raw
+        if spec.name == "radon":
+            county = np.ascontiguousarray(r["county"], np.int32)
+            u = np.ascontiguousarray(r["u"], np.float32)
+            x = np.ascontiguousarray(r["x"], np.float32)
+            y = np.ascontiguousarray(r["y"], np.float32)
+            self._h = C.c_void_p(L.orc_radon_create(len(y), len(u), _p(county), _p(u), _p(x), _p(y)))
+        else:
+            raise NotImplementedError(spec.name)
+        self.D = L.orc_model_dim(self._h)
+        assert self.D == spec.D
+
+    def __del__(self):
+        try:
+            lib().orc_model_destroy(self._h)
+        except Exception:
+            pass
+
+    def logp_const(self):
+        return lib().orc_model_logp_const(self._h)
+
+    @staticmethod
+    def _sfx(dtype):
+        return "_f32" if np.dtype(dtype) == np.float32 else "_f64"
+
+    def logp_grad(self, x, a, b, dtype=np.float64):
+        x = np.ascontiguousarray(x, dtype)
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        n = x.shape[0]
+        logp = np.empty(n, dtype); grad = np.empty_like(x)
+        getattr(lib(), "orc_logp_grad" + self._sfx(dtype))(self._h, _p(a), _p(b), _p(x), n, _p(logp), _p(grad))
+        return logp, grad
+
+    def transform(self, x, a, b, to_centered=True, dtype=np.float64):
+        x = np.ascontiguousarray(x, dtype)
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        out = np.empty_like(x)
+        getattr(lib(), "orc_transform" + self._sfx(dtype))(self._h, _p(a), _p(b), 0 if to_centered else 1,
+                                                         _p(x), x.shape[0], _p(out))
+        return out
+
+    def hmc_run(self, st, a, b, eps0, n_leapfrog, n_steps, seed=0, chain_offset=0, adapt_kind=0, n_adapt=0,
+                adapt_target=0.75, adapt_rate=0.05, n_burnin=0, thin=1, trace=None, trace_accept=None,
+                trace_centered=True, lanes=4):
+        """`st` is a dict with q, grad, logp, adapt, rng, accept_count (numpy, dtype of st['q']) and 'step'."""
+        dtype = st["q"].dtype
+        cfg = HmcCfg(st["q"].shape[0], n_leapfrog, n_steps, st["step"], chain_offset, seed, adapt_kind, n_adapt,
+                     adapt_target, adapt_rate, n_burnin, thin,
+                     trace.shape[0] if trace is not None else (trace_accept.shape[0] if trace_accept is not None else 0),
+                     1 if trace_centered else 0, lanes)
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        eps0 = np.ascontiguousarray(eps0, np.float32)
+        getattr(lib(), "orc_hmc_run" + self._sfx(dtype))(
+            self._h, _p(a), _p(b), C.byref(cfg), _p(st["q"]), _p(st["grad"]), _p(st["logp"]), _p(st["adapt"]),
+            _p(st["rng"]), _p(st["accept_count"]), _p(eps0), _p(trace), _p(trace_accept))
+        st["step"] += n_steps
+        return st
+
+
+def new_state(q, dtype=np.float64):
+    q = np.ascontiguousarray(q, dtype)
+    n = q.shape[0]
+    return dict(q=q.copy(), grad=np.zeros_like(q), logp=np.zeros(n, dtype), adapt=np.zeros((n, 4), dtype),
+                rng=np.zeros((n, 16, 4), np.uint32), accept_count=np.zeros(n, np.uint32), step=0)

@@ -1,0 +1,156 @@
+/*
+ * oracle.c -- CPU restatement (plain C99 + OpenMP over chains) of the hot path:
+ * per-model log joint + gradient under the general VIP parameterisation, the
+ * HMC transition, dual-averaging / simple step-size adaptation and the
+ * sample_chain trace schedule.
+ *
+ * TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg; the product path (autoreparam_amd/) never links
+ * or calls it.  PARITY UNPINNED (see oracle_impl.h).
+ *
+ * Reference files restated: models.py:131-166, 809-857, 884-923, 967-1008
+ * (densities), program_transformations.py:262-279, 555-600 (NCP / VIP algebra),
+ * inference.py:198-242 (HMC wiring, step scaling, thinning),
+ * interleaved.py:113-155 (interleaving order).  TFP internals (leapfrog,
+ * Metropolis, adaptation recurrences) are restated from the published
+ * algorithms; they are not under /root/reference.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct orc_model {
+  int model;       /* same ids as include/autoreparam.h */
+  int D;
+  int n_glob;      /* replicated top-level scalars (RNG stream layout) */
+  int n_groups;    /* sliced axis length (RNG stream layout) */
+  int glob_idx[8]; /* flattened index of each top-level scalar */
+  int* group_idx;  /* [n_groups] flattened index of group j, -1 if it has no latent */
+  /* radon sufficient statistics */
+  int J;
+  float *n, *sx, *sy, *u;
+  float sxy, sxx;
+  double logp_const;
+} orc_model;
+
+typedef struct orc_hmc_cfg {
+  int n_chains, n_leapfrog, n_steps;
+  long long step_base, chain_offset;
+  uint64_t seed;
+  int adapt_kind, n_adapt;
+  float adapt_target, adapt_rate;
+  int n_burnin, thin, n_samples, trace_centered;
+  int lanes;
+} orc_hmc_cfg;
+
+/* ---- RNG: xoshiro128++ streams seeded by Philox4x32-10 (DESIGN.md "Randomness") ---- */
+typedef struct { uint32_t s[4]; } orc_rng;
+
+static uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+
+static uint32_t orc_rng_next(orc_rng* r) {
+  uint32_t* s = r->s;
+  uint32_t result = rotl32(s[0] + s[3], 7) + s[0];
+  uint32_t t = s[1] << 9;
+  s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+  s[2] ^= t;
+  s[3] = rotl32(s[3], 11);
+  return result;
+}
+
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+static orc_rng orc_rng_seed(uint64_t seed, uint64_t chain, uint32_t slot, uint32_t lanes) {
+  uint32_t c[4] = {(uint32_t)chain, (uint32_t)(chain >> 32), slot, lanes};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  orc_rng r = {{c[0], c[1], c[2], c[3]}};
+  if ((c[0] | c[1] | c[2] | c[3]) == 0u) r.s[0] = 1u;
+  return r;
+}
+
+/* Box-Muller: u in (0,1] from the top 24 bits of w0, angle from the top 24 bits of w1 */
+static void orc_normal_pair(uint32_t w0, uint32_t w1, float* z0, float* z1) {
+  float u = (float)((w0 >> 8) + 1u) * 5.9604644775390625e-08f;
+  float rev = (float)(w1 >> 8) * 5.9604644775390625e-08f;
+  float r = sqrtf(-1.3862943611198906f * log2f(u));
+  float ang = 6.283185307179586f * rev;
+  *z0 = r * cosf(ang);
+  *z1 = r * sinf(ang);
+}
+
+/* exported for the RNG known-answer tests */
+void orc_philox(uint32_t ctr[4], uint32_t k0, uint32_t k1) { philox4x32_10(ctr, k0, k1); }
+void orc_stream(uint64_t seed, uint64_t chain, uint32_t slot, uint32_t lanes, int n, uint32_t* out) {
+  orc_rng r = orc_rng_seed(seed, chain, slot, lanes);
+  for (int i = 0; i < n; ++i) out[i] = orc_rng_next(&r);
+}
+void orc_normals(uint64_t seed, uint64_t chain, uint32_t slot, uint32_t lanes, int n_pairs, float* out) {
+  orc_rng r = orc_rng_seed(seed, chain, slot, lanes);
+  for (int i = 0; i < n_pairs; ++i) {
+    uint32_t w0 = orc_rng_next(&r), w1 = orc_rng_next(&r);
+    orc_normal_pair(w0, w1, &out[2 * i], &out[2 * i + 1]);
+  }
+}
+
+/* ---- model construction from the reference's raw inputs ---- */
+static const double HALF_LOG_2PI = 0.9189385332046727;
+
+orc_model* orc_radon_create(int N, int J, const int32_t* county, const float* u, const float* x,
+                            const float* y) {
+  orc_model* M = (orc_model*)calloc(1, sizeof(orc_model));
+  M->model = 1; M->J = J; M->D = 3 + J;
+  M->n_glob = 3; M->n_groups = J;
+  M->glob_idx[0] = 0; M->glob_idx[1] = 1; M->glob_idx[2] = 2;
+  M->group_idx = (int*)malloc(sizeof(int) * J);
+  M->n = (float*)calloc(J, sizeof(float)); M->sx = (float*)calloc(J, sizeof(float));
+  M->sy = (float*)calloc(J, sizeof(float)); M->u = (float*)calloc(J, sizeof(float));
+  double* n = (double*)calloc(J, sizeof(double));
+  double* sx = (double*)calloc(J, sizeof(double));
+  double* sy = (double*)calloc(J, sizeof(double));
+  double sxy = 0, sxx = 0, syy = 0;
+  for (int i = 0; i < N; ++i) {
+    int j = county[i];
+    sxy += (double)x[i] * y[i]; sxx += (double)x[i] * x[i]; syy += (double)y[i] * y[i];
+    if (j < 0 || j >= J) continue; /* tf.one_hot: all-zero row, models.py:834 */
+    n[j] += 1; sx[j] += x[i]; sy[j] += y[i];
+  }
+  for (int j = 0; j < J; ++j) {
+    M->group_idx[j] = 3 + j;
+    M->n[j] = (float)n[j]; M->sx[j] = (float)sx[j]; M->sy[j] = (float)sy[j]; M->u[j] = u[j];
+  }
+  M->sxy = (float)sxy; M->sxx = (float)sxx;
+  M->logp_const = -(3.0 + J + N) * HALF_LOG_2PI - 0.5 * syy;
+  free(n); free(sx); free(sy);
+  return M;
+}
+
+void orc_model_destroy(orc_model* M) {
+  if (!M) return;
+  free(M->group_idx); free(M->n); free(M->sx); free(M->sy); free(M->u);
+  free(M);
+}
+int orc_model_dim(const orc_model* M) { return M->D; }
+double orc_model_logp_const(const orc_model* M) { return M->logp_const; }
+
+#define REAL float
+#define FN(x) x##_f32
+#include "oracle_impl.h"
+#undef REAL
+#undef FN
+#define REAL double
+#define FN(x) x##_f64
+#include "oracle_impl.h"
+#undef REAL
+#undef FN
