@@ -41,15 +41,21 @@ static const LaneOps* pick(const std::vector<LaneOps>& ops, int groups, int K_re
 static const std::vector<LaneOps>* family(const arp_model* m) {
   switch (m->model) {
     case ARP_MODEL_RADON: return &radon_ops();
+    case ARP_MODEL_EIGHT_SCHOOLS: return &schools_ops();
+    case ARP_MODEL_ELECTION: return &election_ops();
     default: return nullptr;
   }
 }
 static const void* family_args(const arp_model* m) {
   switch (m->model) {
     case ARP_MODEL_RADON: return &m->radon;
+    case ARP_MODEL_EIGHT_SCHOOLS: return &m->schools;
+    case ARP_MODEL_ELECTION: return &m->election;
     default: return nullptr;
   }
 }
+
+static int upload_tables(arp_model* m);
 
 static int build_radon(arp_model* m, const arp_dataset* d) {
   const int J = d->n_groups, N = d->n_obs;
@@ -77,9 +83,7 @@ static int build_radon(arp_model* m, const arp_dataset* d) {
     m->host_tables[2 * J + j] = (float)sy[j];
     m->host_tables[3 * J + j] = d->u_host[j];
   }
-  ARP_HIP_OK(hipMalloc(&m->dev_tables, m->host_tables.size() * sizeof(float)));
-  ARP_HIP_OK(hipMemcpy(m->dev_tables, m->host_tables.data(), m->host_tables.size() * sizeof(float),
-                       hipMemcpyHostToDevice));
+  if (upload_tables(m)) return 1;
   m->radon.n = m->dev_tables;
   m->radon.sx = m->dev_tables + J;
   m->radon.sy = m->dev_tables + 2 * J;
@@ -88,8 +92,61 @@ static int build_radon(arp_model* m, const arp_dataset* d) {
   m->radon.sxx = (float)sxx;
   m->radon.J = J;
   // every Normal has unit scale under every (a,b): const = -(3+J+N) 0.5 log 2pi - 0.5 Syy
-  double c = -(3.0 + J + N) * kHalfLog2Pi - 0.5 * syy;
-  m->logp_const[0] = m->logp_const[1] = c;
+  m->const_base = -(3.0 + J + N) * kHalfLog2Pi - 0.5 * syy;
+  return 0;
+}
+
+static int upload_tables(arp_model* m) {
+  ARP_HIP_OK(hipMalloc(&m->dev_tables, m->host_tables.size() * sizeof(float)));
+  ARP_HIP_OK(hipMemcpy(m->dev_tables, m->host_tables.data(), m->host_tables.size() * sizeof(float),
+                       hipMemcpyHostToDevice));
+  return 0;
+}
+
+// reference models.py:131-147: y_host = effects, u_host = stddevs
+static int build_schools(arp_model* m, const arp_dataset* d) {
+  if (!d->y_host || !d->u_host) { set_error("8schools: y (effects) and u (stddevs) are required"); return 1; }
+  m->D = 10; m->n_groups = 8;
+  m->host_tables.assign(d->y_host, d->y_host + 8);
+  m->host_tables.insert(m->host_tables.end(), d->u_host, d->u_host + 8);
+  if (upload_tables(m)) return 1;
+  m->schools.y = m->dev_tables;
+  m->schools.sigma = m->dev_tables + 8;
+  double c = -18.0 * kHalfLog2Pi;
+  for (int k = 0; k < 8; ++k) c -= log((double)d->u_host[k]);
+  m->const_base = c;
+  m->top_scale = {{0, log(5.0)}, {1, log(5.0)}};
+  return 0;
+}
+
+// reference models.py:967-989: group = 1-based state fed to tf.one_hot(., S); x = female, x2 = black
+static int build_election(arp_model* m, const arp_dataset* d) {
+  const int S = d->n_groups, N = d->n_obs;
+  if (!d->group_host || !d->x_host || !d->x2_host || !d->y_host || S <= 0 || N <= 0) {
+    set_error("election: group/x(female)/x2(black)/y and n_groups/n_obs are required");
+    return 1;
+  }
+  m->D = S + 4; m->n_groups = S + 1;
+  std::vector<double> cn((size_t)(S + 1) * 4, 0.0), cy((size_t)(S + 1) * 4, 0.0);
+  for (int i = 0; i < N; ++i) {
+    int t = d->group_host[i];
+    if (t < 0 || t >= S) t = S;  // all-zero one-hot row: no state effect
+    int c = (d->x_host[i] != 0.0f ? 1 : 0) + (d->x2_host[i] != 0.0f ? 2 : 0);
+    if ((d->x_host[i] != 0.0f && d->x_host[i] != 1.0f) || (d->x2_host[i] != 0.0f && d->x2_host[i] != 1.0f)) {
+      set_error("election: female/black must be 0/1 indicators for the cell collapse");
+      return 1;
+    }
+    cn[(size_t)t * 4 + c] += 1.0;
+    cy[(size_t)t * 4 + c] += d->y_host[i];
+  }
+  m->host_tables.resize(cn.size() * 2);
+  for (size_t i = 0; i < cn.size(); ++i) { m->host_tables[i] = (float)cn[i]; m->host_tables[cn.size() + i] = (float)cy[i]; }
+  if (upload_tables(m)) return 1;
+  m->election.cell_n = m->dev_tables;
+  m->election.cell_y = m->dev_tables + cn.size();
+  m->election.S = S;
+  m->const_base = -(4.0 + S) * kHalfLog2Pi;
+  m->top_scale = {{0, log(100.0)}, {1, log(10.0)}, {2 + S, log(100.0)}, {3 + S, log(100.0)}};
   return 0;
 }
 
@@ -110,6 +167,8 @@ int arp_model_create(const arp_dataset* data, arp_model** out) {
   int rc;
   switch (data->model) {
     case ARP_MODEL_RADON: rc = build_radon(m.get(), data); break;
+    case ARP_MODEL_EIGHT_SCHOOLS: rc = build_schools(m.get(), data); break;
+    case ARP_MODEL_ELECTION: rc = build_election(m.get(), data); break;
     default: set_error("arp_model_create: unknown model id"); return 1;
   }
   if (rc) return rc;
@@ -141,6 +200,10 @@ int arp_model_set_param(arp_model* m, int which, const float* a_host, const floa
   ARP_HIP_OK(hipMemcpy(m->dev_ab[which], a_host, m->D * sizeof(float), hipMemcpyHostToDevice));
   ARP_HIP_OK(hipMemcpy(m->dev_ab[which] + m->D, b_host, m->D * sizeof(float), hipMemcpyHostToDevice));
   m->has_param[which] = true;
+  // dropped constant: -sum_i b_i log(prior scale_i) over the top-level latents, plus the base
+  double c = m->const_base;
+  for (const auto& ts : m->top_scale) c -= (double)b_host[ts.first] * ts.second;
+  m->logp_const[which] = c;
   return 0;
 }
 

@@ -4,10 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <utility>
 #include <vector>
 #include "../../include/autoreparam.h"
 #include "kernels.h"
 #include "model_radon.h"
+#include "model_schools.h"
+#include "model_election.h"
 
 namespace arp {
 
@@ -54,6 +57,8 @@ struct Launch {
 
 // per-family tables (defined in inst_*.hip)
 const std::vector<LaneOps>& radon_ops();
+const std::vector<LaneOps>& schools_ops();
+const std::vector<LaneOps>& election_ops();
 
 }  // namespace arp
 
@@ -67,5 +72,9 @@ struct arp_model {
   bool has_param[2] = {false, false};
   double logp_const[2] = {0.0, 0.0};
   arp::RadonArgs radon{};
+  arp::SchoolsArgs schools{};
+  arp::ElectionArgs election{};
   std::vector<float> host_tables;
+  double const_base = 0.0;                       // parameterisation independent part of the dropped constant
+  std::vector<std::pair<int, double>> top_scale; // (flattened index, log prior scale) of top-level latents
 };

@@ -37,7 +37,7 @@ struct HmcParams {
 template <class Lane>
 ARP_DEV void load_row(const Lane& M, const float* __restrict__ row, float (&v)[Lane::ND]) {
 #pragma unroll
-  for (int i = 0; i < Lane::NG; ++i) v[i] = row[Lane::gg(i)];
+  for (int i = 0; i < Lane::NG; ++i) v[i] = row[M.gg(i)];
   const float* lb = row + Lane::LBASE + M.slot;
 #pragma unroll
   for (int i = 0; i < Lane::NL; ++i) v[Lane::NG + i] = (i < M.nloc) ? lb[Lane::K * i] : 0.0f;
@@ -46,7 +46,7 @@ template <class Lane>
 ARP_DEV void store_row(const Lane& M, float* __restrict__ row, const float (&v)[Lane::ND], bool live) {
   if (live && M.slot == 0) {
 #pragma unroll
-    for (int i = 0; i < Lane::NG; ++i) row[Lane::gg(i)] = v[i];
+    for (int i = 0; i < Lane::NG; ++i) row[M.gg(i)] = v[i];
   }
   float* lb = row + Lane::LBASE + M.slot;
 #pragma unroll

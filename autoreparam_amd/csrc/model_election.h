@@ -1,0 +1,138 @@
+// Election88 hierarchical logistic regression (reference models.py:967-1008)
+// under the general VIP parameterisation, with the 11 566 Bernoulli observations
+// collapsed to (state, female, black) cells (n = observations, y = ones).
+// Parts in trace order: mua, log_sigma_a, a[S], b1, b2.
+//
+//   mua ~ N(0,100), lsa ~ N(0,10), b1, b2 ~ N(0,100)   top level: xt ~ N(0, s^b), x = s^(1-b) xt
+//   a_t ~ N(mua, sigma), sigma = exp(lsa):
+//       at_t ~ N(al_t mua, sigma^be_t), z_t = (at_t - al_t mua) exp(-be_t lsa), a_t = mua + sigma z_t
+//   y_i ~ Bernoulli(logit = a[state_i] + female_i b2 + black_i b1)
+// The reference feeds the 1-based state index to tf.one_hot(., S): index t uses
+// column t for t < S and index S hits an all-zero row, so those observations have
+// no state effect (group S below: cells only, no latent).  SURVEY.md 8c-(i).
+#pragma once
+#include "arp_device.h"
+
+namespace arp {
+
+struct ElectionArgs {
+  const float* cell_n;  // [S+1][4] cell index = female + 2*black
+  const float* cell_y;  // [S+1][4]
+  int S;
+};
+
+template <int K_, int NL_>
+struct ElectionLane {
+  static constexpr int K = K_;
+  static constexpr int NG = 4;   // mua, lsa, b1, b2
+  static constexpr int NL = NL_; // groups owned by this lane: t = slot + K*i, t <= S
+  static constexpr int ND = NG + NL;
+  static constexpr int LBASE = 2;
+  using Args = ElectionArgs;
+
+  float cn[NL][4], cy[NL][4], al[NL], be[NL], lat[NL];
+  float si[4], cs[4];   // 1/s^b and s^(1-b) for mua, lsa, b1, b2
+  int nloc, slot, ndraw, S;
+
+  // flattened index of replicated global i (b1 -> 2+S, b2 -> 3+S: S is a run-time value)
+  int gmap[NG];
+  ARP_DEV int gg(int i) const { return gmap[i]; }
+
+  ARP_DEV void init(const Args& A, const float* av, const float* bv, int slot_) {
+    slot = slot_;
+    S = A.S;
+    nloc = (S - slot + K - 1) / K;       // latents: t < S
+    if (nloc < 0) nloc = 0;
+    ndraw = NG + (S + 1 + K - 1) / K;    // RNG layout counts the S+1 groups
+    gmap[0] = 0; gmap[1] = 1; gmap[2] = 2 + S; gmap[3] = 3 + S;
+    const float l100 = 6.643856189774724f, l10 = 3.321928094887362f;  // log2
+    const float lg[4] = {l100, l10, l100, l100};
+    const float sc[4] = {100.0f, 10.0f, 100.0f, 100.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      si[i] = __builtin_amdgcn_exp2f(-bv[gmap[i]] * lg[i]);
+      cs[i] = sc[i] * si[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      int t = slot + K * i;
+      bool cell = t <= S, has = t < S;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        cn[i][c] = cell ? A.cell_n[t * 4 + c] : 0.0f;
+        cy[i][c] = cell ? A.cell_y[t * 4 + c] : 0.0f;
+      }
+      al[i] = has ? av[LBASE + t] : 0.0f;
+      be[i] = has ? bv[LBASE + t] : 0.0f;
+      lat[i] = has ? 1.0f : 0.0f;
+    }
+  }
+
+  template <bool LOGP>
+  ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const {
+    const float mua = cs[0] * q[0], ls = cs[1] * q[1], b1 = cs[2] * q[2], b2 = cs[3] * q[3];
+    const float sig = fast_exp(ls);
+    float g_mua = 0.0f, g_ls = 0.0f, g_b1 = 0.0f, g_b2 = 0.0f, lp = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float e = fast_exp(-be[i] * ls);
+      float z = (q[NG + i] - al[i] * mua) * e;      // group S / padding: q = 0, al = 0 -> z = 0
+      float as = lat[i] * fmaf(sig, z, mua);
+      const float eta[4] = {as, as + b2, as + b1, as + b1 + b2};
+      float w[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        // sigmoid / softplus share exp(-|eta|)
+        float ex = fast_exp(-fabsf(eta[c]));
+        float rc = __builtin_amdgcn_rcpf(1.0f + ex);
+        float sg = eta[c] >= 0.0f ? rc : ex * rc;
+        w[c] = fmaf(-cn[i][c], sg, cy[i][c]);
+        if (LOGP) {
+          float sp = fmaxf(eta[c], 0.0f) + fast_log(1.0f + ex);
+          lp += fmaf(cy[i][c], eta[c], -cn[i][c] * sp);
+        }
+      }
+      float W = (w[0] + w[1]) + (w[2] + w[3]);
+      g_b2 += w[1] + w[3];
+      g_b1 += w[2] + w[3];
+      float gt = lat[i] * e * fmaf(sig, W, -z);
+      g[NG + i] = gt;
+      g_mua += lat[i] * fmaf(-al[i], gt, W);
+      g_ls += fmaf(be[i], fmaf(z, z, -1.0f), lat[i] * W * sig * z * (1.0f - be[i]));
+      if (LOGP) lp += fmaf(-0.5f * z, z, -be[i] * ls);
+    }
+    g_mua = group_sum<K>(g_mua);
+    g_ls = group_sum<K>(g_ls);
+    g_b1 = group_sum<K>(g_b1);
+    g_b2 = group_sum<K>(g_b2);
+    float u[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = q[i] * si[i];
+    g[0] = fmaf(cs[0], g_mua, -u[0] * si[0]);
+    g[1] = fmaf(cs[1], g_ls, -u[1] * si[1]);
+    g[2] = fmaf(cs[2], g_b1, -u[2] * si[2]);
+    g[3] = fmaf(cs[3], g_b2, -u[3] * si[3]);
+    if (LOGP) {
+      lp = group_sum<K>(lp);
+      lp += -0.5f * (u[0] * u[0] + u[1] * u[1] + u[2] * u[2] + u[3] * u[3]);
+    }
+    return lp;
+  }
+
+  ARP_DEV void to_centered(const float (&q)[ND], float (&x)[ND]) const {
+    const float mua = cs[0] * q[0], ls = cs[1] * q[1];
+    x[0] = mua; x[1] = ls; x[2] = cs[2] * q[2]; x[3] = cs[3] * q[3];
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      x[NG + i] = fmaf(fast_exp((1.0f - be[i]) * ls), q[NG + i] - al[i] * mua, mua);
+  }
+  ARP_DEV void from_centered(const float (&x)[ND], float (&q)[ND]) const {
+    const float mua = x[0], ls = x[1];
+    q[0] = mua / cs[0]; q[1] = ls / cs[1]; q[2] = x[2] / cs[2]; q[3] = x[3] / cs[3];
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      q[NG + i] = (i < nloc) ? fmaf(x[NG + i] - mua, fast_exp(-(1.0f - be[i]) * ls), al[i] * mua) : 0.0f;
+  }
+};
+
+}  // namespace arp

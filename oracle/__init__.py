@@ -34,7 +34,8 @@ def lib():
         if not os.path.exists(LIB_PATH):
             build()
         _lib = C.CDLL(LIB_PATH)
-        _lib.orc_radon_create.restype = C.c_void_p
+        for f in ("orc_radon_create", "orc_schools_create", "orc_election_create", "orc_german_create"):
+            getattr(_lib, f).restype = C.c_void_p
         _lib.orc_model_dim.argtypes = [C.c_void_p]
         _lib.orc_model_destroy.argtypes = [C.c_void_p]
         _lib.orc_model_logp_const.argtypes = [C.c_void_p]
@@ -59,6 +60,17 @@ class OracleModel(object):
             x = np.ascontiguousarray(r["x"], np.float32)
             y = np.ascontiguousarray(r["y"], np.float32)
             self._h = C.c_void_p(L.orc_radon_create(len(y), len(u), _p(county), _p(u), _p(x), _p(y)))
+        elif spec.name == "8schools":
+            y = np.ascontiguousarray(r["y"], np.float32); sg = np.ascontiguousarray(r["sigma"], np.float32)
+            self._h = C.c_void_p(L.orc_schools_create(_p(y), _p(sg)))
+        elif spec.name == "election":
+            st = np.ascontiguousarray(r["state"], np.int32)
+            f = np.ascontiguousarray(r["female"], np.float32); k = np.ascontiguousarray(r["black"], np.float32)
+            y = np.ascontiguousarray(r["y"], np.float32)
+            self._h = C.c_void_p(L.orc_election_create(len(y), int(r["n_state"]), _p(st), _p(f), _p(k), _p(y)))
+        elif spec.name == "german_credit_lognormalcentered":
+            X = np.ascontiguousarray(r["X"], np.float32); y = np.ascontiguousarray(r["y"], np.float32)
+            self._h = C.c_void_p(L.orc_german_create(X.shape[0], X.shape[1], _p(X), _p(y)))
         else:
             raise NotImplementedError(spec.name)
         self.D = L.orc_model_dim(self._h)
@@ -70,8 +82,17 @@ class OracleModel(object):
         except Exception:
             pass
 
-    def logp_const(self):
-        return lib().orc_model_logp_const(self._h)
+    def logp_const(self, b=None):
+        """Constant dropped from logp: value under CP, or under parameterisation b ([D])
+        (the only (a,b)-dependent part is -b_i log(scale_i) of the top-level latents)."""
+        c = lib().orc_model_logp_const(self._h)
+        if b is None:
+            return c
+        S = self.D - 4
+        top = {"8schools": [(0, 5.0), (1, 5.0)], "radon": [],
+               "german_credit_lognormalcentered": [(0, 10.0)],
+               "election": [(0, 100.0), (1, 10.0), (2 + S, 100.0), (3 + S, 100.0)]}[self.spec.name]
+        return c + sum((1.0 - float(b[i])) * np.log(s) for i, s in top)
 
     @staticmethod
     def _sfx(dtype):

@@ -25,13 +25,18 @@ typedef struct orc_model {
   int D;
   int n_glob;      /* replicated top-level scalars (RNG stream layout) */
   int n_groups;    /* sliced axis length (RNG stream layout) */
+  int n_local_parts; /* latent parts sliced along that axis (german: beta_log_scales and beta) */
   int glob_idx[8]; /* flattened index of each top-level scalar */
-  int* group_idx;  /* [n_groups] flattened index of group j, -1 if it has no latent */
+  int* group_idx;  /* [n_local_parts][n_groups] flattened index of element j, -1 if it has no latent */
   /* radon sufficient statistics */
   int J;
   float *n, *sx, *sy, *u;
   float sxy, sxx;
-  double logp_const;
+  /* schools: u = treatment stddevs, y = effects.  german: X [N][F], y [N].
+   * election: cell tables [(S+1)][4] indexed (state, female + 2*black). */
+  int S, F, N;
+  float *y, *X, *cell_n, *cell_y;
+  double logp_const;   /* value dropped from logp under CP (tests add the (a,b)-dependent part) */
 } orc_model;
 
 typedef struct orc_hmc_cfg {
@@ -111,7 +116,7 @@ orc_model* orc_radon_create(int N, int J, const int32_t* county, const float* u,
                             const float* y) {
   orc_model* M = (orc_model*)calloc(1, sizeof(orc_model));
   M->model = 1; M->J = J; M->D = 3 + J;
-  M->n_glob = 3; M->n_groups = J;
+  M->n_glob = 3; M->n_groups = J; M->n_local_parts = 1;
   M->glob_idx[0] = 0; M->glob_idx[1] = 1; M->glob_idx[2] = 2;
   M->group_idx = (int*)malloc(sizeof(int) * J);
   M->n = (float*)calloc(J, sizeof(float)); M->sx = (float*)calloc(J, sizeof(float));
@@ -136,9 +141,58 @@ orc_model* orc_radon_create(int N, int J, const int32_t* county, const float* u,
   return M;
 }
 
+orc_model* orc_schools_create(const float* y, const float* sigma) {
+  orc_model* M = (orc_model*)calloc(1, sizeof(orc_model));
+  M->model = 0; M->D = 10; M->n_glob = 2; M->n_groups = 8; M->n_local_parts = 1;
+  M->glob_idx[0] = 0; M->glob_idx[1] = 1;
+  M->group_idx = (int*)malloc(sizeof(int) * 8);
+  M->u = (float*)malloc(sizeof(float) * 8); M->y = (float*)malloc(sizeof(float) * 8);
+  double c = -18.0 * HALF_LOG_2PI - 2.0 * log(5.0);
+  for (int k = 0; k < 8; ++k) { M->group_idx[k] = 2 + k; M->u[k] = sigma[k]; M->y[k] = y[k]; c -= log((double)sigma[k]); }
+  M->logp_const = c;
+  return M;
+}
+
+orc_model* orc_election_create(int N, int S, const int32_t* state, const float* female,
+                               const float* black, const float* y) {
+  orc_model* M = (orc_model*)calloc(1, sizeof(orc_model));
+  M->model = 3; M->S = S; M->N = N; M->D = S + 4;
+  M->n_glob = 4; M->n_groups = S + 1; M->n_local_parts = 1;
+  M->glob_idx[0] = 0; M->glob_idx[1] = 1; M->glob_idx[2] = 2 + S; M->glob_idx[3] = 3 + S;
+  M->group_idx = (int*)malloc(sizeof(int) * (S + 1));
+  for (int t = 0; t < S; ++t) M->group_idx[t] = 2 + t;
+  M->group_idx[S] = -1;
+  M->cell_n = (float*)calloc((size_t)(S + 1) * 4, sizeof(float));
+  M->cell_y = (float*)calloc((size_t)(S + 1) * 4, sizeof(float));
+  for (int i = 0; i < N; ++i) {
+    int t = state[i];
+    if (t < 0 || t >= S) t = S;                 /* tf.one_hot zero row, models.py:978 */
+    int fk = (female[i] != 0.0f ? 1 : 0) + (black[i] != 0.0f ? 2 : 0);
+    M->cell_n[t * 4 + fk] += 1.0f;
+    M->cell_y[t * 4 + fk] += y[i];
+  }
+  M->logp_const = -(4.0 + S) * HALF_LOG_2PI - 3.0 * log(100.0) - log(10.0);
+  return M;
+}
+
+orc_model* orc_german_create(int N, int F, const float* X, const float* y) {
+  orc_model* M = (orc_model*)calloc(1, sizeof(orc_model));
+  M->model = 2; M->N = N; M->F = F; M->D = 1 + 2 * F;
+  /* RNG stream layout: overall_log_scale is the top-level scalar; feature d owns
+   * beta_log_scales[d] and beta[d] (two sliced parts, see draw_momentum) */
+  M->n_glob = 1; M->n_groups = F; M->n_local_parts = 2; M->glob_idx[0] = 0;
+  M->group_idx = (int*)malloc(sizeof(int) * 2 * F);
+  for (int d = 0; d < F; ++d) { M->group_idx[d] = 1 + d; M->group_idx[F + d] = 1 + F + d; }
+  M->X = (float*)malloc(sizeof(float) * (size_t)N * F); memcpy(M->X, X, sizeof(float) * (size_t)N * F);
+  M->y = (float*)malloc(sizeof(float) * N); memcpy(M->y, y, sizeof(float) * N);
+  M->logp_const = -(1.0 + 2.0 * F) * HALF_LOG_2PI - log(10.0);
+  return M;
+}
+
 void orc_model_destroy(orc_model* M) {
   if (!M) return;
   free(M->group_idx); free(M->n); free(M->sx); free(M->sy); free(M->u);
+  free(M->y); free(M->X); free(M->cell_n); free(M->cell_y);
   free(M);
 }
 int orc_model_dim(const orc_model* M) { return M->D; }

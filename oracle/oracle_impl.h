@@ -71,22 +71,219 @@ static void FN(radon_from_centered)(const orc_model* M, const float* a, const fl
   }
 }
 
+
+/* A group of Normal latents with a shared location parent `loc` and a shared
+ * log-scale parent `ls` (8 schools' theta, election's a):
+ *   xt_k ~ N(a_k loc, exp(b_k ls)),  x_k = loc + exp(ls) z_k,  z_k = (xt_k - a_k loc) exp(-b_k ls).
+ * Given w_k = d loglik / d x_k it adds the prior + chain-rule terms:
+ *   d/dxt_k = e_k (sigma w_k - z_k),  d/dloc += w_k - a_k d/dxt_k,
+ *   d/dls  += b_k z_k^2 - b_k + w_k sigma z_k (1 - b_k),  logp += -z_k^2/2 - b_k ls.   */
+
+/* eight schools, reference models.py:139-147.  Parts: mu, log_tau, theta[8]. */
+static REAL FN(schools_logp_grad)(const orc_model* M, const float* a, const float* b,
+                                  const REAL* x, REAL* g) {
+  const REAL s0 = (REAL)pow(5.0, (double)b[0]), s1 = (REAL)pow(5.0, (double)b[1]);
+  const REAL c0 = 5 / s0, c1 = 5 / s1;
+  const REAL mu = c0 * x[0], lt = c1 * x[1];
+  const REAL tau = (REAL)exp((double)lt);
+  REAL lp = -(REAL)0.5 * (x[0] / s0) * (x[0] / s0) - (REAL)0.5 * (x[1] / s1) * (x[1] / s1);
+  REAL g_mu = 0, g_lt = 0;
+  for (int k = 0; k < 8; ++k) {
+    const REAL ak = a[2 + k], bk = b[2 + k];
+    const REAL e = (REAL)exp((double)(-bk * lt));
+    const REAL z = (x[2 + k] - ak * mu) * e;
+    const REAL th = mu + tau * z;
+    const REAL sg = M->u[k];                       /* treatment stddev */
+    const REAL w = ((REAL)M->y[k] - th) / (sg * sg);
+    lp += -(REAL)0.5 * z * z - bk * lt - (REAL)0.5 * ((REAL)M->y[k] - th) * ((REAL)M->y[k] - th) / (sg * sg);
+    const REAL gk = e * (tau * w - z);
+    g[2 + k] = gk;
+    g_mu += w - ak * gk;
+    g_lt += bk * z * z - bk + w * tau * z * (1 - bk);
+  }
+  g[0] = -x[0] / (s0 * s0) + c0 * g_mu;
+  g[1] = -x[1] / (s1 * s1) + c1 * g_lt;
+  return lp;
+}
+static void FN(schools_convert)(const orc_model* M, const float* a, const float* b, const REAL* x,
+                                REAL* out, int to_centered) {
+  (void)M;
+  const REAL c0 = (REAL)pow(5.0, 1.0 - (double)b[0]), c1 = (REAL)pow(5.0, 1.0 - (double)b[1]);
+  if (to_centered) {
+    const REAL mu = c0 * x[0], lt = c1 * x[1];
+    out[0] = mu; out[1] = lt;
+    for (int k = 0; k < 8; ++k)
+      out[2 + k] = mu + (REAL)exp((double)((1 - b[2 + k]) * lt)) * (x[2 + k] - a[2 + k] * mu);
+  } else {
+    const REAL mu = x[0], lt = x[1];
+    out[0] = mu / c0; out[1] = lt / c1;
+    for (int k = 0; k < 8; ++k)
+      out[2 + k] = a[2 + k] * mu + (x[2 + k] - mu) * (REAL)exp((double)(-(1 - b[2 + k]) * lt));
+  }
+}
+
+/* election, reference models.py:969-982.  Parts: mua, log_sigma_a, a[S], b1, b2.
+ * Likelihood collapsed to (state, female, black) cells: cell (t, f, k) holds
+ * n = #observations and y = #ones; t is the reference's 1-based state index used
+ * as a 0-based one-hot column, so t = S has no `a` term (tf.one_hot zero row). */
+static REAL FN(election_logp_grad)(const orc_model* M, const float* a, const float* b,
+                                   const REAL* x, REAL* g) {
+  const int S = M->S;
+  const int iB1 = 2 + S, iB2 = 3 + S;
+  const REAL s0 = (REAL)pow(100.0, (double)b[0]), s1 = (REAL)pow(10.0, (double)b[1]);
+  const REAL sb1 = (REAL)pow(100.0, (double)b[iB1]), sb2 = (REAL)pow(100.0, (double)b[iB2]);
+  const REAL c0 = 100 / s0, c1 = 10 / s1, cb1 = 100 / sb1, cb2 = 100 / sb2;
+  const REAL mua = c0 * x[0], ls = c1 * x[1], b1 = cb1 * x[iB1], b2 = cb2 * x[iB2];
+  const REAL sig = (REAL)exp((double)ls);
+  REAL lp = -(REAL)0.5 * ((x[0] / s0) * (x[0] / s0) + (x[1] / s1) * (x[1] / s1) +
+                          (x[iB1] / sb1) * (x[iB1] / sb1) + (x[iB2] / sb2) * (x[iB2] / sb2));
+  REAL g_mua = 0, g_ls = 0, g_b1 = 0, g_b2 = 0;
+  for (int t = 0; t <= S; ++t) {               /* t == S: observations without a state effect */
+    REAL as = 0, z = 0, e = 0, at = 0, bt = 0;
+    if (t < S) {
+      at = a[2 + t]; bt = b[2 + t];
+      e = (REAL)exp((double)(-bt * ls));
+      z = (x[2 + t] - at * mua) * e;
+      as = mua + sig * z;
+    }
+    REAL W = 0;
+    for (int fk = 0; fk < 4; ++fk) {
+      const REAL n = M->cell_n[t * 4 + fk], y = M->cell_y[t * 4 + fk];
+      if (n == 0) continue;
+      const REAL f = (REAL)(fk & 1), k = (REAL)(fk >> 1);
+      const REAL eta = as + f * b2 + k * b1;
+      const REAL sp = (eta > 0 ? eta : 0) + (REAL)log1p(exp(-fabs((double)eta)));
+      const REAL sgm = (REAL)(1.0 / (1.0 + exp(-(double)eta)));
+      lp += y * eta - n * sp;
+      const REAL w = y - n * sgm;
+      W += w; g_b2 += f * w; g_b1 += k * w;
+    }
+    if (t < S) {
+      lp += -(REAL)0.5 * z * z - bt * ls;
+      const REAL gt = e * (sig * W - z);
+      g[2 + t] = gt;
+      g_mua += W - at * gt;
+      g_ls += bt * z * z - bt + W * sig * z * (1 - bt);
+    }
+  }
+  g[0] = -x[0] / (s0 * s0) + c0 * g_mua;
+  g[1] = -x[1] / (s1 * s1) + c1 * g_ls;
+  g[iB1] = -x[iB1] / (sb1 * sb1) + cb1 * g_b1;
+  g[iB2] = -x[iB2] / (sb2 * sb2) + cb2 * g_b2;
+  return lp;
+}
+static void FN(election_convert)(const orc_model* M, const float* a, const float* b, const REAL* x,
+                                 REAL* out, int to_centered) {
+  const int S = M->S, iB1 = 2 + S, iB2 = 3 + S;
+  const REAL c0 = (REAL)pow(100.0, 1.0 - (double)b[0]), c1 = (REAL)pow(10.0, 1.0 - (double)b[1]);
+  const REAL cb1 = (REAL)pow(100.0, 1.0 - (double)b[iB1]), cb2 = (REAL)pow(100.0, 1.0 - (double)b[iB2]);
+  if (to_centered) {
+    const REAL mua = c0 * x[0], ls = c1 * x[1];
+    out[0] = mua; out[1] = ls; out[iB1] = cb1 * x[iB1]; out[iB2] = cb2 * x[iB2];
+    for (int t = 0; t < S; ++t)
+      out[2 + t] = mua + (REAL)exp((double)((1 - b[2 + t]) * ls)) * (x[2 + t] - a[2 + t] * mua);
+  } else {
+    const REAL mua = x[0], ls = x[1];
+    out[0] = mua / c0; out[1] = ls / c1; out[iB1] = x[iB1] / cb1; out[iB2] = x[iB2] / cb2;
+    for (int t = 0; t < S; ++t)
+      out[2 + t] = a[2 + t] * mua + (x[2 + t] - mua) * (REAL)exp((double)(-(1 - b[2 + t]) * ls));
+  }
+}
+
+/* german_credit_lognormalcentered, reference models.py:888-904.
+ * Parts: overall_log_scale, beta_log_scales[F], beta[F]; logits = X beta. */
+static REAL FN(german_logp_grad)(const orc_model* M, const float* a, const float* b,
+                                 const REAL* x, REAL* g) {
+  const int F = M->F, N = M->N;
+  const REAL s0 = (REAL)pow(10.0, (double)b[0]), c0 = 10 / s0;
+  const REAL ols = c0 * x[0];
+  REAL lp = -(REAL)0.5 * (x[0] / s0) * (x[0] / s0);
+  REAL* beta = (REAL*)malloc(sizeof(REAL) * 2 * (size_t)F);
+  REAL* v = beta + F;
+  for (int d = 0; d < F; ++d) {
+    const REAL ad = a[1 + d];
+    const REAL r = x[1 + d] - ad * ols;
+    const REAL bls = r + ols;
+    const REAL bd = b[1 + F + d];
+    beta[d] = (REAL)exp((double)((1 - bd) * bls)) * x[1 + F + d];
+    v[d] = 0;
+    lp += -(REAL)0.5 * r * r;
+  }
+  for (int n = 0; n < N; ++n) {
+    const float* row = M->X + (size_t)n * F;
+    REAL eta = 0;
+    for (int d = 0; d < F; ++d) eta += (REAL)row[d] * beta[d];
+    const REAL sp = (eta > 0 ? eta : 0) + (REAL)log1p(exp(-fabs((double)eta)));
+    const REAL sgm = (REAL)(1.0 / (1.0 + exp(-(double)eta)));
+    const REAL yn = M->y[n];
+    lp += yn * eta - sp;
+    const REAL w = yn - sgm;
+    for (int d = 0; d < F; ++d) v[d] += (REAL)row[d] * w;
+  }
+  REAL g_ols = 0;
+  for (int d = 0; d < F; ++d) {
+    const REAL ad = a[1 + d], bd = b[1 + F + d];
+    const REAL r = x[1 + d] - ad * ols;
+    const REAL bls = r + ols;
+    const REAL e = (REAL)exp((double)(-bd * bls));
+    const REAL zb = x[1 + F + d] * e;
+    lp += -(REAL)0.5 * zb * zb - bd * bls;
+    g[1 + F + d] = -zb * e + v[d] * (REAL)exp((double)((1 - bd) * bls));
+    const REAL hb = bd * zb * zb - bd + v[d] * (1 - bd) * beta[d];
+    g[1 + d] = hb - r;
+    g_ols += ad * r + (1 - ad) * hb;
+  }
+  g[0] = -x[0] / (s0 * s0) + c0 * g_ols;
+  free(beta);
+  return lp;
+}
+static void FN(german_convert)(const orc_model* M, const float* a, const float* b, const REAL* x,
+                               REAL* out, int to_centered) {
+  const int F = M->F;
+  const REAL c0 = (REAL)pow(10.0, 1.0 - (double)b[0]);
+  if (to_centered) {
+    const REAL ols = c0 * x[0];
+    out[0] = ols;
+    for (int d = 0; d < F; ++d) {
+      const REAL bls = x[1 + d] + (1 - a[1 + d]) * ols;
+      out[1 + d] = bls;
+      out[1 + F + d] = (REAL)exp((double)((1 - b[1 + F + d]) * bls)) * x[1 + F + d];
+    }
+  } else {
+    const REAL ols = x[0];
+    out[0] = ols / c0;
+    for (int d = 0; d < F; ++d) {
+      out[1 + d] = x[1 + d] - (1 - a[1 + d]) * ols;
+      out[1 + F + d] = x[1 + F + d] * (REAL)exp((double)(-(1 - b[1 + F + d]) * x[1 + d]));
+    }
+  }
+}
+
 /* dispatch */
 static REAL FN(logp_grad)(const orc_model* M, const float* a, const float* b, const REAL* x, REAL* g) {
   switch (M->model) {
+    case 0: return FN(schools_logp_grad)(M, a, b, x, g);
     case 1: return FN(radon_logp_grad)(M, a, b, x, g);
+    case 2: return FN(german_logp_grad)(M, a, b, x, g);
+    case 3: return FN(election_logp_grad)(M, a, b, x, g);
     default: return (REAL)NAN;
   }
 }
 static void FN(to_centered)(const orc_model* M, const float* a, const float* b, const REAL* x, REAL* o) {
   switch (M->model) {
+    case 0: FN(schools_convert)(M, a, b, x, o, 1); break;
     case 1: FN(radon_to_centered)(M, a, b, x, o); break;
+    case 2: FN(german_convert)(M, a, b, x, o, 1); break;
+    case 3: FN(election_convert)(M, a, b, x, o, 1); break;
     default: break;
   }
 }
 static void FN(from_centered)(const orc_model* M, const float* a, const float* b, const REAL* x, REAL* o) {
   switch (M->model) {
+    case 0: FN(schools_convert)(M, a, b, x, o, 0); break;
     case 1: FN(radon_from_centered)(M, a, b, x, o); break;
+    case 2: FN(german_convert)(M, a, b, x, o, 0); break;
+    case 3: FN(election_convert)(M, a, b, x, o, 0); break;
     default: break;
   }
 }
@@ -112,12 +309,13 @@ int FN(orc_transform)(const orc_model* M, const float* a, const float* b, int di
 /* ------------------------------------------------------------------------
  * Momentum and Metropolis draws of one transition for one chain.
  * Stream partition: slot s of `lanes` owns the replicated top-level scalars
- * (only slot 0's draw is used) followed by the groups j = s + lanes*i.
+ * (only slot 0's draw is used) followed, for each sliced latent part in trace
+ * order, by its elements j = s + lanes*i.
  * ---------------------------------------------------------------------- */
 static void FN(draw_momentum)(const orc_model* M, orc_rng* streams, int lanes, REAL* p, REAL* u_out) {
-  const int NG = M->n_glob, G = M->n_groups;
+  const int NG = M->n_glob, G = M->n_groups, P = M->n_local_parts;
   const int per_lane = (G + lanes - 1) / lanes;
-  const int nd = NG + per_lane;
+  const int nd = NG + P * per_lane;   /* normals every slot draws: scalars, then part by part */
   for (int s = 0; s < lanes; ++s) {
     orc_rng* r = &streams[s];
     for (int i = 0; i < nd; i += 2) {
@@ -131,8 +329,9 @@ static void FN(draw_momentum)(const orc_model* M, orc_rng* streams, int lanes, R
         if (ii < NG) {
           if (s == 0) p[M->glob_idx[ii]] = (REAL)z;
         } else {
-          int j = s + lanes * (ii - NG);
-          if (j < G && M->group_idx[j] >= 0) p[M->group_idx[j]] = (REAL)z;
+          int part = (ii - NG) / per_lane;
+          int j = s + lanes * ((ii - NG) % per_lane);
+          if (j < G && M->group_idx[part * G + j] >= 0) p[M->group_idx[part * G + j]] = (REAL)z;
         }
       }
     }
@@ -205,6 +404,27 @@ static void FN(adapt_update)(int kind, long long n, int n_adapt, REAL target, RE
       *kappa = (lacc > (REAL)log((double)target)) ? *kappa * opr : *kappa / opr;
     }
   }
+}
+
+/* test hooks: a bare leapfrog trajectory and one adaptation update */
+int FN(orc_leapfrog)(const orc_model* M, const float* a, const float* b, int L, const REAL* eps,
+                     REAL* q, REAL* p, REAL* logp_out) {
+  const int D = M->D;
+  REAL* g = (REAL*)malloc(sizeof(REAL) * D);
+  REAL lp = FN(logp_grad)(M, a, b, q, g);
+  for (int d = 0; d < D; ++d) p[d] += (REAL)0.5 * eps[d] * g[d];
+  for (int l = 0; l < L; ++l) {
+    for (int d = 0; d < D; ++d) q[d] += eps[d] * p[d];
+    lp = FN(logp_grad)(M, a, b, q, g);
+    const REAL w = (l + 1 < L) ? (REAL)1 : (REAL)0.5;
+    for (int d = 0; d < D; ++d) p[d] += w * eps[d] * g[d];
+  }
+  *logp_out = lp;
+  free(g);
+  return 0;
+}
+void FN(orc_adapt_update)(int kind, long long n, int n_adapt, REAL target, REAL rate, REAL la, REAL* state3) {
+  FN(adapt_update)(kind, n, n_adapt, target, rate, la, &state3[0], &state3[1], &state3[2]);
 }
 
 /* A run of n_steps transitions for C chains, same contract as arp_hmc_run

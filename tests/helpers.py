@@ -1,0 +1,32 @@
+"""Shared test helpers: model specs, seeded parameterisations and states."""
+import numpy as np
+
+from autoreparam_amd import models
+
+MODEL_SPECS = {
+    "8schools": lambda: models._spec_eight_schools(),
+    "radon_MN": lambda: models._spec_radon("MN"),
+    "radon_PA": lambda: models._spec_radon("PA"),
+    "german": lambda: models._spec_german(),
+    "election": lambda: models._spec_election(),
+}
+_cache = {}
+
+
+def spec(name):
+    if name not in _cache:
+        _cache[name] = MODEL_SPECS[name]()
+    return _cache[name]
+
+
+def params(sp, kind, seed=0):
+    """(a, b) float32 [D] for 'CP', 'NCP' or a seeded 'VIP'."""
+    if kind in ("CP", "NCP"):
+        return sp.ab_from_reparam(kind)
+    rs = np.random.RandomState(1000 + seed)
+    return rs.rand(sp.D).astype(np.float32), rs.rand(sp.D).astype(np.float32)
+
+
+def states(sp, n, seed=0, scale=0.3):
+    rs = np.random.RandomState(seed)
+    return (scale * rs.randn(n, sp.D)).astype(np.float32)

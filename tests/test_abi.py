@@ -1,0 +1,66 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol that
+include/autoreparam.h declares; no compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    from autoreparam_amd import _lib
+    return _lib
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "autoreparam.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(arp_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(built):
+    L = built.lib()
+    names = _declared()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(names) == sorted(built.SYMBOLS)
+    assert L.arp_version() == 1
+
+
+def test_struct_layout_matches_header(built):
+    # sizes the C compiler gives the ABI structs (host compile of the header)
+    import subprocess, tempfile
+    code = '#include <stdio.h>\n#include "autoreparam.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",' \
+           'sizeof(arp_dataset),sizeof(arp_hmc_config),sizeof(arp_hmc_io),sizeof(arp_interleaved_io),' \
+           'sizeof(arp_vi_config),sizeof(arp_vi_io));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(code)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o",
+                               os.path.join(d, "t")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+    got = [ctypes.sizeof(x) for x in (built.Dataset, built.HmcConfig, built.HmcIO, built.InterleavedIO,
+                                      built.ViConfig, built.ViIO)]
+    assert [int(v) for v in out] == got
+
+
+def test_bad_arguments_fail_loudly(built):
+    L = built.lib()
+    assert L.arp_model_create(None, None) != 0
+    assert b"null" in L.arp_last_error()
+    assert L.arp_model_dim(None) == -1
+
+
+def test_product_path_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "autoreparam_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), (dirpath, f)
+                assert "liboracle" not in txt, (dirpath, f)

@@ -1,0 +1,146 @@
+"""GPU: the fused HMC kernel against the float32 C oracle (same RNG
+specification, so trajectories agree to float32 tolerance), chunk invariance,
+adaptation, the trace schedule and posterior moments at BASELINE sizes."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+LANES = {"8schools": [1, 8], "radon_MN": [4, 8, 16], "radon_PA": [4, 8, 16], "election": [4, 8, 16]}
+
+
+def _eng(mname, gpu):
+    from autoreparam_amd import engine
+    return engine.Engine(helpers.spec(mname), gpu)
+
+
+def _eps0(oracle_lib, sp, a, b, x, frac):
+    """a stable per-element step: frac / sqrt(|diag Hessian|) from finite differences of the oracle gradient"""
+    orc = oracle_lib.OracleModel(sp)
+    x0 = x[:1].astype(np.float64)
+    _, g0 = orc.logp_grad(x0, a, b)
+    h = 1e-4
+    diag = np.zeros(sp.D)
+    for d in range(sp.D):
+        xp = x0.copy(); xp[0, d] += h
+        diag[d] = -(orc.logp_grad(xp, a, b)[1][0, d] - g0[0, d]) / h
+    return (frac / np.sqrt(np.abs(diag) + 1.0)).astype(np.float32)
+
+
+@pytest.mark.parametrize("mname", ["8schools", "radon_MN", "radon_PA", "election"])
+@pytest.mark.parametrize("kind", ["CP", "NCP", "VIP"])
+def test_trajectories_match_oracle(oracle_lib, gpu, mname, kind):
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec(mname)
+    eng = _eng(mname, gpu)
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, kind)
+    eng.set_param(0, (a, b))
+    Cn, L, n = 96, 4, 12
+    q0 = helpers.states(sp, Cn, seed=2, scale=0.1)
+    eps0 = _eps0(oracle_lib, sp, a, b, q0, 0.15)
+    for lanes in LANES[mname]:
+        st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+        tr = torch.zeros(4, Cn, sp.D, device=gpu); ta = torch.zeros(4, Cn, dtype=torch.uint8, device=gpu)
+        eng.hmc_run(st, eps0, L, n, seed=9, chain_offset=1000, adapt_kind=_lib.ADAPT_DUAL, n_adapt=8,
+                    n_burnin=2, thin=3, trace=tr, trace_accept=ta, trace_centered=True, lanes=lanes)
+        so = oracle_lib.new_state(q0, np.float32)
+        tro = np.zeros((4, Cn, sp.D), np.float32); tao = np.zeros((4, Cn), np.uint8)
+        orc.hmc_run(so, a, b, eps0, L, n, seed=9, chain_offset=1000, adapt_kind=1, n_adapt=8, n_burnin=2, thin=3,
+                    trace=tro, trace_accept=tao, trace_centered=True, lanes=lanes)
+        q = st.q.cpu().numpy()
+        # a chain whose Metropolis test sat within rounding of the threshold may take the other branch
+        same = (st.accept_count.cpu().numpy() == so["accept_count"])
+        assert same.mean() >= 0.97, (lanes, same.mean())
+        scale = np.abs(so["q"]).max() + 1.0
+        assert np.abs(q[same] - so["q"][same]).max() <= 2e-4 * scale, lanes
+        assert np.abs(st.adapt.cpu().numpy()[same, :3] - so["adapt"][same, :3]).max() <= 2e-3
+        assert np.abs(tr.cpu().numpy()[:, same] - tro[:, same]).max() <= 2e-4 * scale
+        assert (ta.cpu().numpy()[:, same] == tao[:, same]).mean() > 0.99
+        assert np.array_equal(st.rng.cpu().numpy().view(np.uint32)[:, :lanes], so["rng"][:, :lanes])
+
+
+@pytest.mark.parametrize("mname", ["radon_MN", "election"])
+def test_chunked_run_is_bitwise_single_run(gpu, mname):
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec(mname)
+    eng = _eng(mname, gpu)
+    eng.set_param(0, "CP")
+    q0 = helpers.states(sp, 300, seed=5, scale=0.1)
+    eps0 = np.full(sp.D, 0.02, np.float32)
+    kw = dict(seed=3, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=6, n_burnin=1, thin=2)
+    one = engine.ChainState(torch.as_tensor(q0, device=gpu)); t1 = torch.zeros(5, 300, sp.D, device=gpu)
+    eng.hmc_run(one, eps0, 3, 11, trace=t1, **kw)
+    two = engine.ChainState(torch.as_tensor(q0, device=gpu)); t2 = torch.zeros(5, 300, sp.D, device=gpu)
+    for n in (1, 4, 6):
+        eng.hmc_run(two, eps0, 3, n, trace=t2, **kw)
+    for k in ("q", "grad", "logp", "adapt", "rng", "accept_count"):
+        assert torch.equal(getattr(one, k), getattr(two, k)), k
+    assert torch.equal(t1, t2)
+
+
+def test_chain_offset_keys_the_streams(gpu):
+    """Sharding invariance: chains [64,128) run alone with chain_offset=64 equal the
+    same chains inside a 128-chain launch (what one rank of a multi-GPU run does)."""
+    from autoreparam_amd import engine
+    sp = helpers.spec("radon_PA")
+    eng = _eng("radon_PA", gpu)
+    eng.set_param(0, "CP")
+    q0 = helpers.states(sp, 128, seed=8, scale=0.1)
+    eps0 = np.full(sp.D, 0.02, np.float32)
+    full = engine.ChainState(torch.as_tensor(q0, device=gpu))
+    eng.hmc_run(full, eps0, 4, 6, seed=1, lanes=8)
+    half = engine.ChainState(torch.as_tensor(q0[64:], device=gpu))
+    eng.hmc_run(half, eps0, 4, 6, seed=1, chain_offset=64, lanes=8)
+    assert torch.equal(full.q[64:], half.q)
+
+
+def test_radon_posterior_means_config2(gpu, oracle_lib):
+    """BASELINE config 2 shape: radon MN, CP, 4096 chains, 4 leapfrog steps; posterior
+    means within 1 % of the closed-form Gaussian answer."""
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec("radon_MN")
+    eng = _eng("radon_MN", gpu)
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "CP")
+    eng.set_param(0, "CP")
+    D = sp.D
+    _, g0 = orc.logp_grad(np.zeros((1, D)), a, b)
+    _, gI = orc.logp_grad(np.eye(D), a, b)
+    P = -(gI - g0)
+    mean = np.linalg.solve(P, g0[0]); sd = np.sqrt(np.diag(np.linalg.inv(P)))
+    Cn, S = 4096, 200
+    rs = np.random.RandomState(0)
+    q0 = (mean + 1.5 * sd * rs.randn(Cn, D)).astype(np.float32)
+    st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+    tr = torch.zeros(S, Cn, D, device=gpu)
+    eng.hmc_run(st, sd.astype(np.float32), 4, 1 + 200 + 2 * (S - 1), seed=4, adapt_kind=_lib.ADAPT_DUAL, n_adapt=150,
+                n_burnin=200, thin=2, trace=tr, trace_centered=True)
+    m = tr.double().mean(dim=(0, 1)).cpu().numpy()
+    v = tr.double().reshape(-1, D).std(dim=0).cpu().numpy()
+    acc = st.accept_count.double().mean().item() / st.step
+    assert 0.6 < acc < 0.95
+    assert np.abs((m - mean) / sd).max() < 0.02          # every coordinate within 2 % of a posterior sd
+    assert np.abs(m[:3] - mean[:3]).max() <= 0.01 * np.abs(mean[:3]).max()   # "means within 1 %"
+    assert np.abs(v / sd - 1).max() < 0.03
+
+
+def test_full_size_headline_invariants(gpu):
+    """radon PA at 65 536 chains (BASELINE headline size): finite states, sane
+    acceptance, pooled means equal to the closed form within Monte-Carlo error."""
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec("radon_PA")
+    eng = _eng("radon_PA", gpu)
+    eng.set_param(0, "CP")
+    Cn = 65536
+    q0 = helpers.states(sp, Cn, seed=1, scale=0.5)
+    st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+    eps0 = np.full(sp.D, 0.1, np.float32); eps0[2] = 0.01
+    eng.hmc_run(st, eps0, 8, 300, seed=2, adapt_kind=_lib.ADAPT_DUAL, n_adapt=200)
+    assert torch.isfinite(st.q).all()
+    acc = st.accept_count.double().mean().item() / st.step
+    assert 0.55 < acc < 0.95
+    m = st.q.double().mean(dim=0).cpu().numpy()
+    np.testing.assert_allclose(m[:3], (1.3389, -0.0480, -0.1026), atol=0.01)

@@ -1,0 +1,169 @@
+"""CPU: properties of the oracle's HMC restatement (the TFP internals are not
+under /root/reference, so they are pinned by algorithmic properties and by an
+independent restatement of the published recurrences)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+
+
+def _leapfrog(oracle, orc, a, b, L, eps, q, p):
+    q = np.ascontiguousarray(q, np.float64).copy(); p = np.ascontiguousarray(p, np.float64).copy()
+    eps = np.ascontiguousarray(eps, np.float64)
+    lp = C.c_double(0)
+    oracle.lib().orc_leapfrog_f64(orc._h, oracle._p(a), oracle._p(b), L, oracle._p(eps), oracle._p(q), oracle._p(p),
+                                  C.byref(lp))
+    return q, p, lp.value
+
+
+@pytest.mark.parametrize("mname", ["radon_MN", "8schools", "election"])
+def test_leapfrog_reversible_and_second_order(oracle_lib, mname):
+    sp = helpers.spec(mname)
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "VIP", seed=1)
+    rs = np.random.RandomState(0)
+    q0 = 0.1 * rs.randn(sp.D); p0 = rs.randn(sp.D)
+    lp0, g0 = orc.logp_grad(q0[None], a, b)
+    scale = 1.0 / np.sqrt(np.abs(g0[0]).max() + 1.0)
+    errs = []
+    for h in (1e-2, 5e-3, 2.5e-3):
+        eps = np.full(sp.D, h * scale)
+        q1, p1, lp1 = _leapfrog(oracle_lib, orc, a, b, 8, eps, q0, p0)
+        # reversibility: flip the momentum and integrate back
+        q2, p2, _ = _leapfrog(oracle_lib, orc, a, b, 8, eps, q1, -p1)
+        np.testing.assert_allclose(q2, q0, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(-p2, p0, rtol=0, atol=1e-8)
+        errs.append(abs((lp1 - 0.5 * p1 @ p1) - (lp0[0] - 0.5 * p0 @ p0)))
+    # energy error shrinks ~4x per halving of the step (second-order integrator)
+    assert errs[0] / errs[1] > 3.0 and errs[1] / errs[2] > 3.0
+
+
+def _run(oracle, sp, orc, kind, q0, eps0, L, n, dtype=np.float64, **kw):
+    a, b = helpers.params(sp, kind)
+    st = oracle.new_state(q0, dtype)
+    orc.hmc_run(st, a, b, eps0, L, n, **kw)
+    return st
+
+
+def test_chunked_run_equals_single_run(oracle_lib):
+    sp = helpers.spec("radon_MN")
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "CP")
+    q0 = helpers.states(sp, 16, seed=3)
+    eps0 = np.full(sp.D, 0.05, np.float32)
+    one = oracle_lib.new_state(q0)
+    orc.hmc_run(one, a, b, eps0, 4, 12, seed=5, adapt_kind=1, n_adapt=8, lanes=4)
+    two = oracle_lib.new_state(q0)
+    orc.hmc_run(two, a, b, eps0, 4, 5, seed=5, adapt_kind=1, n_adapt=8, lanes=4)
+    orc.hmc_run(two, a, b, eps0, 4, 7, seed=5, adapt_kind=1, n_adapt=8, lanes=4)
+    for k in ("q", "grad", "logp", "adapt", "rng", "accept_count"):
+        assert np.array_equal(one[k], two[k]), k
+
+
+def test_trace_schedule_matches_sample_chain(oracle_lib):
+    """tfp.mcmc.sample_chain(num_results=S, num_burnin_steps=B, num_steps_between_results=1):
+    result r is the state after transition 1 + B + 2r."""
+    sp = helpers.spec("8schools")
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "CP")
+    q0 = helpers.states(sp, 4, seed=1)
+    eps0 = np.full(sp.D, 0.1, np.float32)
+    B, S, thin = 3, 4, 2
+    total = 1 + B + thin * (S - 1)
+    st = oracle_lib.new_state(q0)
+    trace = np.zeros((S, 4, sp.D)); acc = np.zeros((S, 4), np.uint8)
+    orc.hmc_run(st, a, b, eps0, 3, total, seed=2, n_burnin=B, thin=thin, trace=trace, trace_accept=acc,
+                trace_centered=False, lanes=1)
+    for r in range(S):
+        ref = oracle_lib.new_state(q0)
+        orc.hmc_run(ref, a, b, eps0, 3, 1 + B + thin * r, seed=2, lanes=1)
+        assert np.array_equal(ref["q"], trace[r])
+    assert st["step"] == total
+
+
+def test_radon_posterior_moments(oracle_lib):
+    sp = helpers.spec("radon_MN")
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "CP")
+    D = sp.D
+    _, g0 = orc.logp_grad(np.zeros((1, D)), a, b)
+    _, gI = orc.logp_grad(np.eye(D), a, b)
+    P = -(gI - g0)
+    mean = np.linalg.solve(P, g0[0]); sd = np.sqrt(np.diag(np.linalg.inv(P)))
+    Cn, S = 256, 150
+    rs = np.random.RandomState(0)
+    q0 = mean + sd * rs.randn(Cn, D)
+    eps0 = (0.35 * sd).astype(np.float32)
+    st = oracle_lib.new_state(q0)
+    trace = np.zeros((S, Cn, D))
+    orc.hmc_run(st, a, b, eps0, 8, 50 + S, seed=11, n_burnin=49, thin=1, trace=trace, trace_centered=True, lanes=4)
+    acc = st["accept_count"].mean() / st["step"]
+    assert 0.6 < acc <= 1.0
+    m = trace.mean(axis=(0, 1)); v = trace.reshape(-1, D).std(axis=0)
+    # Monte-Carlo error: chains are independent, within-chain samples correlated -> be generous
+    assert np.abs((m - mean) / sd).max() < 0.1
+    assert np.abs(v / sd - 1).max() < 0.1
+    # "posterior means within 1 %" (BASELINE.json) on the three regression coefficients' scale
+    assert np.abs(m[:3] - mean[:3]).max() < 0.01 * np.abs(mean[:3]).max() + 0.05 * sd[:3].max()
+
+
+def _tfp_dual_averaging(eps0, alphas, n_adapt, target=0.75, shrink=0.05, smoothing=10.0, decay=0.75):
+    """Published dual-averaging recurrence as TFP's DualAveragingStepSizeAdaptation
+    applies it (absolute log step; shrinkage target log(10 eps0)); returns the step
+    size used for each transition."""
+    log_target = np.log(10.0 * eps0)
+    err, log_avg, step = 0.0, 0.0, eps0
+    used = []
+    for t, al in enumerate(alphas, start=1):
+        used.append(step)
+        if t <= n_adapt:
+            err += target - al
+            log_step = log_target - err * np.sqrt(t) / ((t + smoothing) * shrink)
+            eta = t ** (-decay)
+            log_avg = eta * log_step + (1 - eta) * log_avg
+            step = np.exp(log_step)
+        else:
+            step = np.exp(log_avg)
+    return np.array(used)
+
+
+def test_dual_averaging_recurrence(oracle_lib):
+    rs = np.random.RandomState(3)
+    alphas = rs.rand(40)
+    eps0, n_adapt = 0.037, 25
+    ref = _tfp_dual_averaging(eps0, alphas, n_adapt)
+    st = (C.c_double * 3)(1.0, 0.0, 0.0)
+    used = []
+    for n, al in enumerate(alphas, start=1):
+        used.append(eps0 * st[0])
+        oracle_lib.lib().orc_adapt_update_f64(1, C.c_longlong(n), n_adapt, C.c_double(0.75), C.c_double(0.05),
+                                              C.c_double(np.log(al)), st)
+    np.testing.assert_allclose(used, ref, rtol=1e-12)
+
+
+def test_simple_adaptation_recurrence(oracle_lib):
+    rs = np.random.RandomState(4)
+    alphas = rs.rand(30)
+    st = (C.c_double * 3)(1.0, 0.0, 0.0)
+    k = 1.0
+    for n, al in enumerate(alphas, start=1):
+        oracle_lib.lib().orc_adapt_update_f64(2, C.c_longlong(n), 20, C.c_double(0.75), C.c_double(0.05),
+                                              C.c_double(np.log(al)), st)
+        if n <= 20:
+            k = k * 1.05 if al > 0.75 else k / 1.05
+        assert abs(st[0] - k) < 1e-12
+
+
+def test_non_finite_energy_rejects(oracle_lib):
+    """A proposal whose energy is not finite must be rejected (TFP safe_sum; inference.py:323-324)."""
+    sp = helpers.spec("8schools")
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "CP")
+    q0 = helpers.states(sp, 8, seed=1)
+    eps0 = np.full(sp.D, 50.0, np.float32)   # absurd step: exp(log_tau) overflows
+    st = oracle_lib.new_state(q0, np.float32)
+    orc.hmc_run(st, a, b, eps0, 4, 5, seed=3, lanes=1)
+    assert np.isfinite(st["q"]).all()
+    assert (st["accept_count"] <= 5).all()

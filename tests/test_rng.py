@@ -1,0 +1,70 @@
+"""CPU: known-answer and distribution tests of the sampler's RNG specification
+(Philox4x32-10 seeding, xoshiro128++ streams, Box-Muller normals)."""
+import ctypes as C
+
+import numpy as np
+
+
+def _philox(oracle, ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    oracle.lib().orc_philox(c, C.c_uint32(key[0]), C.c_uint32(key[1]))
+    return [int(v) for v in c]
+
+
+def test_philox_known_answers(oracle_lib):
+    # Random123 kat_vectors, philox4x32 10 rounds
+    assert _philox(oracle_lib, [0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert _philox(oracle_lib, [0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert _philox(oracle_lib, [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def _xoshiro128pp(state, n):
+    """Independent restatement (python ints) of Blackman & Vigna's xoshiro128++."""
+    s = list(state)
+    M = 0xffffffff
+    rotl = lambda x, k: ((x << k) | (x >> (32 - k))) & M
+    out = []
+    for _ in range(n):
+        out.append((rotl((s[0] + s[3]) & M, 7) + s[0]) & M)
+        t = (s[1] << 9) & M
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = rotl(s[3], 11)
+    return out
+
+
+def test_stream_is_philox_seeded_xoshiro(oracle_lib):
+    seed, chain, slot, lanes = 0x123456789abcdef, 4242, 3, 8
+    out = np.zeros(64, np.uint32)
+    oracle_lib.lib().orc_stream(C.c_uint64(seed), C.c_uint64(chain), C.c_uint32(slot), C.c_uint32(lanes), 64,
+                                out.ctypes.data_as(C.c_void_p))
+    st = _philox(oracle_lib, [chain & 0xffffffff, chain >> 32, slot, lanes], [seed & 0xffffffff, seed >> 32])
+    assert [int(v) for v in out] == _xoshiro128pp(st, 64)
+
+
+def test_streams_differ_by_chain_slot_and_seed(oracle_lib):
+    def first(seed, chain, slot, lanes):
+        out = np.zeros(4, np.uint32)
+        oracle_lib.lib().orc_stream(C.c_uint64(seed), C.c_uint64(chain), C.c_uint32(slot), C.c_uint32(lanes), 4,
+                                    out.ctypes.data_as(C.c_void_p))
+        return tuple(int(v) for v in out)
+    base = first(1, 0, 0, 4)
+    assert len({base, first(2, 0, 0, 4), first(1, 1, 0, 4), first(1, 0, 1, 4), first(1, 0, 0, 8)}) == 5
+
+
+def test_normals_moments(oracle_lib):
+    n_pairs = 200000
+    z = np.zeros(2 * n_pairs, np.float32)
+    oracle_lib.lib().orc_normals(C.c_uint64(7), C.c_uint64(0), C.c_uint32(0), C.c_uint32(4), n_pairs,
+                                 z.ctypes.data_as(C.c_void_p))
+    z = z.astype(np.float64)
+    n = z.size
+    assert abs(z.mean()) < 4 / np.sqrt(n)
+    assert abs(z.var() - 1) < 4 * np.sqrt(2.0 / n)
+    assert abs((z ** 3).mean()) < 4 * np.sqrt(15.0 / n)
+    assert abs((z ** 4).mean() - 3) < 4 * np.sqrt(96.0 / n)
+    # the two outputs of a pair are uncorrelated, and so are successive pairs
+    assert abs(np.corrcoef(z[0::2], z[1::2])[0, 1]) < 4 / np.sqrt(n_pairs)
+    assert abs(np.corrcoef(z[:-2:2], z[2::2])[0, 1]) < 4 / np.sqrt(n_pairs)
+    assert np.abs(z).max() < 6.0  # 24-bit uniform: |z| <= sqrt(2*24*ln2) = 5.77
