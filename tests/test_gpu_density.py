@@ -73,7 +73,8 @@ def test_converter_properties(engines, mname):
     eng = engines(mname)
     x = helpers.states(sp, 257, seed=4)
     eng.set_param(0, "CP")
-    assert np.array_equal(eng.transform(x, 0, True).cpu().numpy(), x)
+    # identity up to float32 rounding of mu + (x - mu), as in the reference's own float32 graph
+    np.testing.assert_allclose(eng.transform(x, 0, True).cpu().numpy(), x, rtol=0, atol=2e-7 * 4)
     for kind in ("NCP", "VIP"):
         eng.set_param(1, helpers.params(sp, kind))
         t1 = eng.transform(x, 1, to_centered=False)
