@@ -240,21 +240,18 @@ int arp_transform(arp_model* m, int which, int dir, const float* in, int n_chain
   return 0;
 }
 
-int arp_hmc_run(arp_model* m, int which, const arp_hmc_config* cfg, const arp_hmc_io* io, void* stream) {
-  if (!m || !cfg || !io || which < 0 || which > 1) { set_error("arp_hmc_run: null argument"); return 1; }
+static int fill_params(arp_model* m, const arp_hmc_config* cfg, const arp_hmc_io* io, bool need_cache, HmcParams* Pp) {
   if (cfg->n_chains <= 0 || cfg->n_leapfrog <= 0 || cfg->n_steps < 0 || cfg->thin <= 0 || cfg->step_base < 0) {
-    set_error("arp_hmc_run: n_chains, n_leapfrog, thin must be positive and n_steps, step_base non-negative");
+    set_error("n_chains, n_leapfrog, thin must be positive and n_steps, step_base non-negative");
     return 1;
   }
-  if (!io->q || !io->grad || !io->logp || !io->adapt || !io->rng || !io->accept_count || !io->eps0) {
-    set_error("arp_hmc_run: q, grad, logp, adapt, rng, accept_count and eps0 are required");
+  if (!io->q || !io->adapt || !io->rng || !io->accept_count || !io->eps0 ||
+      (need_cache && (!io->grad || !io->logp))) {
+    set_error("q, grad, logp, adapt, rng, accept_count and eps0 are required");
     return 1;
   }
-  if (cfg->adapt_kind < ARP_ADAPT_NONE || cfg->adapt_kind > ARP_ADAPT_SIMPLE) { set_error("arp_hmc_run: bad adapt_kind"); return 1; }
-  if (cfg->n_steps == 0) return 0;
-  const LaneOps* o = select_ops(m, cfg->lanes_per_chain, cfg->n_chains);
-  if (!o) return 1;
-  HmcParams P;
+  if (cfg->adapt_kind < ARP_ADAPT_NONE || cfg->adapt_kind > ARP_ADAPT_SIMPLE) { set_error("bad adapt_kind"); return 1; }
+  HmcParams& P = *Pp;
   P.C = cfg->n_chains; P.L = cfg->n_leapfrog; P.n_steps = cfg->n_steps;
   P.step_base = cfg->step_base; P.chain_offset = cfg->chain_offset; P.seed = cfg->seed;
   P.adapt_kind = cfg->adapt_kind; P.n_adapt = cfg->n_adapt;
@@ -279,14 +276,41 @@ int arp_hmc_run(arp_model* m, int which, const arp_hmc_config* cfg, const arp_hm
   P.q = io->q; P.grad = io->grad; P.logp = io->logp; P.adapt = io->adapt;
   P.rng = io->rng; P.accept_count = io->accept_count; P.eps0 = io->eps0;
   P.trace = io->trace; P.trace_accept = io->trace_accept; P.moments = io->moments;
+  P.L1 = 0; P.adapt1 = nullptr; P.accept_count1 = nullptr; P.eps0_1 = nullptr; P.trace_accept1 = nullptr;
+  return 0;
+}
+
+int arp_hmc_run(arp_model* m, int which, const arp_hmc_config* cfg, const arp_hmc_io* io, void* stream) {
+  if (!m || !cfg || !io || which < 0 || which > 1) { set_error("arp_hmc_run: null argument"); return 1; }
+  HmcParams P;
+  if (fill_params(m, cfg, io, true, &P)) return 1;
+  if (cfg->n_steps == 0) return 0;
+  const LaneOps* o = select_ops(m, cfg->lanes_per_chain, cfg->n_chains);
+  if (!o) return 1;
   o->hmc(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, (hipStream_t)stream);
   ARP_HIP_OK(hipGetLastError());
   return 0;
 }
 
-int arp_interleaved_run(arp_model*, const arp_hmc_config*, int, const arp_interleaved_io*, void*) {
-  set_error("arp_interleaved_run: not built yet");
-  return 1;
+int arp_interleaved_run(arp_model* m, const arp_hmc_config* cfg, int n_leapfrog_1,
+                        const arp_interleaved_io* io, void* stream) {
+  if (!m || !cfg || !io) { set_error("arp_interleaved_run: null argument"); return 1; }
+  if (n_leapfrog_1 <= 0 || !io->adapt1 || !io->accept_count1 || !io->eps0_1) {
+    set_error("arp_interleaved_run: n_leapfrog_1, adapt1, accept_count1 and eps0_1 are required");
+    return 1;
+  }
+  HmcParams P;
+  if (fill_params(m, cfg, &io->k0, false, &P)) return 1;
+  if (io->trace_accept1 && !P.n_samples) P.n_samples = cfg->n_samples;
+  P.L1 = n_leapfrog_1; P.adapt1 = io->adapt1; P.accept_count1 = io->accept_count1;
+  P.eps0_1 = io->eps0_1; P.trace_accept1 = io->trace_accept1;
+  if (cfg->n_steps == 0) return 0;
+  const LaneOps* o = select_ops(m, cfg->lanes_per_chain, cfg->n_chains);
+  if (!o) return 1;
+  o->interleaved(family_args(m), m->dev_ab[0], m->dev_ab[0] + m->D, m->dev_ab[1], m->dev_ab[1] + m->D, P,
+                 (hipStream_t)stream);
+  ARP_HIP_OK(hipGetLastError());
+  return 0;
 }
 
 int arp_vi_run(arp_model*, int, const arp_vi_config*, const arp_vi_io*, void*) {

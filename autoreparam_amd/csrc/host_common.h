@@ -33,6 +33,8 @@ struct LaneOps {
   void (*transform)(const void* args, const float* a, const float* b, int dir, const float* in,
                     int C, int D, float* out, hipStream_t s);
   void (*hmc)(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s);
+  void (*interleaved)(const void* args, const float* a0, const float* b0, const float* a1, const float* b1,
+                      const HmcParams& P, hipStream_t s);
 };
 
 template <class Lane>
@@ -52,7 +54,12 @@ struct Launch {
     hipLaunchKernelGGL(hmc_kernel<Lane>, dim3(blocks(P.C)), dim3(kBlock), 0, s,
                        *(const typename Lane::Args*)args, a, b, P);
   }
-  static LaneOps ops() { return LaneOps{Lane::K, Lane::NL, &logp_grad, &transform, &hmc}; }
+  static void interleaved(const void* args, const float* a0, const float* b0, const float* a1, const float* b1,
+                          const HmcParams& P, hipStream_t s) {
+    hipLaunchKernelGGL(interleaved_kernel<Lane>, dim3(blocks(P.C)), dim3(kBlock), 0, s,
+                       *(const typename Lane::Args*)args, a0, b0, a1, b1, P);
+  }
+  static LaneOps ops() { return LaneOps{Lane::K, Lane::NL, &logp_grad, &transform, &hmc, &interleaved}; }
 };
 
 // per-family tables (defined in inst_*.hip)

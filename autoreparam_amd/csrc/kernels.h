@@ -26,6 +26,9 @@ struct HmcParams {
   uint32_t* rng; uint32_t* accept_count;
   const float* eps0;
   float* trace; uint8_t* trace_accept; float* moments;
+  // interleaved kernel only: second transition kernel (parameterisation 1)
+  int L1;
+  float* adapt1; uint32_t* accept_count1; const float* eps0_1; uint8_t* trace_accept1;
 };
 
 
@@ -275,6 +278,101 @@ __global__ __launch_bounds__(kBlock) void hmc_kernel(
       P.logp[c] = lp;
       P.adapt[c * 4 + 0] = kappa; P.adapt[c * 4 + 1] = esum; P.adapt[c * 4 + 2] = logavg;
       P.accept_count[c] = nacc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Interleaved CP/NCP sampling (interleaved.Interleaved.one_step,
+// interleaved.py:113-155): per step
+//   re-bootstrap logp/grad at the current state under parameterisation 0,
+//   one HMC transition there, map the state to parameterisation 1
+//   (to_ncp = from_centred_1 o to_centred_0), re-bootstrap, one HMC transition,
+//   map back.  Each inner kernel keeps its own step-size adaptation state, which
+//   survives the re-bootstrap because it lives outside the HMC results
+//   (inference.py:288-306).  2*(L+1) gradient evaluations per step.
+// ---------------------------------------------------------------------------
+template <class Lane>
+__global__ __launch_bounds__(kBlock) void interleaved_kernel(
+    typename Lane::Args A, const float* __restrict__ av0, const float* __restrict__ bv0,
+    const float* __restrict__ av1, const float* __restrict__ bv1, HmcParams P) {
+  constexpr int K = Lane::K, ND = Lane::ND;
+  long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const int slot = (int)(t % K);
+  long long c = t / K;
+  const bool live = c < P.C;
+  if (!live) c = P.C - 1;
+  const int D = P.D;
+  Lane M;
+  M.init(A, av0, bv0, slot);
+
+  float q[ND], g[ND], eps[ND], x[ND];
+  float* qrow = P.q + c * D;
+  load_row(M, qrow, q);
+  float kap[2], es[2], la_[2];
+  Rng rng;
+  uint32_t* rs = P.rng + ((size_t)c * kRngSlots + slot) * 4;
+  uint32_t nacc0, nacc1;
+  if (P.step_base == 0) {
+    kap[0] = kap[1] = 1.0f; es[0] = es[1] = 0.0f; la_[0] = la_[1] = 0.0f;
+    nacc0 = nacc1 = 0u;
+    rng = rng_seed(P.seed, (unsigned long long)(P.chain_offset + c), (uint32_t)slot, (uint32_t)K);
+  } else {
+    kap[0] = P.adapt[c * 4 + 0]; es[0] = P.adapt[c * 4 + 1]; la_[0] = P.adapt[c * 4 + 2];
+    kap[1] = P.adapt1[c * 4 + 0]; es[1] = P.adapt1[c * 4 + 1]; la_[1] = P.adapt1[c * 4 + 2];
+    nacc0 = P.accept_count[c]; nacc1 = P.accept_count1[c];
+    rng = Rng{rs[0], rs[1], rs[2], rs[3]};
+  }
+
+  int next_rec = P.rec_step, rec_row = P.rec_row;
+  for (int s = 0; s < P.n_steps; ++s) {
+    const long long n = P.step_base + s + 1;
+    bool acc0, acc1;
+    // --- parameterisation 0 ---
+    float lp = M.template grad<true>(q, g);
+    load_row(M, P.eps0, eps);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) eps[i] *= kap[0];
+    float la = hmc_transition<Lane>(M, rng, P.L, eps, q, g, lp, acc0);
+    nacc0 += acc0 ? 1u : 0u;
+    adapt_update(P.adapt_kind, n, P.n_adapt, P.adapt_target, P.adapt_rate, la, kap[0], es[0], la_[0]);
+    M.to_centered(q, x);
+    // --- parameterisation 1 ---
+    M.set_param(av1, bv1);
+    M.from_centered(x, q);
+    lp = M.template grad<true>(q, g);
+    load_row(M, P.eps0_1, eps);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) eps[i] *= kap[1];
+    la = hmc_transition<Lane>(M, rng, P.L1, eps, q, g, lp, acc1);
+    nacc1 += acc1 ? 1u : 0u;
+    adapt_update(P.adapt_kind, n, P.n_adapt, P.adapt_target, P.adapt_rate, la, kap[1], es[1], la_[1]);
+    M.to_centered(q, x);
+    M.set_param(av0, bv0);
+    M.from_centered(x, q);
+
+    if (s == next_rec && rec_row < P.n_samples) {
+      if (P.trace) {
+        float* row = P.trace + ((size_t)rec_row * P.C + c) * D;
+        // x already holds the centred state; q the parameterisation-0 state the reference records
+        if (P.trace_centered) store_row(M, row, x, live); else store_row(M, row, q, live);
+      }
+      if (live && slot == 0) {
+        if (P.trace_accept) P.trace_accept[(size_t)rec_row * P.C + c] = acc0 ? 1 : 0;
+        if (P.trace_accept1) P.trace_accept1[(size_t)rec_row * P.C + c] = acc1 ? 1 : 0;
+      }
+      next_rec += P.thin;
+      rec_row += 1;
+    }
+  }
+
+  store_row(M, qrow, q, live);
+  if (live) {
+    rs[0] = rng.s0; rs[1] = rng.s1; rs[2] = rng.s2; rs[3] = rng.s3;
+    if (slot == 0) {
+      P.adapt[c * 4 + 0] = kap[0]; P.adapt[c * 4 + 1] = es[0]; P.adapt[c * 4 + 2] = la_[0];
+      P.adapt1[c * 4 + 0] = kap[1]; P.adapt1[c * 4 + 1] = es[1]; P.adapt1[c * 4 + 2] = la_[1];
+      P.accept_count[c] = nacc0; P.accept_count1[c] = nacc1;
     }
   }
 }

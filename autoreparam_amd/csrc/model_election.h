@@ -45,6 +45,20 @@ struct ElectionLane {
     if (nloc < 0) nloc = 0;
     ndraw = NG + (S + 1 + K - 1) / K;    // RNG layout counts the S+1 groups
     gmap[0] = 0; gmap[1] = 1; gmap[2] = 2 + S; gmap[3] = 3 + S;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      int t = slot + K * i;
+      bool cell = t <= S;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        cn[i][c] = cell ? A.cell_n[t * 4 + c] : 0.0f;
+        cy[i][c] = cell ? A.cell_y[t * 4 + c] : 0.0f;
+      }
+      lat[i] = t < S ? 1.0f : 0.0f;
+    }
+    set_param(av, bv);
+  }
+  ARP_DEV void set_param(const float* av, const float* bv) {
     const float l100 = 6.643856189774724f, l10 = 3.321928094887362f;  // log2
     const float lg[4] = {l100, l10, l100, l100};
     const float sc[4] = {100.0f, 10.0f, 100.0f, 100.0f};
@@ -55,16 +69,9 @@ struct ElectionLane {
     }
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      int t = slot + K * i;
-      bool cell = t <= S, has = t < S;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        cn[i][c] = cell ? A.cell_n[t * 4 + c] : 0.0f;
-        cy[i][c] = cell ? A.cell_y[t * 4 + c] : 0.0f;
-      }
-      al[i] = has ? av[LBASE + t] : 0.0f;
-      be[i] = has ? bv[LBASE + t] : 0.0f;
-      lat[i] = has ? 1.0f : 0.0f;
+      bool has = i < nloc;
+      al[i] = has ? av[LBASE + slot + K * i] : 0.0f;
+      be[i] = has ? bv[LBASE + slot + K * i] : 0.0f;
     }
   }
 

@@ -44,7 +44,7 @@ struct RadonLane {
   // flattened index of replicated global i
   static ARP_DEV int gg(int i) { return i; }
 
-  ARP_DEV void init(const Args& A, const float* av, const float* /*bv*/, int slot_) {
+  ARP_DEV void init(const Args& A, const float* av, const float* bv, int slot_) {
     slot = slot_;
     const int J = A.J;
     nloc = (J - slot + K - 1) / K;
@@ -59,8 +59,13 @@ struct RadonLane {
       sx[i] = ok ? A.sx[j] : 0.0f;
       sy[i] = ok ? A.sy[j] : 0.0f;
       u[i] = ok ? A.u[j] : 0.0f;
-      a[i] = ok ? av[NG + j] : 0.0f;
     }
+    set_param(av, bv);
+  }
+  // (re)load the parameterisation-dependent slice (the interleaved kernel switches it twice per step)
+  ARP_DEV void set_param(const float* av, const float* /*bv*/) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) a[i] = (i < nloc) ? av[LBASE + slot + K * i] : 0.0f;
   }
 
   // Gradient of the log joint at q (and the log joint itself, additive

@@ -38,11 +38,6 @@ struct SchoolsLane {
     nloc = (8 - slot + K - 1) / K;
     if (nloc < 0) nloc = 0;
     ndraw = NG + (8 + K - 1) / K;
-    const float l5 = 2.321928094887362f;  // log2(5)
-    s0i = __builtin_amdgcn_exp2f(-bv[0] * l5);
-    s1i = __builtin_amdgcn_exp2f(-bv[1] * l5);
-    c0 = 5.0f * s0i;
-    c1 = 5.0f * s1i;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       int k = slot + K * i;
@@ -50,8 +45,20 @@ struct SchoolsLane {
       y[i] = ok ? A.y[k] : 0.0f;
       float s = ok ? A.sigma[k] : 1.0f;
       is2[i] = ok ? 1.0f / (s * s) : 0.0f;
-      a[i] = ok ? av[NG + k] : 0.0f;
-      b[i] = ok ? bv[NG + k] : 0.0f;
+    }
+    set_param(av, bv);
+  }
+  ARP_DEV void set_param(const float* av, const float* bv) {
+    const float l5 = 2.321928094887362f;  // log2(5)
+    s0i = __builtin_amdgcn_exp2f(-bv[0] * l5);
+    s1i = __builtin_amdgcn_exp2f(-bv[1] * l5);
+    c0 = 5.0f * s0i;
+    c1 = 5.0f * s1i;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      bool ok = i < nloc;
+      a[i] = ok ? av[LBASE + slot + K * i] : 0.0f;
+      b[i] = ok ? bv[LBASE + slot + K * i] : 0.0f;
     }
   }
 

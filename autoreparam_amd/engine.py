@@ -31,6 +31,9 @@ class ChainState(object):
         self.adapt = torch.zeros(C_, 4, dtype=torch.float32, device=dev)
         self.rng = torch.zeros(C_, _lib.RNG_SLOTS, 4, dtype=torch.int32, device=dev)
         self.accept_count = torch.zeros(C_, dtype=torch.int32, device=dev)
+        # second inner kernel of the interleaved sampler
+        self.adapt1 = torch.zeros(C_, 4, dtype=torch.float32, device=dev)
+        self.accept_count1 = torch.zeros(C_, dtype=torch.int32, device=dev)
         self.step = 0  # transitions done
 
 
@@ -126,6 +129,44 @@ class Engine(object):
         io.trace, io.trace_accept, io.moments = _ptr(trace), _ptr(trace_accept), C.c_void_p(0)
         with torch.cuda.device(self.device):
             _lib.check(self._L.arp_hmc_run(self._h, which, C.byref(cfg), C.byref(io), _stream()))
+        state.step += int(n_steps)
+        return state
+
+
+    def interleaved_run(self, state, eps0_0, eps0_1, n_leapfrog_0, n_leapfrog_1, n_steps, seed=0,
+                        chain_offset=0, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=0, adapt_target=0.75,
+                        adapt_rate=0.05, n_burnin=0, thin=1, trace=None, trace_accept0=None,
+                        trace_accept1=None, trace_centered=True, lanes=0):
+        """Advance `state` by n_steps interleaved steps (parameterisation 0 then 1 per step)."""
+        cfg = _lib.HmcConfig()
+        cfg.n_chains = state.q.shape[0]
+        cfg.n_leapfrog = int(n_leapfrog_0)
+        cfg.n_steps = int(n_steps)
+        cfg.step_base = int(state.step)
+        cfg.chain_offset = int(chain_offset)
+        cfg.seed = int(seed)
+        cfg.adapt_kind = int(adapt_kind)
+        cfg.n_adapt = int(n_adapt)
+        cfg.adapt_target = float(adapt_target)
+        cfg.adapt_rate = float(adapt_rate)
+        cfg.n_burnin = int(n_burnin)
+        cfg.thin = int(thin)
+        cfg.n_samples = int(trace.shape[0]) if trace is not None else (
+            int(trace_accept0.shape[0]) if trace_accept0 is not None else 0)
+        cfg.trace_centered = 1 if trace_centered else 0
+        cfg.lanes_per_chain = int(lanes)
+        io = _lib.InterleavedIO()
+        io.k0.q = _ptr(state.q)
+        io.k0.adapt, io.k0.rng, io.k0.accept_count = _ptr(state.adapt), _ptr(state.rng), _ptr(state.accept_count)
+        self._eps0 = self._dev(eps0_0)
+        self._eps1 = self._dev(eps0_1)
+        io.k0.eps0 = _ptr(self._eps0)
+        io.k0.trace, io.k0.trace_accept = _ptr(trace), _ptr(trace_accept0)
+        io.adapt1, io.accept_count1 = _ptr(state.adapt1), _ptr(state.accept_count1)
+        io.eps0_1 = _ptr(self._eps1)
+        io.trace_accept1 = _ptr(trace_accept1)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.arp_interleaved_run(self._h, C.byref(cfg), int(n_leapfrog_1), C.byref(io), _stream()))
         state.step += int(n_steps)
         return state
 

@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: leapfrog-steps/sec over all chains, radon(PA), 65 536 chains
+per GPU (BASELINE.json metric), on the fused HIP HMC kernel.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one launch of the hot path over the whole chain batch: `--transitions`
+HMC transitions (each `--leapfrog` leapfrog steps + Metropolis test + step-size
+adaptation) for every chain on the rank.  Chains are independent, so ranks shard
+them with no data-path collective (weak scaling: the per-GPU batch is fixed); one
+RCCL all-gather of the acceptance statistics runs after the timed region.
+
+Prints ONE JSON line (see DESIGN.md "Measurement" for the roofline definition).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def algorithmic_bytes_per_transition(D):
+    # read q, grad, logp, 3 adaptation scalars; write the same + accept byte + trace row
+    return 4 * (5 * D + 8) + 1
+
+
+def cpu_baseline(spec, L, n_chains, n_trans, eps0, lanes):
+    """The C oracle (oracle/, a port of the same algorithm) timed on this host's cores."""
+    import oracle
+    orc = oracle.OracleModel(spec)
+    a, b = spec.ab_from_reparam("CP")
+    rs = np.random.RandomState(0)
+    q0 = (0.1 * rs.randn(n_chains, spec.D)).astype(np.float32)
+    st = oracle.new_state(q0, np.float32)
+    t0 = time.time()
+    orc.hmc_run(st, a, b, eps0, L, 16, seed=1, adapt_kind=1, n_adapt=10 ** 6, lanes=lanes)  # warm-up + calibration
+    rate = 16.0 / (time.time() - t0)
+    n_trans = int(min(max(n_trans, 12.0 * rate), 4096))   # about 12 s of CPU work
+    t0 = time.time()
+    orc.hmc_run(st, a, b, eps0, L, n_trans, seed=1, adapt_kind=1, n_adapt=10 ** 6, lanes=lanes)
+    dt = time.time() - t0
+    cores = len(os.sched_getaffinity(0))
+    return {"value": n_chains * n_trans * L / dt, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d chains x %d transitions x L=%d, float32 C oracle with OpenMP over chains, %.1f s"
+                      % (n_chains, n_trans, L, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
+    ap.add_argument("--leapfrog", type=int, default=8)
+    ap.add_argument("--transitions", type=int, default=32, help="HMC transitions per launch (= per step)")
+    ap.add_argument("--dataset", default="PA")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from autoreparam_amd import models, engine, _lib
+    spec = models._spec_radon(args.dataset)
+    eng = engine.Engine(spec, dev)
+    eng.set_param(0, "CP")
+    C, L, T, D = args.chains, args.leapfrog, args.transitions, spec.D
+
+    # synthetic chain population: i.i.d. draws keyed by the global chain id
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    q0 = (0.1 * torch.randn(C, D, generator=g)).to(dev)
+    eps0 = np.full(D, 0.08 / (L / 4.0) ** 2, np.float32)
+    eps0[2] = 0.02 / (L / 4.0) ** 2
+    st = engine.ChainState(q0)
+    S = args.steps * T  # every timed transition appends a trace row
+    trace = torch.empty(min(S, 64), C, D, dtype=torch.float32, device=dev)  # ring of rows that gets overwritten
+
+    def launch(record):
+        # trace rows cycle through a bounded buffer so a long bench does not need S*C*D floats
+        eng.hmc_run(st, eps0, L, T, seed=7, chain_offset=rank * C, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9,
+                    n_burnin=st.step, thin=1, trace=trace[:T] if record else None, trace_centered=True,
+                    lanes=args.lanes)
+
+    for _ in range(args.warmup):
+        launch(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        launch(True)
+        ev[k][1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    # end-of-run statistics exchange (the only collective of the path)
+    acc = st.accept_count.float() / st.step
+    t_coll = 0.0
+    if dist is not None:
+        tm = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        elapsed = float(tm.item())
+        torch.cuda.synchronize(); tc = time.perf_counter()
+        gathered = [torch.empty_like(acc) for _ in range(world)]
+        dist.all_gather(gathered, acc)
+        acc = torch.cat(gathered)
+        torch.cuda.synchronize(); t_coll = time.perf_counter() - tc
+    assert torch.isfinite(st.q).all(), "non-finite chain state"
+    accept_rate = float(acc.mean().item())
+
+    if rank == 0:
+        value = world * C * T * args.steps * L / elapsed
+        BT = algorithmic_bytes_per_transition(D)
+        achieved = C * T * BT / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "leapfrog-steps/sec (all chains), radon(PA) 65536 chains per GPU",
+            "value": value, "unit": "leapfrog-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "radon --dataset=%s --method=CP --inference=HMC, %d chains/GPU, L=%d, "
+                                   "%d transitions per launch, dual-averaging adaptation, centred trace row "
+                                   "every transition" % (args.dataset, C, L, T),
+                       "chains_per_gpu": C, "num_leapfrog_steps": L, "transitions_per_step": T, "D": D,
+                       "lanes_per_chain": args.lanes, "parallelism": "chains sharded, %d rank(s)" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "kernel": "hmc_kernel<RadonLane>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": C * T * BT},
+            "accept_rate": accept_rate, "stats_allgather_s": t_coll,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(spec, L, 4096, 64, eps0, 8)
+            except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,8 +132,31 @@ class OracleModel(object):
         return st
 
 
+def _interleaved(self, st, ab0, ab1, eps0_0, eps0_1, L0, L1, n_steps, seed=0, chain_offset=0, adapt_kind=2,
+                 n_adapt=0, adapt_target=0.75, adapt_rate=0.05, n_burnin=0, thin=1, trace=None, trace_acc0=None,
+                 trace_acc1=None, trace_centered=True, lanes=4):
+    """`st`: dict from new_state plus 'adapt1' and 'accept_count1'."""
+    dtype = st["q"].dtype
+    ns = trace.shape[0] if trace is not None else (trace_acc0.shape[0] if trace_acc0 is not None else 0)
+    cfg = HmcCfg(st["q"].shape[0], L0, n_steps, st["step"], chain_offset, seed, adapt_kind, n_adapt, adapt_target,
+                 adapt_rate, n_burnin, thin, ns, 1 if trace_centered else 0, lanes)
+    f32 = lambda v: np.ascontiguousarray(v, np.float32)
+    a0, b0, a1, b1 = f32(ab0[0]), f32(ab0[1]), f32(ab1[0]), f32(ab1[1])
+    e0, e1 = f32(eps0_0), f32(eps0_1)
+    getattr(lib(), "orc_interleaved_run" + self._sfx(dtype))(
+        self._h, _p(a0), _p(b0), _p(a1), _p(b1), C.byref(cfg), L1, _p(st["q"]), _p(st["adapt"]), _p(st["adapt1"]),
+        _p(st["rng"]), _p(st["accept_count"]), _p(st["accept_count1"]), _p(e0), _p(e1), _p(trace), _p(trace_acc0),
+        _p(trace_acc1))
+    st["step"] += n_steps
+    return st
+
+
+OracleModel.interleaved_run = _interleaved
+
+
 def new_state(q, dtype=np.float64):
     q = np.ascontiguousarray(q, dtype)
     n = q.shape[0]
     return dict(q=q.copy(), grad=np.zeros_like(q), logp=np.zeros(n, dtype), adapt=np.zeros((n, 4), dtype),
+                adapt1=np.zeros((n, 4), dtype), accept_count1=np.zeros(n, np.uint32),
                 rng=np.zeros((n, 16, 4), np.uint32), accept_count=np.zeros(n, np.uint32), step=0)

@@ -484,3 +484,68 @@ int FN(orc_hmc_run)(const orc_model* M, const float* a, const float* b, const or
   }
   return 0;
 }
+
+/* Interleaved sampling, same contract as arp_interleaved_run: per step a
+ * transition under parameterisation (a0,b0), the change of coordinates, a
+ * transition under (a1,b1), and the change back (interleaved.py:113-155);
+ * logp/grad are recomputed ("bootstrapped") after every change of coordinates
+ * (interleaved.py:120-123, 136-139); each inner kernel carries its own
+ * adaptation state (inference.py:288-306). */
+int FN(orc_interleaved_run)(const orc_model* M, const float* a0, const float* b0, const float* a1,
+                            const float* b1, const orc_hmc_cfg* cfg, int L1, REAL* q, REAL* adapt0,
+                            REAL* adapt1, uint32_t* rng, uint32_t* acc0, uint32_t* acc1,
+                            const float* eps0_0, const float* eps0_1, REAL* trace,
+                            uint8_t* trace_acc0, uint8_t* trace_acc1) {
+  const int D = M->D, C = cfg->n_chains, lanes = cfg->lanes;
+#pragma omp parallel
+  {
+    REAL* work = (REAL*)malloc(sizeof(REAL) * (size_t)D * 6);
+    REAL* eps = work + 3 * D; REAL* xc = work + 4 * D; REAL* g = work + 5 * D;
+#pragma omp for schedule(static)
+    for (int c = 0; c < C; ++c) {
+      REAL* qc = q + (size_t)c * D;
+      orc_rng* st = (orc_rng*)(rng + (size_t)c * 16 * 4);
+      REAL k0, e0, l0, k1, e1, l1;
+      uint32_t n0, n1;
+      if (cfg->step_base == 0) {
+        k0 = k1 = 1; e0 = e1 = 0; l0 = l1 = 0; n0 = n1 = 0;
+        for (int s = 0; s < lanes; ++s)
+          st[s] = orc_rng_seed(cfg->seed, (uint64_t)(cfg->chain_offset + c), (uint32_t)s, (uint32_t)lanes);
+      } else {
+        k0 = adapt0[c * 4]; e0 = adapt0[c * 4 + 1]; l0 = adapt0[c * 4 + 2];
+        k1 = adapt1[c * 4]; e1 = adapt1[c * 4 + 1]; l1 = adapt1[c * 4 + 2];
+        n0 = acc0[c]; n1 = acc1[c];
+      }
+      for (int s = 0; s < cfg->n_steps; ++s) {
+        const long long n = cfg->step_base + s + 1;
+        int a_0, a_1;
+        REAL lp = FN(logp_grad)(M, a0, b0, qc, g);
+        for (int d = 0; d < D; ++d) eps[d] = (REAL)eps0_0[d] * k0;
+        REAL la = FN(hmc_transition)(M, a0, b0, st, lanes, cfg->n_leapfrog, eps, qc, g, &lp, &a_0, work);
+        n0 += (uint32_t)a_0;
+        FN(adapt_update)(cfg->adapt_kind, n, cfg->n_adapt, (REAL)cfg->adapt_target, (REAL)cfg->adapt_rate, la, &k0, &e0, &l0);
+        FN(to_centered)(M, a0, b0, qc, xc);
+        FN(from_centered)(M, a1, b1, xc, qc);
+        lp = FN(logp_grad)(M, a1, b1, qc, g);
+        for (int d = 0; d < D; ++d) eps[d] = (REAL)eps0_1[d] * k1;
+        la = FN(hmc_transition)(M, a1, b1, st, lanes, L1, eps, qc, g, &lp, &a_1, work);
+        n1 += (uint32_t)a_1;
+        FN(adapt_update)(cfg->adapt_kind, n, cfg->n_adapt, (REAL)cfg->adapt_target, (REAL)cfg->adapt_rate, la, &k1, &e1, &l1);
+        FN(to_centered)(M, a1, b1, qc, xc);
+        FN(from_centered)(M, a0, b0, xc, qc);
+        const long long k = n - 1 - cfg->n_burnin;
+        if (k >= 0 && k % cfg->thin == 0 && k / cfg->thin < cfg->n_samples) {
+          const long long r = k / cfg->thin;
+          if (trace) memcpy(trace + ((size_t)r * C + c) * D, cfg->trace_centered ? xc : qc, sizeof(REAL) * D);
+          if (trace_acc0) trace_acc0[(size_t)r * C + c] = (uint8_t)a_0;
+          if (trace_acc1) trace_acc1[(size_t)r * C + c] = (uint8_t)a_1;
+        }
+      }
+      adapt0[c * 4] = k0; adapt0[c * 4 + 1] = e0; adapt0[c * 4 + 2] = l0;
+      adapt1[c * 4] = k1; adapt1[c * 4 + 1] = e1; adapt1[c * 4 + 2] = l1;
+      acc0[c] = n0; acc1[c] = n1;
+    }
+    free(work);
+  }
+  return 0;
+}

@@ -174,3 +174,40 @@ def test_full_size_headline_invariants(gpu):
     assert 0.55 < acc < 0.95
     m = st.q.double().mean(dim=0).cpu().numpy()
     np.testing.assert_allclose(m[:3], (1.3389, -0.0480, -0.1026), atol=0.01)
+
+
+@pytest.mark.parametrize("mname", ["8schools", "radon_PA", "election"])
+def test_interleaved_matches_oracle(oracle_lib, gpu, mname):
+    """Interleaved CP/NCP kernel (interleaved.py:113-155) against the float32 oracle:
+    fixed small step sizes during the compared stretch, simple adaptation on."""
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec(mname)
+    eng = _eng(mname, gpu)
+    orc = oracle_lib.OracleModel(sp)
+    cp, ncp = helpers.params(sp, "CP"), helpers.params(sp, "NCP")
+    eng.set_param(0, cp); eng.set_param(1, ncp)
+    Cn = 96
+    q0 = helpers.states(sp, Cn, seed=6, scale=0.1)
+    e0 = _eps0(oracle_lib, sp, cp[0], cp[1], q0, 0.03)
+    q0n = orc.transform(q0, ncp[0], ncp[1], to_centered=False).astype(np.float32)
+    e1 = _eps0(oracle_lib, sp, ncp[0], ncp[1], q0n, 0.03)
+    for lanes in LANES[mname][-2:]:
+        st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+        tr = torch.zeros(3, Cn, sp.D, device=gpu)
+        t0 = torch.zeros(3, Cn, dtype=torch.uint8, device=gpu); t1 = torch.zeros(3, Cn, dtype=torch.uint8, device=gpu)
+        kw = dict(seed=13, chain_offset=77, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=4, n_burnin=1, thin=2, lanes=lanes)
+        eng.interleaved_run(st, e0, e1, 3, 2, 3, trace=tr, trace_accept0=t0, trace_accept1=t1, **kw)
+        eng.interleaved_run(st, e0, e1, 3, 2, 3, trace=tr, trace_accept0=t0, trace_accept1=t1, **kw)  # chunked
+        so = oracle_lib.new_state(q0, np.float32)
+        tro = np.zeros((3, Cn, sp.D), np.float32); t0o = np.zeros((3, Cn), np.uint8); t1o = np.zeros((3, Cn), np.uint8)
+        orc.interleaved_run(so, cp, ncp, e0, e1, 3, 2, 6, trace=tro, trace_acc0=t0o, trace_acc1=t1o, **kw)
+        scale = np.abs(so["q"]).max() + 1.0
+        err = np.abs(st.q.cpu().numpy() - so["q"]).max(axis=1) / scale
+        ok = err <= 2e-4
+        assert ok.mean() >= 0.95, (lanes, ok.mean(), np.sort(err)[-4:])
+        assert np.array_equal(st.accept_count.cpu().numpy()[ok], so["accept_count"][ok])
+        assert np.array_equal(st.accept_count1.cpu().numpy()[ok], so["accept_count1"][ok])
+        assert np.abs(tr.cpu().numpy()[:, ok] - tro[:, ok]).max() <= 2e-4 * scale
+        assert np.array_equal(t0.cpu().numpy()[:, ok], t0o[:, ok]) and np.array_equal(t1.cpu().numpy()[:, ok], t1o[:, ok])
+        np.testing.assert_allclose(st.adapt.cpu().numpy()[ok, 0], so["adapt"][ok, 0], rtol=1e-5)
+        np.testing.assert_allclose(st.adapt1.cpu().numpy()[ok, 0], so["adapt1"][ok, 0], rtol=1e-5)

@@ -167,3 +167,44 @@ def test_non_finite_energy_rejects(oracle_lib):
     orc.hmc_run(st, a, b, eps0, 4, 5, seed=3, lanes=1)
     assert np.isfinite(st["q"]).all()
     assert (st["accept_count"] <= 5).all()
+
+
+def test_interleaved_step_structure(oracle_lib):
+    """One interleaved step == CP transition, to_ncp, NCP transition, to_cp, with
+    logp/grad re-bootstrapped after each change of coordinates (interleaved.py:113-155).
+    Rebuilt here from single hmc_run calls that share the same RNG streams."""
+    sp = helpers.spec("radon_MN")
+    orc = oracle_lib.OracleModel(sp)
+    cp, ncp = helpers.params(sp, "CP"), helpers.params(sp, "NCP")
+    q0 = helpers.states(sp, 6, seed=4)
+    e0 = np.full(sp.D, 0.05, np.float32); e1 = np.full(sp.D, 0.08, np.float32)
+    st = oracle_lib.new_state(q0)
+    orc.interleaved_run(st, cp, ncp, e0, e1, 3, 2, 2, seed=21, adapt_kind=2, n_adapt=1, lanes=4)
+    # manual: each half step is a fresh single-transition run whose rng/adapt state is carried over by hand
+    man = oracle_lib.new_state(q0)
+    rng = None; ad = [np.zeros((6, 4)), np.zeros((6, 4))]; ad[0][:, 0] = 1; ad[1][:, 0] = 1
+    q = q0.astype(np.float64)
+    for n in (1, 2):
+        for w, (ab, eps, L) in enumerate(((cp, e0, 3), (ncp, e1, 2))):
+            h = oracle_lib.new_state(q)
+            h["step"] = n - 1           # transition index drives the adaptation window
+            if n - 1 > 0 or w > 0:
+                # not the first call: continue the streams; logp/grad must be re-bootstrapped
+                h["rng"] = rng
+                h["logp"], h["grad"] = orc.logp_grad(q, ab[0], ab[1])
+                h["adapt"] = ad[w].copy()
+                if n - 1 == 0:          # step_base 0 would reseed: emulate by shifting the window
+                    h["step"] = 0
+            if h["step"] == 0 and (n - 1 > 0 or w > 0):
+                # run with step_base = 1 and an adaptation window one longer (same decisions)
+                h["step"] = 1
+                orc.hmc_run(h, ab[0], ab[1], eps, L, 1, seed=21, adapt_kind=2, n_adapt=2, lanes=4)
+            else:
+                orc.hmc_run(h, ab[0], ab[1], eps, L, 1, seed=21, adapt_kind=2, n_adapt=1 if n == 1 else 0, lanes=4)
+            rng = h["rng"]; ad[w] = h["adapt"]
+            xc = orc.transform(h["q"], ab[0], ab[1], True)
+            other = ncp if w == 0 else cp
+            q = orc.transform(xc, other[0], other[1], False)
+    np.testing.assert_allclose(st["q"], q, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(st["adapt"][:, 0], ad[0][:, 0], rtol=1e-12)
+    np.testing.assert_allclose(st["adapt1"][:, 0], ad[1][:, 0], rtol=1e-12)
