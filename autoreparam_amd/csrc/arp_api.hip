@@ -313,9 +313,35 @@ int arp_interleaved_run(arp_model* m, const arp_hmc_config* cfg, int n_leapfrog_
   return 0;
 }
 
-int arp_vi_run(arp_model*, int, const arp_vi_config*, const arp_vi_io*, void*) {
-  set_error("arp_vi_run: not built yet");
-  return 1;
+int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_io* io, void* stream) {
+  if (!m || !cfg || !io || which < 0 || which > 1) { set_error("arp_vi_run: null argument"); return 1; }
+  if (cfg->n_lr <= 0 || cfg->n_steps <= 0 || cfg->n_mc <= 0 || cfg->n_mc > 4096) {
+    set_error("arp_vi_run: n_lr, n_steps must be positive and 0 < n_mc <= 4096");
+    return 1;
+  }
+  if (!io->lr || !io->loc || !io->rho || !io->elbo || (cfg->learn_a && !io->w)) {
+    set_error("arp_vi_run: lr, loc, rho, elbo (and w when learn_a) are required");
+    return 1;
+  }
+  if (m->D > kViDmax) { set_error("arp_vi_run: model dimension exceeds the VI kernel's limit"); return 1; }
+  const auto* fam = family(m);
+  if (!fam) { set_error("model family has no kernels"); return 1; }
+  // the VI kernel wants the smallest per-lane slice: the widest lanes-per-chain instantiation
+  int Kmax = 0;
+  for (const auto& o : *fam) Kmax = std::max(Kmax, o.K);
+  const LaneOps* o = pick(*fam, m->n_groups, Kmax, 1 << 30);
+  if (!o) { set_error("no kernel instantiation covers this group count"); return 1; }
+  ViParams P;
+  P.n_steps = cfg->n_steps; P.n_mc = cfg->n_mc; P.learn_a = cfg->learn_a; P.tied_b = cfg->tied_b; P.D = m->D;
+  P.seed = cfg->seed;
+  P.const_base = (float)m->const_base;
+  P.n_top = (int)m->top_scale.size();
+  for (int k = 0; k < 4; ++k) { P.top_idx[k] = 0; P.top_logscale[k] = 0.f; }
+  for (int k = 0; k < P.n_top; ++k) { P.top_idx[k] = m->top_scale[k].first; P.top_logscale[k] = (float)m->top_scale[k].second; }
+  P.lr = io->lr; P.loc = io->loc; P.rho = io->rho; P.w = io->w; P.elbo = io->elbo;
+  o->vi(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, cfg->n_lr, (hipStream_t)stream);
+  ARP_HIP_OK(hipGetLastError());
+  return 0;
 }
 
 }  // extern "C"

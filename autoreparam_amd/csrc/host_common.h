@@ -35,6 +35,7 @@ struct LaneOps {
   void (*hmc)(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s);
   void (*interleaved)(const void* args, const float* a0, const float* b0, const float* a1, const float* b1,
                       const HmcParams& P, hipStream_t s);
+  void (*vi)(const void* args, const float* a, const float* b, const ViParams& P, int n_lr, hipStream_t s);
 };
 
 template <class Lane>
@@ -59,7 +60,11 @@ struct Launch {
     hipLaunchKernelGGL(interleaved_kernel<Lane>, dim3(blocks(P.C)), dim3(kBlock), 0, s,
                        *(const typename Lane::Args*)args, a0, b0, a1, b1, P);
   }
-  static LaneOps ops() { return LaneOps{Lane::K, Lane::NL, &logp_grad, &transform, &hmc, &interleaved}; }
+  static void vi(const void* args, const float* a, const float* b, const ViParams& P, int n_lr, hipStream_t s) {
+    hipLaunchKernelGGL(vi_kernel<Lane>, dim3(n_lr), dim3(kViBlock), 0, s,
+                       *(const typename Lane::Args*)args, a, b, P);
+  }
+  static LaneOps ops() { return LaneOps{Lane::K, Lane::NL, &logp_grad, &transform, &hmc, &interleaved, &vi}; }
 };
 
 // per-family tables (defined in inst_*.hip)

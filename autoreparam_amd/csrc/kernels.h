@@ -377,4 +377,180 @@ __global__ __launch_bounds__(kBlock) void interleaved_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Mean-field VI (inference.find_best_learning_rate, inference.py:26-154, on
+// util.get_mean_field_elbo, util.py:232-268): q(z) = prod N(loc, softplus(rho)),
+// ELBO estimated with n_mc reparameterised draws, Adam on -ELBO with the
+// reference's three-stage learning-rate decay, NaN gradients zeroed.  One
+// workgroup runs one learning rate for all optimisation steps, so the whole
+// sweep is a single launch instead of n_lr x n_steps session round trips.
+// With learn_a the VIP parameter a = sigmoid(w) is optimised too (cVIP,
+// program_transformations.py:507-510).
+// ---------------------------------------------------------------------------
+constexpr int kViBlock = 512;
+constexpr int kViDmax = 128;
+
+struct ViParams {
+  int n_steps, n_mc, learn_a, tied_b, D;
+  unsigned long long seed;
+  float const_base;            // parameterisation independent part of the dropped constant
+  int n_top; int top_idx[4]; float top_logscale[4];   // -b_i log(scale_i) of the top-level latents
+  const float* lr; float* loc; float* rho; float* w; float* elbo;
+};
+
+template <int K>
+ARP_DEV float chain_sum(float v) {  // sum over the 64/K chains of a wave, result in every lane
+#pragma unroll
+  for (int off = K; off < 64; off <<= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+template <class Lane>
+__global__ __launch_bounds__(kViBlock) void vi_kernel(
+    typename Lane::Args A, const float* __restrict__ av, const float* __restrict__ bv, ViParams P) {
+  constexpr int K = Lane::K, ND = Lane::ND, NG = Lane::NG;
+  __shared__ float s_loc[kViDmax], s_sig[kViDmax], s_lsig[kViDmax], s_a[kViDmax], s_b[kViDmax];
+  __shared__ float s_acc[4][kViDmax];   // sum g, sum g*eps, sum dlogp/da, sum dlogp/db
+  __shared__ float s_elbo;
+  const int D = P.D, tid = threadIdx.x, lr_i = blockIdx.x;
+  const int slot = tid % K, chain0 = tid / K;
+  constexpr int chains_per_pass = kViBlock / K;
+  const int passes = (P.n_mc + chains_per_pass - 1) / chains_per_pass;
+
+  // parameter owned by this thread (tid < D): Adam moments live in registers
+  float loc = 0.f, rho = 0.f, w = 0.f, m1[3] = {0.f, 0.f, 0.f}, m2[3] = {0.f, 0.f, 0.f};
+  if (tid < D) {
+    loc = P.loc[(size_t)lr_i * D + tid];
+    rho = P.rho[(size_t)lr_i * D + tid];
+    if (P.learn_a) w = P.w[(size_t)lr_i * D + tid];
+    s_a[tid] = av[tid]; s_b[tid] = bv[tid];
+  }
+  const float base_lr = P.lr[lr_i];
+  Lane M;
+  __syncthreads();
+  M.init(A, s_a, s_b, slot);
+  Rng rng[1];
+  // one stream per (learning rate, first-pass sample, slot); later passes continue it
+  rng[0] = rng_seed(P.seed ^ 0x5649564956495649ull, ((unsigned long long)lr_i << 32) | (unsigned)chain0,
+                    (uint32_t)slot, (uint32_t)K);
+  float b1t = 1.0f, b2t = 1.0f;
+
+  for (int step = 0; step < P.n_steps; ++step) {
+    if (tid < D) {
+      float sp = rho > 20.0f ? rho : fast_log(1.0f + fast_exp(rho));   // softplus
+      s_loc[tid] = loc; s_sig[tid] = sp; s_lsig[tid] = fast_log(sp);
+      if (P.learn_a) {
+        float a = sigmoidf_(w);
+        s_a[tid] = a;
+        if (P.tied_b) s_b[tid] = a;
+      }
+      s_acc[0][tid] = 0.f; s_acc[1][tid] = 0.f; s_acc[2][tid] = 0.f; s_acc[3][tid] = 0.f;
+    }
+    if (tid == 0) s_elbo = 0.f;
+    __syncthreads();
+    if (P.learn_a) M.set_param(s_a, s_b);
+
+    float lc[ND], sg[ND], ls[ND];
+    load_row(M, s_loc, lc); load_row(M, s_sig, sg); load_row(M, s_lsig, ls);
+    float acc[4][ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; acc[2][i] = 0.f; acc[3][i] = 0.f; }
+    float elbo = 0.f;
+    for (int pass = 0; pass < passes; ++pass) {
+      const bool live = chain0 + pass * chains_per_pass < P.n_mc;
+      float eps[ND], z[ND], g[ND];
+#pragma unroll
+      for (int i = 0; i < ND; i += 2) {
+        float z0 = 0.f, z1 = 0.f;
+        if (i < M.ndraw) {
+          uint32_t w0 = rng_next(rng[0]), w1 = rng_next(rng[0]);
+          normal_pair(w0, w1, z0, z1);
+        }
+        eps[i] = z0;
+        if (i + 1 < ND) eps[i + 1] = z1;
+      }
+      float ent = 0.f, entg = 0.f;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        if (i < NG) {
+          eps[i] = group_bcast0<K>(eps[i], slot);
+          entg += fmaf(0.5f * eps[i], eps[i], ls[i]);
+        } else {
+          bool ok = (i - NG) < M.nloc;
+          eps[i] = ok ? eps[i] : 0.f;
+          ent += ok ? fmaf(0.5f * eps[i], eps[i], ls[i]) : 0.f;
+        }
+        z[i] = fmaf(sg[i], eps[i], lc[i]);
+      }
+      float lp = M.template grad<true>(z, g);
+      // one ELBO sample: log p(z) - log q(z), the 0.5 log 2pi per latent added by the host-side constant
+      float e = lp + group_sum<K>(ent) + entg;
+      if (live) {
+        elbo += e;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) { acc[0][i] += g[i]; acc[1][i] = fmaf(g[i], eps[i], acc[1][i]); }
+        if (P.learn_a) {
+          float da[ND], db[ND];
+          M.dparam(z, g, da, db);
+#pragma unroll
+          for (int i = 0; i < ND; ++i) { acc[2][i] += da[i]; acc[3][i] += db[i]; }
+        }
+      }
+    }
+    // reduce over the chains of the wave, then over waves through LDS
+    const int nq = P.learn_a ? 4 : 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k >= nq) break;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        float v = chain_sum<K>(acc[k][i]);
+        if ((tid & 63) < K) {
+          if (i < NG) { if (slot == 0) atomicAdd(&s_acc[k][M.gg(i)], v); }
+          else if ((i - NG) < M.nloc) atomicAdd(&s_acc[k][Lane::LBASE + slot + K * (i - NG)], v);
+        }
+      }
+    }
+    elbo = chain_sum<K>(elbo);
+    if ((tid & 63) == 0) atomicAdd(&s_elbo, elbo);
+    __syncthreads();
+
+    // Adam (tf.train.AdamOptimizer defaults) on -ELBO with NaN gradients zeroed
+    // (inference.py:47, 62-66) and the learning-rate schedule of inference.py:69-75
+    float lr = base_lr;
+    if (3 * step > 2 * P.n_steps) lr = base_lr / 20.0f; else if (3 * step > P.n_steps) lr = base_lr / 5.0f;
+    b1t *= 0.9f; b2t *= 0.999f;
+    const float lr_t = lr * __builtin_amdgcn_sqrtf(1.0f - b2t) / (1.0f - b1t);
+    if (tid < D) {
+      const float inv = 1.0f / (float)P.n_mc;
+      const float sgm = s_sig[tid];
+      float gr[3];
+      gr[0] = -s_acc[0][tid] * inv;
+      gr[1] = -(s_acc[1][tid] * inv + 1.0f / sgm) * sigmoidf_(rho);
+      float a = s_a[tid];
+      gr[2] = P.learn_a ? -((s_acc[2][tid] + (P.tied_b ? s_acc[3][tid] : 0.f)) * inv) * a * (1.0f - a) : 0.f;
+      float* par[3] = {&loc, &rho, &w};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float gk = gr[k];
+        if (!(gk == gk)) gk = 0.f;
+        m1[k] = 0.9f * m1[k] + 0.1f * gk;
+        m2[k] = 0.999f * m2[k] + 0.001f * gk * gk;
+        if (k < 2 || P.learn_a) *par[k] -= lr_t * m1[k] / (__builtin_amdgcn_sqrtf(m2[k]) + 1e-8f);
+      }
+    }
+    if (tid == 0) {
+      float c = P.const_base + 0.9189385332046727f * (float)D;   // + 0.5 log 2pi per latent from -log q
+      for (int k = 0; k < P.n_top; ++k) c -= s_b[P.top_idx[k]] * P.top_logscale[k];
+      P.elbo[(size_t)lr_i * P.n_steps + step] = s_elbo / (float)P.n_mc + c;
+    }
+    __syncthreads();
+  }
+  if (tid < D) {
+    P.loc[(size_t)lr_i * D + tid] = loc;
+    P.rho[(size_t)lr_i * D + tid] = rho;
+    if (P.learn_a) P.w[(size_t)lr_i * D + tid] = w;
+  }
+}
+
 }  // namespace arp

@@ -126,6 +126,20 @@ struct ElectionLane {
     return lp;
   }
 
+  // d logp / d a, d logp / d b from the state gradient (see model_radon.h)
+  ARP_DEV void dparam(const float (&q)[ND], const float (&g)[ND], float (&da)[ND], float (&db)[ND]) const {
+    const float lns[4] = {4.605170185988092f, 2.302585092994046f, 4.605170185988092f, 4.605170185988092f};
+    const float mua = cs[0] * q[0], ls = cs[1] * q[1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { da[i] = 0.0f; db[i] = -lns[i] * fmaf(q[i], g[i], 1.0f); }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      bool ok = i < nloc;
+      da[NG + i] = ok ? -mua * g[NG + i] : 0.0f;
+      db[NG + i] = ok ? -ls * fmaf(q[NG + i] - al[i] * mua, g[NG + i], 1.0f) : 0.0f;
+    }
+  }
+
   ARP_DEV void to_centered(const float (&q)[ND], float (&x)[ND]) const {
     const float mua = cs[0] * q[0], ls = cs[1] * q[1];
     x[0] = mua; x[1] = ls; x[2] = cs[2] * q[2]; x[3] = cs[3] * q[3];

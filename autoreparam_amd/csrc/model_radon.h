@@ -106,6 +106,15 @@ struct RadonLane {
     return lp;
   }
 
+  // d logp / d a_i and d logp / d b_i from the state gradient g (cVIP learns a):
+  //   d/da = -mu g,   d/db = -log(sigma) (1 + (xt - a mu) g);   here sigma = 1.
+  ARP_DEV void dparam(const float (&q)[ND], const float (&g)[ND], float (&da)[ND], float (&db)[ND]) const {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) { da[i] = 0.0f; db[i] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) da[NG + i] = -fmaf(u[i], q[1], q[0]) * g[NG + i];
+  }
+
   // reparameterised -> centred coordinates
   ARP_DEV void to_centered(const float (&q)[ND], float (&x)[ND]) const {
     x[0] = q[0]; x[1] = q[1]; x[2] = q[2];

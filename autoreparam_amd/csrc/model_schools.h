@@ -92,6 +92,21 @@ struct SchoolsLane {
     return lp;
   }
 
+  // d logp / d a, d logp / d b from the state gradient (see model_radon.h)
+  ARP_DEV void dparam(const float (&q)[ND], const float (&g)[ND], float (&da)[ND], float (&db)[ND]) const {
+    const float ln5 = 1.6094379124341003f;
+    const float mu = c0 * q[0], lt = c1 * q[1];
+    da[0] = 0.0f; da[1] = 0.0f;
+    db[0] = -ln5 * fmaf(q[0], g[0], 1.0f);
+    db[1] = -ln5 * fmaf(q[1], g[1], 1.0f);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      bool ok = i < nloc;
+      da[NG + i] = ok ? -mu * g[NG + i] : 0.0f;
+      db[NG + i] = ok ? -lt * fmaf(q[NG + i] - a[i] * mu, g[NG + i], 1.0f) : 0.0f;
+    }
+  }
+
   ARP_DEV void to_centered(const float (&q)[ND], float (&x)[ND]) const {
     const float mu = c0 * q[0], lt = c1 * q[1];
     x[0] = mu; x[1] = lt;

@@ -171,6 +171,28 @@ class Engine(object):
         return state
 
 
+    # -- mean-field VI ----------------------------------------------------------
+    def vi_run(self, lr, loc, rho, n_steps, n_mc, which=0, w=None, tied_b=False, seed=0):
+        """Run len(lr) independent Adam optimisations of the mean-field ELBO in one launch.
+
+        loc, rho (and w, the unconstrained VIP parameter, when given) are [n_lr, D]
+        device tensors updated in place; returns the ELBO timeline [n_lr, n_steps]."""
+        lr_t = self._dev(np.asarray(lr, np.float32))
+        n_lr = lr_t.shape[0]
+        assert loc.shape == (n_lr, self.D) and rho.shape == (n_lr, self.D)
+        elbo = torch.empty(n_lr, int(n_steps), dtype=torch.float32, device=self.device)
+        cfg = _lib.ViConfig()
+        cfg.n_lr, cfg.n_steps, cfg.n_mc = n_lr, int(n_steps), int(n_mc)
+        cfg.learn_a = 1 if w is not None else 0
+        cfg.tied_b = 1 if tied_b else 0
+        cfg.seed = int(seed)
+        io = _lib.ViIO()
+        io.lr, io.loc, io.rho, io.w, io.elbo = _ptr(lr_t), _ptr(loc), _ptr(rho), _ptr(w), _ptr(elbo)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.arp_vi_run(self._h, which, C.byref(cfg), C.byref(io), _stream()))
+        return elbo
+
+
 # ---------------------------------------------------------------------------
 # State converters with the reference's calling convention (models.py:56-128):
 # callables on lists of [C, *event] arrays, evaluated on the device.

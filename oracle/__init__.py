@@ -153,6 +153,40 @@ def _interleaved(self, st, ab0, ab1, eps0_0, eps0_1, L0, L1, n_steps, seed=0, ch
 
 OracleModel.interleaved_run = _interleaved
 
+_TOP = {"8schools": lambda D: [(0, 5.0), (1, 5.0)], "radon": lambda D: [],
+        "german_credit_lognormalcentered": lambda D: [(0, 10.0)],
+        "election": lambda D: [(0, 100.0), (1, 10.0), (D - 2, 100.0), (D - 1, 100.0)]}
+
+
+def _vi_run(self, a, b, lr, loc, rho, w, n_steps, n_mc, learn_a=False, tied_b=False, seed=0, lanes=16, block=512):
+    """find_best_learning_rate's optimisation loops: returns (elbo [n_lr, n_steps]); loc/rho/w updated in place."""
+    dtype = loc.dtype
+    n_lr = len(lr)
+    top = _TOP[self.spec.name](self.D)
+    # parameterisation independent part of the dropped constant (CP constant + sum log scale of top-level latents)
+    base = lib().orc_model_logp_const(self._h) + sum(np.log(s) for _, s in top)
+    idx = np.ascontiguousarray([i for i, _ in top] + [0] * (4 - len(top)), np.int32)
+    lsc = np.ascontiguousarray([np.log(s) for _, s in top] + [0.0] * (4 - len(top)), np.float64)
+    elbo = np.zeros((n_lr, n_steps), dtype)
+    f32 = lambda v: np.ascontiguousarray(v, np.float32)
+    a, b, lr = f32(a), f32(b), f32(lr)
+    getattr(lib(), "orc_vi_run" + self._sfx(dtype))(
+        self._h, _p(a), _p(b), n_lr, n_steps, n_mc, int(learn_a), int(tied_b), C.c_uint64(seed), lanes, block, _p(lr),
+        _p(loc), _p(rho), _p(w) if w is not None else C.c_void_p(0), _p(elbo), C.c_double(base), len(top), _p(idx), _p(lsc))
+    return elbo
+
+
+def _dparam(self, x, a, b):
+    x = np.ascontiguousarray(x, np.float64)
+    da = np.zeros_like(x); db = np.zeros_like(x)
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    lib().orc_dparam_f64(self._h, _p(a), _p(b), _p(x), _p(da), _p(db))
+    return da, db
+
+
+OracleModel.vi_run = _vi_run
+OracleModel.dparam = _dparam
+
 
 def new_state(q, dtype=np.float64):
     q = np.ascontiguousarray(q, dtype)

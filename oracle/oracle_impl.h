@@ -549,3 +549,132 @@ int FN(orc_interleaved_run)(const orc_model* M, const float* a0, const float* b0
   }
   return 0;
 }
+
+/* d logp / d a_i, d logp / d b_i (cVIP learns a): with xt ~ N(a mu, sigma^b) and
+ * g = d logp / d xt,  d/da = -mu g,  d/db = -log(sigma) (1 + (xt - a mu) g)
+ * (derived from program_transformations.py:569-576; checked against autograd in tests). */
+static void FN(dparam)(const orc_model* M, const float* a, const float* b, const REAL* x, const REAL* g,
+                       REAL* da, REAL* db) {
+  const int D = M->D;
+  REAL* xc = (REAL*)malloc(sizeof(REAL) * D);
+  REAL* mu = (REAL*)calloc(D, sizeof(REAL));
+  REAL* ls = (REAL*)calloc(D, sizeof(REAL));
+  FN(to_centered)(M, a, b, x, xc);
+  switch (M->model) {
+    case 0: ls[0] = ls[1] = (REAL)log(5.0); for (int k = 0; k < 8; ++k) { mu[2 + k] = xc[0]; ls[2 + k] = xc[1]; } break;
+    case 1: for (int j = 0; j < M->J; ++j) mu[3 + j] = xc[0] + (REAL)M->u[j] * xc[1]; break;
+    case 2: ls[0] = (REAL)log(10.0);
+      for (int d = 0; d < M->F; ++d) { mu[1 + d] = xc[0]; ls[1 + M->F + d] = xc[1 + d]; } break;
+    case 3: ls[0] = (REAL)log(100.0); ls[1] = (REAL)log(10.0);
+      ls[2 + M->S] = ls[3 + M->S] = (REAL)log(100.0);
+      for (int t = 0; t < M->S; ++t) { mu[2 + t] = xc[0]; ls[2 + t] = xc[1]; } break;
+    default: break;
+  }
+  for (int d = 0; d < D; ++d) {
+    da[d] = -mu[d] * g[d];
+    db[d] = -ls[d] * (1 + (x[d] - (REAL)a[d] * mu[d]) * g[d]);
+  }
+  free(xc); free(mu); free(ls);
+}
+int FN(orc_dparam)(const orc_model* M, const float* a, const float* b, const REAL* x, REAL* da, REAL* db) {
+  REAL* g = (REAL*)malloc(sizeof(REAL) * M->D);
+  FN(logp_grad)(M, a, b, x, g);
+  FN(dparam)(M, a, b, x, g, da, db);
+  free(g);
+  return 0;
+}
+
+/* Mean-field VI, same contract as arp_vi_run (inference.py:26-154, util.py:232-268,
+ * program_transformations.py:192-241): q = prod N(loc, softplus(rho)); ELBO from
+ * n_mc reparameterised draws; tf.train.AdamOptimizer defaults on -ELBO; NaN
+ * gradients zeroed; learning rate base, base/5 after a third, base/20 after two
+ * thirds of the steps.  Draw layout: `block/lanes` streams per slot, sample s uses
+ * stream s mod (block/lanes). */
+int FN(orc_vi_run)(const orc_model* M, const float* a_in, const float* b_in, int n_lr, int n_steps, int n_mc,
+                   int learn_a, int tied_b, uint64_t seed, int lanes, int block, const float* lr_in,
+                   REAL* loc_io, REAL* rho_io, REAL* w_io, REAL* elbo_out, double const_base, int n_top,
+                   const int* top_idx, const double* top_logscale) {
+  const int D = M->D, NG = M->n_glob, G = M->n_groups, P = M->n_local_parts;
+  const int per_lane = (G + lanes - 1) / lanes, nd = NG + P * per_lane;
+  const int cpp = block / lanes, passes = (n_mc + cpp - 1) / cpp;
+  for (int li = 0; li < n_lr; ++li) {
+    REAL* loc = loc_io + (size_t)li * D; REAL* rho = rho_io + (size_t)li * D;
+    REAL* w = learn_a ? w_io + (size_t)li * D : NULL;
+    float* a = (float*)malloc(sizeof(float) * D); float* b = (float*)malloc(sizeof(float) * D);
+    memcpy(a, a_in, sizeof(float) * D); memcpy(b, b_in, sizeof(float) * D);
+    orc_rng* streams = (orc_rng*)malloc(sizeof(orc_rng) * (size_t)cpp * lanes);
+    for (int c0 = 0; c0 < cpp; ++c0)
+      for (int s = 0; s < lanes; ++s)
+        streams[c0 * lanes + s] = orc_rng_seed(seed ^ 0x5649564956495649ull, ((uint64_t)li << 32) | (uint32_t)c0,
+                                               (uint32_t)s, (uint32_t)lanes);
+    REAL* m1 = (REAL*)calloc(3 * (size_t)D, sizeof(REAL)); REAL* m2 = (REAL*)calloc(3 * (size_t)D, sizeof(REAL));
+    REAL* sig = (REAL*)malloc(sizeof(REAL) * D); REAL* eps = (REAL*)malloc(sizeof(REAL) * D);
+    REAL* z = (REAL*)malloc(sizeof(REAL) * D); REAL* g = (REAL*)malloc(sizeof(REAL) * D);
+    REAL* da = (REAL*)malloc(sizeof(REAL) * D); REAL* db = (REAL*)malloc(sizeof(REAL) * D);
+    REAL* acc = (REAL*)malloc(sizeof(REAL) * 4 * (size_t)D);
+    REAL b1t = 1, b2t = 1;
+    for (int step = 0; step < n_steps; ++step) {
+      for (int d = 0; d < D; ++d) {
+        sig[d] = rho[d] > 20 ? rho[d] : (REAL)log(1.0 + exp((double)rho[d]));
+        if (learn_a) { a[d] = (float)(1.0 / (1.0 + exp(-(double)w[d]))); if (tied_b) b[d] = a[d]; }
+      }
+      memset(acc, 0, sizeof(REAL) * 4 * (size_t)D);
+      REAL elbo = 0;
+      for (int pass = 0; pass < passes; ++pass) {
+        for (int c0 = 0; c0 < cpp; ++c0) {
+          for (int d = 0; d < D; ++d) eps[d] = 0;
+          for (int s = 0; s < lanes; ++s) {   /* same layout as draw_momentum, without the uniform */
+            orc_rng* r = &streams[c0 * lanes + s];
+            for (int i = 0; i < nd; i += 2) {
+              float z0, z1;
+              uint32_t w0 = orc_rng_next(r), w1 = orc_rng_next(r);
+              orc_normal_pair(w0, w1, &z0, &z1);
+              for (int k = 0; k < 2; ++k) {
+                int ii = i + k; float zz = k ? z1 : z0;
+                if (ii >= nd) break;
+                if (ii < NG) { if (s == 0) eps[M->glob_idx[ii]] = (REAL)zz; }
+                else {
+                  int part = (ii - NG) / per_lane, j = s + lanes * ((ii - NG) % per_lane);
+                  if (j < G && M->group_idx[part * G + j] >= 0) eps[M->group_idx[part * G + j]] = (REAL)zz;
+                }
+              }
+            }
+          }
+          if (c0 + pass * cpp >= n_mc) continue;
+          REAL ent = 0;
+          for (int d = 0; d < D; ++d) { z[d] = loc[d] + sig[d] * eps[d]; ent += (REAL)0.5 * eps[d] * eps[d] + (REAL)log((double)sig[d]); }
+          REAL lp = FN(logp_grad)(M, a, b, z, g);
+          elbo += lp + ent;
+          for (int d = 0; d < D; ++d) { acc[d] += g[d]; acc[D + d] += g[d] * eps[d]; }
+          if (learn_a) {
+            FN(dparam)(M, a, b, z, g, da, db);
+            for (int d = 0; d < D; ++d) { acc[2 * D + d] += da[d]; acc[3 * D + d] += db[d]; }
+          }
+        }
+      }
+      REAL lr = (REAL)lr_in[li];
+      if (3 * step > 2 * n_steps) lr = lr / 20; else if (3 * step > n_steps) lr = lr / 5;
+      b1t *= (REAL)0.9; b2t *= (REAL)0.999;
+      const REAL lr_t = lr * (REAL)sqrt((double)(1 - b2t)) / (1 - b1t);
+      double c = const_base + 0.9189385332046727 * D;
+      for (int k = 0; k < n_top; ++k) c -= (double)b[top_idx[k]] * top_logscale[k];
+      elbo_out[(size_t)li * n_steps + step] = elbo / n_mc + (REAL)c;
+      for (int d = 0; d < D; ++d) {
+        REAL gr[3];
+        gr[0] = -acc[d] / n_mc;
+        gr[1] = -(acc[D + d] / n_mc + 1 / sig[d]) * (REAL)(1.0 / (1.0 + exp(-(double)rho[d])));
+        gr[2] = learn_a ? -((acc[2 * D + d] + (tied_b ? acc[3 * D + d] : 0)) / n_mc) * a[d] * (1 - a[d]) : 0;
+        REAL* par[3] = {&loc[d], &rho[d], learn_a ? &w[d] : NULL};
+        for (int k = 0; k < 3; ++k) {
+          REAL gk = gr[k];
+          if (gk != gk) gk = 0;
+          m1[k * D + d] = (REAL)0.9 * m1[k * D + d] + (REAL)0.1 * gk;
+          m2[k * D + d] = (REAL)0.999 * m2[k * D + d] + (REAL)0.001 * gk * gk;
+          if (par[k]) *par[k] -= lr_t * m1[k * D + d] / ((REAL)sqrt((double)m2[k * D + d]) + (REAL)1e-8);
+        }
+      }
+    }
+    free(a); free(b); free(streams); free(m1); free(m2); free(sig); free(eps); free(z); free(g); free(da); free(db); free(acc);
+  }
+  return 0;
+}

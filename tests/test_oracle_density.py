@@ -124,3 +124,23 @@ def test_radon_closed_form_posterior(oracle_lib):
         np.testing.assert_allclose(mean[:3], mean_e, atol=6e-5)
         np.testing.assert_allclose(sd[:3], sd_e, atol=6e-5)
         assert abs(np.linalg.cond(P) - cond_e) < 0.06
+
+
+@pytest.mark.parametrize("mname", MODELS)
+def test_parameter_gradients_by_finite_differences(oracle_lib, mname):
+    """d logp / d a, d logp / d b (what cVIP optimises) against central differences."""
+    sp = helpers.spec(mname)
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "VIP", seed=6)
+    x = helpers.states(sp, 1, seed=8).astype(np.float64)
+    da, db = orc.dparam(x, a, b)
+    h = 1e-3   # a, b are float32 inside the oracle
+    for d in range(0, sp.D, max(1, sp.D // 10)):
+        for which, ref in ((0, da), (1, db)):
+            vp, vm = [a.copy(), b.copy()], [a.copy(), b.copy()]
+            vp[which][d] += h; vm[which][d] -= h
+            step = float(vp[which][d]) - float(vm[which][d])
+            cp = orc.logp_grad(x, vp[0], vp[1])[0][0] + orc.logp_const(vp[1])
+            cm = orc.logp_grad(x, vm[0], vm[1])[0][0] + orc.logp_const(vm[1])
+            fd = (cp - cm) / step
+            assert abs(fd - ref[0, d]) <= 2e-3 * (abs(ref[0, d]) + 1.0), (d, which, fd, ref[0, d])
