@@ -53,7 +53,7 @@ class ViConfig(C.Structure):
 
 class ViIO(C.Structure):
     _fields_ = [("lr", C.c_void_p), ("loc", C.c_void_p), ("rho", C.c_void_p), ("w", C.c_void_p),
-                ("elbo", C.c_void_p)]
+                ("wb", C.c_void_p), ("elbo", C.c_void_p)]
 
 
 # every symbol include/autoreparam.h declares

@@ -338,7 +338,8 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   P.n_top = (int)m->top_scale.size();
   for (int k = 0; k < 4; ++k) { P.top_idx[k] = 0; P.top_logscale[k] = 0.f; }
   for (int k = 0; k < P.n_top; ++k) { P.top_idx[k] = m->top_scale[k].first; P.top_logscale[k] = (float)m->top_scale[k].second; }
-  P.lr = io->lr; P.loc = io->loc; P.rho = io->rho; P.w = io->w; P.elbo = io->elbo;
+  P.lr = io->lr; P.loc = io->loc; P.rho = io->rho; P.w = io->w; P.wb = cfg->learn_a ? io->wb : nullptr;
+  P.elbo = io->elbo;
   o->vi(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, cfg->n_lr, (hipStream_t)stream);
   ARP_HIP_OK(hipGetLastError());
   return 0;

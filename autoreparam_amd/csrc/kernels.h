@@ -395,7 +395,7 @@ struct ViParams {
   unsigned long long seed;
   float const_base;            // parameterisation independent part of the dropped constant
   int n_top; int top_idx[4]; float top_logscale[4];   // -b_i log(scale_i) of the top-level latents
-  const float* lr; float* loc; float* rho; float* w; float* elbo;
+  const float* lr; float* loc; float* rho; float* w; float* wb; float* elbo;
 };
 
 template <int K>
@@ -418,11 +418,12 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
   const int passes = (P.n_mc + chains_per_pass - 1) / chains_per_pass;
 
   // parameter owned by this thread (tid < D): Adam moments live in registers
-  float loc = 0.f, rho = 0.f, w = 0.f, m1[3] = {0.f, 0.f, 0.f}, m2[3] = {0.f, 0.f, 0.f};
+  float loc = 0.f, rho = 0.f, w = 0.f, wb = 0.f, m1[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
   if (tid < D) {
     loc = P.loc[(size_t)lr_i * D + tid];
     rho = P.rho[(size_t)lr_i * D + tid];
     if (P.learn_a) w = P.w[(size_t)lr_i * D + tid];
+    if (P.wb) wb = P.wb[(size_t)lr_i * D + tid];
     s_a[tid] = av[tid]; s_b[tid] = bv[tid];
   }
   const float base_lr = P.lr[lr_i];
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
         float a = sigmoidf_(w);
         s_a[tid] = a;
         if (P.tied_b) s_b[tid] = a;
+        if (P.wb) s_b[tid] = sigmoidf_(wb);
       }
       s_acc[0][tid] = 0.f; s_acc[1][tid] = 0.f; s_acc[2][tid] = 0.f; s_acc[3][tid] = 0.f;
     }
@@ -524,19 +526,21 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
     if (tid < D) {
       const float inv = 1.0f / (float)P.n_mc;
       const float sgm = s_sig[tid];
-      float gr[3];
+      float gr[4];
       gr[0] = -s_acc[0][tid] * inv;
       gr[1] = -(s_acc[1][tid] * inv + 1.0f / sgm) * sigmoidf_(rho);
       float a = s_a[tid];
       gr[2] = P.learn_a ? -((s_acc[2][tid] + (P.tied_b ? s_acc[3][tid] : 0.f)) * inv) * a * (1.0f - a) : 0.f;
-      float* par[3] = {&loc, &rho, &w};
+      float bb = s_b[tid];
+      gr[3] = P.wb ? -(s_acc[3][tid] * inv) * bb * (1.0f - bb) : 0.f;
+      float* par[4] = {&loc, &rho, &w, &wb};
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < 4; ++k) {
         float gk = gr[k];
         if (!(gk == gk)) gk = 0.f;
         m1[k] = 0.9f * m1[k] + 0.1f * gk;
         m2[k] = 0.999f * m2[k] + 0.001f * gk * gk;
-        if (k < 2 || P.learn_a) *par[k] -= lr_t * m1[k] / (__builtin_amdgcn_sqrtf(m2[k]) + 1e-8f);
+        if (k < 2 || (k == 2 && P.learn_a) || (k == 3 && P.wb)) *par[k] -= lr_t * m1[k] / (__builtin_amdgcn_sqrtf(m2[k]) + 1e-8f);
       }
     }
     if (tid == 0) {
@@ -550,6 +554,7 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
     P.loc[(size_t)lr_i * D + tid] = loc;
     P.rho[(size_t)lr_i * D + tid] = rho;
     if (P.learn_a) P.w[(size_t)lr_i * D + tid] = w;
+    if (P.wb) P.wb[(size_t)lr_i * D + tid] = wb;
   }
 }
 

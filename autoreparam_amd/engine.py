@@ -172,7 +172,7 @@ class Engine(object):
 
 
     # -- mean-field VI ----------------------------------------------------------
-    def vi_run(self, lr, loc, rho, n_steps, n_mc, which=0, w=None, tied_b=False, seed=0):
+    def vi_run(self, lr, loc, rho, n_steps, n_mc, which=0, w=None, tied_b=False, wb=None, seed=0):
         """Run len(lr) independent Adam optimisations of the mean-field ELBO in one launch.
 
         loc, rho (and w, the unconstrained VIP parameter, when given) are [n_lr, D]
@@ -188,6 +188,7 @@ class Engine(object):
         cfg.seed = int(seed)
         io = _lib.ViIO()
         io.lr, io.loc, io.rho, io.w, io.elbo = _ptr(lr_t), _ptr(loc), _ptr(rho), _ptr(w), _ptr(elbo)
+        io.wb = _ptr(wb)
         with torch.cuda.device(self.device):
             _lib.check(self._L.arp_vi_run(self._h, which, C.byref(cfg), C.byref(io), _stream()))
         return elbo
@@ -201,9 +202,12 @@ _engines = {}
 
 
 def engine_for(spec, device=None):
-    key = (id(spec), str(device))
+    """One cached Engine per (model spec, device); device defaults to FLAGS.device."""
+    from .flags import FLAGS
+    dev = torch.device(device if device is not None else FLAGS.device)
+    key = (id(spec), str(dev))
     if key not in _engines:
-        _engines[key] = Engine(spec, device)
+        _engines[key] = Engine(spec, dev)
     return _engines[key]
 
 

@@ -1,0 +1,209 @@
+"""Inference drivers with the reference's signatures (inference.py:26-356), running
+on the HIP engine: find_best_learning_rate (mean-field VI with the learning-rate
+sweep), hmc (batched HMC + dual-averaging adaptation + sample_chain thinning) and
+hmc_interleaved (CP/NCP interleaving with simple adaptation).  Results come back as
+numpy arrays in the reference's layouts instead of lazy TF tensors.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import engine as _engine
+from . import util
+from .flags import FLAGS
+
+HmcInnerResults = collections.namedtuple("HmcInnerResults", ["is_accepted"])
+KernelResults = collections.namedtuple("KernelResults", ["inner_results", "new_step_size", "step"])
+InterleavedKernelResults = collections.namedtuple("InterleavedKernelResults", ["cp_results", "ncp_results"])
+
+# transitions per launch: keeps a single launch well under a second at any size
+_MAX_STEPS_PER_LAUNCH = 4096
+
+
+def find_best_learning_rate(elbo, variational_parameters, learnable_parameters_prior=None,
+                            learnable_parameters=None, flags=FLAGS):
+    """Optimise the ELBO with every learning rate of the sweep and keep the best run
+    (reference inference.py:26-154).  All learning rates run concurrently, one
+    workgroup each, inside one kernel launch."""
+    if learnable_parameters_prior is not None:
+        raise NotImplementedError("a prior on the learnable parameterisation (--discrete_prior) is not built")
+    spec = elbo.target.spec
+    dev = torch.device(flags.device)
+    eng = _engine.engine_for(spec, dev)
+    a, b = elbo.target.ab
+    eng.set_param(0, (a, b))
+    lrs = [float(v) for v in flags.learning_rates]
+    n_lr, D = len(lrs), spec.D
+    rs = np.random.RandomState(flags.seed)
+    loc0 = (1e-2 * rs.randn(n_lr, D)).astype(np.float32)
+    rho0 = np.full((n_lr, D), -2.0, np.float32)
+    loc = torch.as_tensor(loc0, device=dev)
+    rho = torch.as_tensor(rho0, device=dev)
+    w = wb = None
+    if elbo.learn_a:
+        w = torch.zeros(n_lr, D, device=dev)
+        if not elbo.tied:
+            wb = torch.zeros(n_lr, D, device=dev)
+    timeline = eng.vi_run(lrs, loc, rho, flags.num_optimization_steps, flags.num_mc_samples, which=0, w=w, wb=wb,
+                          seed=flags.seed).cpu().numpy().astype(np.float64)
+    loc, rho = loc.cpu().numpy(), rho.cpu().numpy()
+    scale = np.where(rho > 20, rho, np.log1p(np.exp(np.minimum(rho, 20))))
+
+    best = None
+    best_elbo = None
+    for i, lr in enumerate(lrs):
+        this = np.mean(timeline[i, -32:])
+        util.print_("     finished optimization with elbo {} vs best ELBO {}".format(this, best_elbo))
+        if not np.isfinite(this):
+            continue
+        if best_elbo is None or best_elbo < this:
+            best_elbo, best = this, i
+    if best is None:
+        raise RuntimeError("no learning rate gave a finite ELBO")
+    learned_variational_params = collections.OrderedDict()
+    for k, name in enumerate(spec.part_names):
+        lo, hi = spec.offsets[k], spec.offsets[k + 1]
+        learned_variational_params[name + "_loc"] = loc[best, lo:hi].reshape(spec.part_shapes[k])
+        learned_variational_params[name + "_scale"] = scale[best, lo:hi].reshape(spec.part_shapes[k])
+    step_size_init = util.get_approximate_step_size(learned_variational_params, num_leapfrog_steps=1)
+    learned_reparam = None
+    if elbo.learn_a:
+        av = 1.0 / (1.0 + np.exp(-w.cpu().numpy()[best]))
+        bv = 1.0 / (1.0 + np.exp(-wb.cpu().numpy()[best])) if wb is not None else None
+        learned_reparam = collections.OrderedDict()
+        for k, name in enumerate(spec.part_names):
+            lo, hi = spec.offsets[k], spec.offsets[k + 1]
+            learned_reparam[name + "_a"] = av[lo:hi].reshape(spec.part_shapes[k]).astype(np.float32)
+            if bv is not None:
+                learned_reparam[name + "_b"] = bv[lo:hi].reshape(spec.part_shapes[k]).astype(np.float32)
+    return (np.float64(best_elbo), list(timeline[best]), lrs[best], step_size_init,
+            learned_variational_params, learned_reparam)
+
+
+def _flat_step(spec, step_size_init, L):
+    """inference.py:212-216: step_size_init[i] * ones(part shape) / (L/4)^2, flattened to [D]."""
+    out = np.zeros(spec.D, np.float32)
+    for k in range(len(spec.part_names)):
+        lo, hi = spec.offsets[k], spec.offsets[k + 1]
+        v = np.asarray(step_size_init[k], np.float64)
+        out[lo:hi] = (np.broadcast_to(v, spec.part_shapes[k]).reshape(-1) / (float(L) / 4.0) ** 2)
+    return out
+
+
+class _LazyOriginalStates(object):
+    """states in the sampler's own coordinates, recovered on demand from the
+    centred trace (the reference materialises both; main.py never reads these)."""
+
+    def __init__(self, eng, spec, trace, which):
+        self._args = (eng, spec, trace, which)
+        self._val = None
+
+    def get(self):
+        if self._val is None:
+            eng, spec, trace, which = self._args
+            S, C, D = trace.shape
+            flat = eng.transform(trace.reshape(S * C, D), which=which, to_centered=False).reshape(S, C, D)
+            self._val = spec.unpack(flat.cpu().numpy())
+        return self._val
+
+    def __iter__(self):
+        return iter(self.get())
+
+    def __getitem__(self, i):
+        return self.get()[i]
+
+    def __len__(self):
+        return len(self._args[1].part_names)
+
+
+def _check_trace_fits(S, C, D, dev):
+    need = 4.0 * S * C * D
+    free, _ = torch.cuda.mem_get_info(dev)
+    if need > 0.8 * free:
+        raise MemoryError("the trace [S=%d, C=%d, D=%d] needs %.1f GB of HBM (%.1f GB free); lower --num_samples "
+                          "or --num_chains" % (S, C, D, need / 1e9, free / 1e9))
+
+
+def hmc(target, model_config, step_size_init, initial_states, reparam, flags=FLAGS, chain_offset=0):
+    """Batched HMC with dual-averaging step-size adaptation (reference inference.py:198-242).
+
+    Returns (states_orig, kernel_results, states_transformed, ess) with
+    states_* = list of [S, C, *event] arrays, kernel_results.inner_results.is_accepted
+    [S, C], ess = list of [C, *event] (tfp.mcmc.effective_sample_size of the
+    centred states).  `reparam` is accepted for signature compatibility; the
+    parameterisation is the target's."""
+    spec = target.spec
+    dev = torch.device(flags.device)
+    eng = _engine.engine_for(spec, dev)
+    eng.set_param(0, target.ab)
+    L = int(flags.num_leapfrog_steps)
+    q0 = torch.as_tensor(spec.pack([np.asarray(p, np.float32) for p in initial_states]), device=dev)
+    C = q0.shape[0]
+    S, B = int(flags.num_samples), int(flags.num_burnin_steps)
+    eps0 = _flat_step(spec, step_size_init, L)
+    thin = 2                                      # num_steps_between_results=1 (inference.py:234)
+    total = 1 + B + thin * (S - 1)
+    _check_trace_fits(S, C, spec.D, dev)
+    trace = torch.empty(S, C, spec.D, dtype=torch.float32, device=dev)
+    tacc = torch.empty(S, C, dtype=torch.uint8, device=dev)
+    st = _engine.ChainState(q0)
+    done = 0
+    while done < total:
+        n = min(_MAX_STEPS_PER_LAUNCH, total - done)
+        eng.hmc_run(st, eps0, L, n, which=0, seed=flags.seed, chain_offset=chain_offset,
+                    adapt_kind=_lib.ADAPT_DUAL, n_adapt=int(flags.num_adaptation_steps), adapt_target=0.75,
+                    n_burnin=B, thin=thin, trace=trace, trace_accept=tacc, trace_centered=True,
+                    lanes=flags.lanes_per_chain)
+        done += n
+    ess_flat = util.effective_sample_size(trace)
+    torch.cuda.synchronize(dev)
+    states_transformed = spec.unpack(trace.cpu().numpy())
+    ess = spec.unpack(ess_flat.cpu().numpy())
+    step_mult = st.adapt[:, 0].cpu().numpy()
+    kernel_results = KernelResults(HmcInnerResults(tacc.cpu().numpy().astype(bool)), step_mult, st.step)
+    states_orig = _LazyOriginalStates(eng, spec, trace, 0)
+    return states_orig, kernel_results, states_transformed, ess
+
+
+def hmc_interleaved(model_config, target_cp, target_ncp, num_leapfrog_steps_cp, num_leapfrog_steps_ncp,
+                    step_size_cp, step_size_ncp, initial_states_cp, flags=FLAGS, chain_offset=0):
+    """Interleaved CP/NCP HMC with SimpleStepSizeAdaptation(0.05, 0.75) on each inner
+    kernel (reference inference.py:258-329, interleaved.py:113-155).
+
+    Returns (states, kernel_results, ess); states are in CP coordinates."""
+    spec = target_cp.spec
+    dev = torch.device(flags.device)
+    eng = _engine.engine_for(spec, dev)
+    eng.set_param(0, target_cp.ab)
+    eng.set_param(1, target_ncp.ab)
+    q0 = torch.as_tensor(spec.pack([np.asarray(p, np.float32) for p in initial_states_cp]), device=dev)
+    C = q0.shape[0]
+    S, B = int(flags.num_samples), int(flags.num_burnin_steps)
+    e_cp = _flat_step(spec, step_size_cp, num_leapfrog_steps_cp)
+    e_ncp = _flat_step(spec, step_size_ncp, num_leapfrog_steps_ncp)
+    thin = 2
+    total = 1 + B + thin * (S - 1)
+    _check_trace_fits(S, C, spec.D, dev)
+    trace = torch.empty(S, C, spec.D, dtype=torch.float32, device=dev)
+    t0 = torch.empty(S, C, dtype=torch.uint8, device=dev)
+    t1 = torch.empty(S, C, dtype=torch.uint8, device=dev)
+    st = _engine.ChainState(q0)
+    done = 0
+    while done < total:
+        n = min(_MAX_STEPS_PER_LAUNCH, total - done)
+        eng.interleaved_run(st, e_cp, e_ncp, int(num_leapfrog_steps_cp), int(num_leapfrog_steps_ncp), n,
+                            seed=flags.seed, chain_offset=chain_offset, adapt_kind=_lib.ADAPT_SIMPLE,
+                            n_adapt=int(flags.num_adaptation_steps), adapt_target=0.75, adapt_rate=0.05,
+                            n_burnin=B, thin=thin, trace=trace, trace_accept0=t0, trace_accept1=t1,
+                            trace_centered=False, lanes=flags.lanes_per_chain)
+        done += n
+    ess_flat = util.effective_sample_size(trace)
+    torch.cuda.synchronize(dev)
+    states = spec.unpack(trace.cpu().numpy())
+    ess = spec.unpack(ess_flat.cpu().numpy())
+    kr = InterleavedKernelResults(
+        cp_results=KernelResults(HmcInnerResults(t0.cpu().numpy().astype(bool)), st.adapt[:, 0].cpu().numpy(), st.step),
+        ncp_results=KernelResults(HmcInnerResults(t1.cpu().numpy().astype(bool)), st.adapt1[:, 0].cpu().numpy(), st.step))
+    return states, kr, ess

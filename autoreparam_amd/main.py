@@ -1,0 +1,317 @@
+"""Command line of the reference (main.py:37-589) on the HIP engine:
+
+    python -m autoreparam_amd.main --model=radon --dataset=MN --inference=VI --method=CP
+    python -m autoreparam_amd.main --model=radon --dataset=MN --inference=HMCtuning --method=CP --num_leapfrog_steps=4
+    python -m autoreparam_amd.main --model=radon --dataset=MN --inference=HMC --method=CP
+
+Same flags, result directory, file names, JSON keys and run sequencing (VI before
+HMC, cVIP before dVIP, tuning runs before an untuned HMC).  Two defects of the
+reference's interleaved entry point are not reproduced: the
+NameError at main.py:515 and the CP.json / CP_tied.json file-name mismatch (both
+spellings are looked up).
+"""
+import collections
+import io
+import json
+import os
+import sys
+import time
+from collections import OrderedDict
+
+import numpy as np
+
+from . import graphs, inference, models, util
+from .flags import FLAGS
+
+
+def _vip_suffix(flags):
+    return "{}{}{}{}".format(flags.learnable_parameterisation_type,
+                             "_tied" if flags.tied_pparams else "",
+                             "_reparam_variational" if flags.reparameterise_variational else "",
+                             "_discrete_prior" if flags.discrete_prior else "")
+
+
+def create_target_graph(model_config, results_dir, flags=FLAGS):
+    """reference main.py:117-187"""
+    cVIP_path = os.path.join(results_dir, "cVIP_{}.json".format(_vip_suffix(flags)))
+    actual_reparam = None
+    if flags.method == "CP":
+        target, model, elbo, vp, lp = graphs.make_cp_graph(model_config, flags=flags)
+        actual_reparam = "CP"
+    elif flags.method == "NCP":
+        target, model, elbo, vp, lp = graphs.make_ncp_graph(model_config, flags=flags)
+        actual_reparam = "NCP"
+    elif flags.method == "i":
+        if flags.inference == "VI":
+            raise Exception("Cannot run interleaved VI. Use `i` method with HMC only.")
+        target_cp, model_cp, _, _, _ = graphs.make_cp_graph(model_config, flags=flags)
+        target_ncp, model_ncp, _, _, _ = graphs.make_ncp_graph(model_config, flags=flags)
+        target, model = (target_cp, target_ncp), (model_cp, model_ncp)
+        elbo, vp, lp = None, None, None
+    elif flags.method == "cVIP":
+        if flags.inference == "VI":
+            target, model, elbo, vp, lp = graphs.make_cvip_graph(
+                model_config, parameterisation_type=flags.learnable_parameterisation_type,
+                tied_pparams=flags.tied_pparams, flags=flags)
+        else:
+            with open(cVIP_path, "r") as f:
+                actual_reparam = json.load(f)["learned_reparam"]
+            target, model, elbo, vp, lp = graphs.make_dvip_graph(
+                model_config, actual_reparam, parameterisation_type=flags.learnable_parameterisation_type,
+                flags=flags)
+    elif flags.method == "dVIP":
+        if os.path.exists(cVIP_path):
+            with open(cVIP_path, "r") as f:
+                reparam = json.load(f)["learned_reparam"]
+        else:
+            raise Exception("Run cVIP first to find reparameterisation")
+        discrete = collections.OrderedDict(
+            [(key, (np.array(reparam[key]) >= 0.5).astype(np.float32)) for key in reparam.keys()])
+        print("discrete parameterisation is", discrete)
+        target, model, elbo, vp, lp = graphs.make_dvip_graph(
+            model_config, discrete, parameterisation_type=flags.learnable_parameterisation_type, flags=flags)
+        actual_reparam = discrete
+    else:
+        raise Exception("unknown method {}".format(flags.method))
+    return target, model, elbo, vp, lp, actual_reparam
+
+
+def _clean_dict(d):
+    if d is None:
+        return None
+    return OrderedDict([(k, np.asarray(d[k]).item() if np.ndim(d[k]) == 0 else np.asarray(d[k]).tolist())
+                        for k in d.keys()])
+
+
+def run_vi(model_config, results_dir, file_path, flags=FLAGS):
+    """reference main.py:234-290"""
+    target, model, elbo, vp, lp, actual_reparam = create_target_graph(model_config, results_dir, flags)
+    if os.path.exists(file_path):
+        util.print_("Already ran experiment {}-{} on model {} with dataset {}. Skipping".format(
+            flags.inference, flags.method, flags.model, flags.dataset))
+        return
+    prior = None
+    if flags.discrete_prior:
+        raise NotImplementedError("--discrete_prior is not built")
+    start_time = time.time()
+    (elbo_final, elbo_timeline, learning_rate, initial_step_size, learned_variational_params,
+     learned_reparam) = inference.find_best_learning_rate(
+         elbo, vp, learnable_parameters_prior=prior, learnable_parameters=lp, flags=flags)
+    end_time = time.time()
+    if learned_reparam is None and isinstance(actual_reparam, dict):
+        learned_reparam = actual_reparam
+    results = {
+        "elbo": float(elbo_final),
+        "variational_fit_time_secs": end_time - start_time,
+        "actual_num_variational_steps": len(elbo_timeline),
+        "estimated_elbo_std": float(np.std(elbo_timeline[-32:])),
+        "learning_rate": learning_rate,
+        "initial_step_size": [np.asarray(i).item() if np.ndim(i) == 0 else np.asarray(i).tolist()
+                              for i in initial_step_size],
+        "learned_reparam": _clean_dict(learned_reparam),
+        "learned_variational_params": _clean_dict(learned_variational_params),
+    }
+    with open(file_path, "w") as outfile:
+        json.dump(results, outfile)
+    return results
+
+
+def get_best_num_leapfrog_steps_from_tuning_runs(tuning_runs):
+    best_run = max(tuning_runs, key=lambda d: d["ess_min"])
+    return best_run["num_leapfrog_steps"]
+
+
+def _param_names(model_config):
+    return list(model_config.model.part_names)
+
+
+def run_hmc(model_config, results_dir, file_path, tuning=False, flags=FLAGS):
+    """reference main.py:296-398"""
+    if os.path.exists(file_path):
+        with open(file_path, "r") as f:
+            prev_results = json.load(f)
+    else:
+        raise Exception("Run VI first to find initial step sizes")
+    param_names = _param_names(model_config)
+    initial_step_size = prev_results["initial_step_size"]
+    initial_states = list(util.variational_inits_from_params(
+        prev_results["learned_variational_params"], param_names=param_names, num_inits=flags.num_chains,
+        seed=flags.seed).values())
+    if tuning:
+        if not flags.num_leapfrog_steps:
+            raise ValueError("You must specify the number of leapfrog steps for a tuning run.")
+        for existing_run in prev_results.get("tuning_runs", []):
+            if existing_run["num_leapfrog_steps"] == flags.num_leapfrog_steps:
+                print("A tuning run already exists for HMC with {} leapfrog steps, skipping. ({})".format(
+                    flags.num_leapfrog_steps, existing_run))
+                return
+    if not flags.num_leapfrog_steps:
+        flags.num_leapfrog_steps = get_best_num_leapfrog_steps_from_tuning_runs(prev_results["tuning_runs"])
+    util.print_("\nNumber of leaprog steps is set to {}.\n".format(flags.num_leapfrog_steps))
+    if flags.count_in_leapfrog_steps:
+        flags.num_samples = int(flags.num_samples / float(flags.num_leapfrog_steps))
+        flags.num_burnin_steps = int(flags.num_burnin_steps / float(flags.num_leapfrog_steps))
+        flags.num_adaptation_steps = int(flags.num_adaptation_steps / float(flags.num_leapfrog_steps))
+    target, _, elbo, vp, lp, actual_reparam = create_target_graph(model_config, results_dir, flags)
+    start_time = time.time()
+    states_orig, kernel_results, samples, ess_final = inference.hmc(
+        target, model_config, initial_step_size, initial_states=initial_states, reparam=actual_reparam, flags=flags)
+    is_accepted = kernel_results.inner_results.is_accepted
+    mcmc_time = time.time() - start_time
+    normalized_ess_final = [1000 * e / (flags.num_samples * flags.num_leapfrog_steps) for e in ess_final]
+    ess_min, sem_min = util.get_min_ess(normalized_ess_final)
+    util.print_("ESS per 1000 gradients: {} +/- {}".format(ess_min, sem_min))
+    acceptance_rate = np.sum(is_accepted) * 100.0 / float(flags.num_samples * flags.num_chains)
+    if tuning:
+        save_hmc_results(file_path=file_path,
+                         tuning_runs={"num_leapfrog_steps": flags.num_leapfrog_steps, "ess_min": float(ess_min),
+                                      "sem_min": float(sem_min), "acceptance_rate": float(acceptance_rate),
+                                      "mcmc_time": mcmc_time, "num_samples": flags.num_samples,
+                                      "num_burnin_steps": flags.num_burnin_steps})
+    else:
+        save_hmc_results(file_path=file_path, ess_min=float(ess_min), sem_min=float(sem_min),
+                         acceptance_rate=float(acceptance_rate), mcmc_time_sec=mcmc_time)
+        save_ess(file_path_base=file_path[:-5], samples=samples, param_names=param_names,
+                 normalized_ess_final=normalized_ess_final, num_chains_to_save=flags.num_chains_to_save)
+    return ess_min, sem_min, acceptance_rate, mcmc_time
+
+
+def run_interleaved_hmc_with_leapfrog_steps(model_config, results_dir, num_leapfrog_steps_cp,
+                                            num_leapfrog_steps_ncp, initial_step_size_cp, initial_step_size_ncp,
+                                            initial_states_cp, flags=FLAGS):
+    """reference main.py:401-449"""
+    target, model, elbo, vp, lp, actual_reparam = create_target_graph(model_config, results_dir, flags)
+    target_cp, target_ncp = target
+    start_time = time.time()
+    states, kernel_results, ess_final = inference.hmc_interleaved(
+        model_config, target_cp, target_ncp, num_leapfrog_steps_cp=num_leapfrog_steps_cp,
+        num_leapfrog_steps_ncp=num_leapfrog_steps_ncp, step_size_cp=initial_step_size_cp,
+        step_size_ncp=initial_step_size_ncp, initial_states_cp=initial_states_cp, flags=flags)
+    mcmc_time = time.time() - start_time
+    is_accepted_cp = kernel_results.cp_results.inner_results.is_accepted
+    is_accepted_ncp = kernel_results.ncp_results.inner_results.is_accepted
+    normalized_ess_final = [1000 * e / (flags.num_samples * flags.num_leapfrog_steps) for e in ess_final]
+    ess_min, sem_min = util.get_min_ess(normalized_ess_final)
+    util.print_("ESS: {} +/- {}".format(ess_min, sem_min))
+    denom = float(flags.num_samples * flags.num_chains)
+    return (ess_min, sem_min, np.sum(is_accepted_cp) * 100.0 / denom, np.sum(is_accepted_ncp) * 100.0 / denom,
+            mcmc_time, states, normalized_ess_final)
+
+
+def _first_existing(results_dir, names):
+    for n in names:
+        p = os.path.join(results_dir, n)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def run_interleaved_hmc(model_config, results_dir, file_path, flags=FLAGS):
+    """reference main.py:452-528 (intended behaviour, see module docstring)"""
+    tied = "_tied" if flags.tied_pparams else ""
+    file_path_cp = _first_existing(results_dir, ["CP.json", "CP%s.json" % tied])
+    file_path_ncp = _first_existing(results_dir, ["NCP.json", "NCP%s.json" % tied])
+    param_names = _param_names(model_config)
+    if file_path_cp and file_path_ncp:
+        with open(file_path_cp, "r") as f:
+            prev = json.load(f)
+            initial_step_size_cp = prev["initial_step_size"]
+            num_leapfrog_steps_cp = get_best_num_leapfrog_steps_from_tuning_runs(prev["tuning_runs"])
+            learned_variational_params_cp = prev["learned_variational_params"]
+        with open(file_path_ncp, "r") as f:
+            prev = json.load(f)
+            initial_step_size_ncp = prev["initial_step_size"]
+            num_leapfrog_steps_ncp = get_best_num_leapfrog_steps_from_tuning_runs(prev["tuning_runs"])
+    else:
+        raise Exception("Run VI first to find initial step sizes, and HMC first to find num_leapfrog_steps.")
+    initial_states_cp = list(util.variational_inits_from_params(
+        learned_variational_params_cp, param_names=param_names, num_inits=flags.num_chains,
+        seed=flags.seed).values())
+    best_ess_min, best_num_ls, results = 0, None, ()
+    for num_ls in sorted(set([num_leapfrog_steps_ncp, num_leapfrog_steps_cp])):
+        flags.num_leapfrog_steps = num_ls + num_ls
+        util.print_("\nNumber of leaprog steps is set to {}.\n".format(flags.num_leapfrog_steps))
+        res = run_interleaved_hmc_with_leapfrog_steps(
+            model_config=model_config, results_dir=results_dir, num_leapfrog_steps_cp=num_ls,
+            num_leapfrog_steps_ncp=num_ls, initial_step_size_cp=initial_step_size_cp,
+            initial_step_size_ncp=initial_step_size_ncp, initial_states_cp=initial_states_cp, flags=flags)
+        if float(res[0]) > best_ess_min or best_num_ls is None:
+            best_ess_min, best_num_ls, results = float(res[0]), num_ls, res
+    ess_min, sem_min, acceptance_rate_cp, acceptance_rate_ncp, mcmc_time, samples, normalized_ess_final = results
+    flags.num_leapfrog_steps = best_num_ls + best_num_ls
+    save_hmc_results(file_path=file_path, initial_step_size_ncp=initial_step_size_ncp,
+                     initial_step_size_cp=initial_step_size_cp, num_leapfrog_steps=best_num_ls,
+                     ess_min=float(ess_min), sem_min=float(sem_min), acceptance_rate_cp=float(acceptance_rate_cp),
+                     acceptance_rate_ncp=float(acceptance_rate_ncp), mcmc_time_sec=mcmc_time)
+    save_ess(file_path_base=file_path[:-5], samples=samples, param_names=param_names,
+             normalized_ess_final=normalized_ess_final, num_chains_to_save=flags.num_chains_to_save)
+    return results
+
+
+def save_hmc_results(file_path, **kwargs):
+    """reference main.py:531-550: every key is a list that is appended to."""
+    try:
+        with open(file_path, "r") as f:
+            results = json.load(f)
+    except IOError:
+        results = {}
+    for k in kwargs.keys():
+        if k not in results.keys():
+            results[k] = []
+    for k, v in kwargs.items():
+        results.get(k).append(v)
+    with open(file_path, "w") as outfile:
+        json.dump(results, outfile)
+
+
+def save_ess(file_path_base, samples, normalized_ess_final, param_names, num_chains_to_save=0):
+    """reference main.py:552-585"""
+    dict_ess = dict([(param_names[i], np.array(normalized_ess_final[i])) for i in range(len(param_names))])
+    with open(file_path_base + "_ess.npz", "wb") as out_f:
+        buf = io.BytesIO()
+        np.savez(buf, **dict_ess)
+        out_f.write(buf.getvalue())
+    with open(file_path_base + "_ess.txt", "w") as out_f:
+        for k, v in dict_ess.items():
+            out_f.write("{}: {}\n\n".format(k, v))
+        out_f.write("\n\n")
+        for k, v in dict_ess.items():
+            out_f.write("{} mean: {}\n".format(k, np.mean(v, axis=0)))
+            out_f.write("{} stddev: {}\n\n".format(k, np.std(v, axis=0)))
+    if num_chains_to_save > 0:
+        dict_res = dict([(param_names[i], samples[i][:, :num_chains_to_save]) for i in range(len(param_names))])
+        with open(file_path_base + "_traces.npz", "wb") as out_f:
+            buf = io.BytesIO()
+            np.savez(buf, **dict_res)
+            out_f.write(buf.getvalue())
+
+
+def main(argv=None, flags=FLAGS):
+    """reference main.py:190-231"""
+    if argv is not None:
+        flags.parse(list(argv))
+    util.print_("Loading model {} with dataset {}.".format(flags.model, flags.dataset))
+    model_config = models.get_model_by_name(flags.model, dataset=flags.dataset)
+    results_dir = flags.results_dir if flags.results_dir != "" else flags.model + "_" + flags.dataset
+    if not os.path.exists(results_dir):
+        os.makedirs(results_dir)
+    filename = "{}{}{}{}{}.json".format(
+        flags.method,
+        ("_" + flags.learnable_parameterisation_type if "VIP" in flags.method else ""),
+        ("_tied" if flags.tied_pparams else ""),
+        ("_reparam_variational" if "VIP" in flags.method and flags.reparameterise_variational else ""),
+        ("_discrete_prior" if "VIP" in flags.method and flags.discrete_prior else ""))
+    file_path = os.path.join(results_dir, filename)
+    if flags.inference == "VI":
+        return run_vi(model_config, results_dir, file_path, flags)
+    elif flags.inference == "HMC":
+        if flags.method == "i":
+            return run_interleaved_hmc(model_config, results_dir, file_path, flags)
+        return run_hmc(model_config, results_dir, file_path, tuning=False, flags=flags)
+    elif flags.inference == "HMCtuning":
+        return run_hmc(model_config, results_dir, file_path, tuning=True, flags=flags)
+    raise Exception("unknown inference {}".format(flags.inference))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

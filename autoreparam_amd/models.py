@@ -70,13 +70,9 @@ class ModelSpec(object):
             lo, hi = self.offsets[k], self.offsets[k + 1]
             if name + "_a" not in reparam:
                 raise KeyError("parameterisation has no entry for %s_a" % name)
-            a[lo:hi] = np.broadcast_to(np.asarray(reparam[name + "_a"], np.float32).reshape(-1)
-                                       if np.ndim(reparam[name + "_a"]) else np.float32(reparam[name + "_a"]),
-                                       (hi - lo,))
+            a[lo:hi] = np.broadcast_to(np.asarray(reparam[name + "_a"], np.float32).reshape(-1), (hi - lo,))
             if name + "_b" in reparam:
-                vb = reparam[name + "_b"]
-                b[lo:hi] = np.broadcast_to(np.asarray(vb, np.float32).reshape(-1) if np.ndim(vb)
-                                           else np.float32(vb), (hi - lo,))
+                b[lo:hi] = np.broadcast_to(np.asarray(reparam[name + "_b"], np.float32).reshape(-1), (hi - lo,))
         return a, b
 
     def dataset(self):

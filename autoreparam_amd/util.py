@@ -1,0 +1,74 @@
+"""Helpers around the hot path: ESS, step-size and initial-state bookkeeping
+(reference util.py:271-276, 394-410, 445-460 and tfp.mcmc.effective_sample_size
+as called at inference.py:240, 327)."""
+import collections
+
+import numpy as np
+import torch
+
+
+def print_(*args):
+    print(*args, flush=True)
+
+
+def get_approximate_step_size(variational_parameters, num_leapfrog_steps):
+    """reference util.py:271-276: the variational scales divided by L^2."""
+    return [np.asarray(variational_parameters[key]) / num_leapfrog_steps ** 2
+            for key in variational_parameters.keys() if key.endswith("_scale")]
+
+
+def variational_inits_from_params(learned_variational_params, param_names, num_inits, seed=None):
+    """Sample initial states from the fitted mean-field Normal (reference util.py:394-410;
+    the reference uses the unseeded global numpy RNG, here a seed may be given)."""
+    rs = np.random.RandomState(seed) if seed is not None else np.random
+    locs, stddevs, samples = collections.OrderedDict(), collections.OrderedDict(), collections.OrderedDict()
+    for k, v in learned_variational_params.items():
+        if k.endswith("_loc"):
+            locs[k[:-4]] = v
+        elif k.endswith("_scale"):
+            stddevs[k[:-6]] = v
+    for k in param_names:
+        shape = (num_inits,) + np.asarray(locs[k]).shape
+        samples[k] = (rs.randn(*shape) * stddevs[k] + locs[k]).astype(np.float32)
+    return samples
+
+
+def effective_sample_size(states, max_chains_per_batch=None):
+    """tfp.mcmc.effective_sample_size with its defaults (filter_threshold=0), per chain
+    and element: `states` [S, C, D] (torch, any device) -> [C, D].
+
+    Restated from the published definition: auto-correlation by FFT of the
+    mean-removed series, lag k divided by (S - k) and normalised by lag 0; every
+    lag from the first negative one on is dropped; ESS = S / (-1 + 2 sum_k (S-k)/S rho_k).
+    Runs on the tensor's device (rocFFT through torch.fft), in chain batches so the
+    complex work buffers stay bounded.
+    """
+    S, C, D = states.shape
+    out = torch.empty(C, D, dtype=torch.float32, device=states.device)
+    n_fft = 1 << int(np.ceil(np.log2(2 * S)))
+    if max_chains_per_batch is None:
+        max_chains_per_batch = max(1, int(2 ** 27 // (n_fft * D)))   # ~1 GiB of complex64 per batch
+    k = torch.arange(S, device=states.device, dtype=torch.float32)
+    for c0 in range(0, C, max_chains_per_batch):
+        x = states[:, c0:c0 + max_chains_per_batch, :].to(torch.float32)
+        x = x - x.mean(dim=0, keepdim=True)
+        f = torch.fft.rfft(x, n=n_fft, dim=0)
+        ac = torch.fft.irfft(f * f.conj(), n=n_fft, dim=0)[:S]
+        ac = ac / (S - k).view(-1, 1, 1)
+        ac = ac / ac[:1]
+        mask = (ac < 0).to(torch.float32).cumsum(dim=0)
+        ac = ac * torch.clamp(1.0 - mask, min=0.0)
+        nk = ((S - k) / S).view(-1, 1, 1)
+        out[c0:c0 + max_chains_per_batch] = S / (-1.0 + 2.0 * (nk * ac).sum(dim=0))
+    return out
+
+
+def get_min_ess(ess):
+    """reference util.py:445-460: per chain the minimum over all elements of all parts,
+    then mean and standard error over chains.  `ess` is a list of [C, *event] arrays."""
+    ess = [np.nan_to_num(np.asarray(e)) for e in ess]
+    num_chains = ess[0].shape[0]
+    min_ess = [min(np.array(e[c]).min() for e in ess) for c in range(num_chains)]
+    mean_ess = np.mean(min_ess)
+    sem_ess = np.std(min_ess) / np.sqrt(len(min_ess))
+    return mean_ess, sem_ess

@@ -152,7 +152,7 @@ typedef struct arp_vi_config {
   int32_t n_steps;           /* num_optimization_steps */
   int32_t n_mc;              /* num_mc_samples (<= 1024) */
   int32_t learn_a;           /* 1: also optimise the VIP parameter a = sigmoid(w) (cVIP) */
-  int32_t tied_b;            /* 1: b := a in the density (tied_pparams as intended); 0: b fixed from set_param */
+  int32_t tied_b;            /* 1: b := a in the density (tied_pparams as intended); 0: b from set_param, or learned via io.wb */
   int32_t reserved;
   uint64_t seed;
 } arp_vi_config;
@@ -161,6 +161,7 @@ typedef struct arp_vi_io {
   float* loc;                /* [n_lr][D] in: initial loc, out: final */
   float* rho;                /* [n_lr][D] in: initial pre-softplus scale, out: final */
   float* w;                  /* [n_lr][D] in/out unconstrained a (only if learn_a) */
+  float* wb;                 /* [n_lr][D] in/out unconstrained b, learned separately (untied), or NULL */
   float* elbo;               /* [n_lr][n_steps] ELBO estimate per step (reference-valued, constants included) */
 } arp_vi_io;
 int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_io* io, void* stream);

@@ -592,7 +592,7 @@ int FN(orc_dparam)(const orc_model* M, const float* a, const float* b, const REA
  * stream s mod (block/lanes). */
 int FN(orc_vi_run)(const orc_model* M, const float* a_in, const float* b_in, int n_lr, int n_steps, int n_mc,
                    int learn_a, int tied_b, uint64_t seed, int lanes, int block, const float* lr_in,
-                   REAL* loc_io, REAL* rho_io, REAL* w_io, REAL* elbo_out, double const_base, int n_top,
+                   REAL* loc_io, REAL* rho_io, REAL* w_io, REAL* wb_io, REAL* elbo_out, double const_base, int n_top,
                    const int* top_idx, const double* top_logscale) {
   const int D = M->D, NG = M->n_glob, G = M->n_groups, P = M->n_local_parts;
   const int per_lane = (G + lanes - 1) / lanes, nd = NG + P * per_lane;
@@ -600,6 +600,7 @@ int FN(orc_vi_run)(const orc_model* M, const float* a_in, const float* b_in, int
   for (int li = 0; li < n_lr; ++li) {
     REAL* loc = loc_io + (size_t)li * D; REAL* rho = rho_io + (size_t)li * D;
     REAL* w = learn_a ? w_io + (size_t)li * D : NULL;
+    REAL* wb = (learn_a && wb_io) ? wb_io + (size_t)li * D : NULL;
     float* a = (float*)malloc(sizeof(float) * D); float* b = (float*)malloc(sizeof(float) * D);
     memcpy(a, a_in, sizeof(float) * D); memcpy(b, b_in, sizeof(float) * D);
     orc_rng* streams = (orc_rng*)malloc(sizeof(orc_rng) * (size_t)cpp * lanes);
@@ -607,7 +608,7 @@ int FN(orc_vi_run)(const orc_model* M, const float* a_in, const float* b_in, int
       for (int s = 0; s < lanes; ++s)
         streams[c0 * lanes + s] = orc_rng_seed(seed ^ 0x5649564956495649ull, ((uint64_t)li << 32) | (uint32_t)c0,
                                                (uint32_t)s, (uint32_t)lanes);
-    REAL* m1 = (REAL*)calloc(3 * (size_t)D, sizeof(REAL)); REAL* m2 = (REAL*)calloc(3 * (size_t)D, sizeof(REAL));
+    REAL* m1 = (REAL*)calloc(4 * (size_t)D, sizeof(REAL)); REAL* m2 = (REAL*)calloc(4 * (size_t)D, sizeof(REAL));
     REAL* sig = (REAL*)malloc(sizeof(REAL) * D); REAL* eps = (REAL*)malloc(sizeof(REAL) * D);
     REAL* z = (REAL*)malloc(sizeof(REAL) * D); REAL* g = (REAL*)malloc(sizeof(REAL) * D);
     REAL* da = (REAL*)malloc(sizeof(REAL) * D); REAL* db = (REAL*)malloc(sizeof(REAL) * D);
@@ -616,7 +617,8 @@ int FN(orc_vi_run)(const orc_model* M, const float* a_in, const float* b_in, int
     for (int step = 0; step < n_steps; ++step) {
       for (int d = 0; d < D; ++d) {
         sig[d] = rho[d] > 20 ? rho[d] : (REAL)log(1.0 + exp((double)rho[d]));
-        if (learn_a) { a[d] = (float)(1.0 / (1.0 + exp(-(double)w[d]))); if (tied_b) b[d] = a[d]; }
+        if (learn_a) { a[d] = (float)(1.0 / (1.0 + exp(-(double)w[d]))); if (tied_b) b[d] = a[d];
+          if (wb) b[d] = (float)(1.0 / (1.0 + exp(-(double)wb[d]))); }
       }
       memset(acc, 0, sizeof(REAL) * 4 * (size_t)D);
       REAL elbo = 0;
@@ -660,12 +662,13 @@ int FN(orc_vi_run)(const orc_model* M, const float* a_in, const float* b_in, int
       for (int k = 0; k < n_top; ++k) c -= (double)b[top_idx[k]] * top_logscale[k];
       elbo_out[(size_t)li * n_steps + step] = elbo / n_mc + (REAL)c;
       for (int d = 0; d < D; ++d) {
-        REAL gr[3];
+        REAL gr[4];
         gr[0] = -acc[d] / n_mc;
         gr[1] = -(acc[D + d] / n_mc + 1 / sig[d]) * (REAL)(1.0 / (1.0 + exp(-(double)rho[d])));
         gr[2] = learn_a ? -((acc[2 * D + d] + (tied_b ? acc[3 * D + d] : 0)) / n_mc) * a[d] * (1 - a[d]) : 0;
-        REAL* par[3] = {&loc[d], &rho[d], learn_a ? &w[d] : NULL};
-        for (int k = 0; k < 3; ++k) {
+        gr[3] = wb ? -(acc[3 * D + d] / n_mc) * b[d] * (1 - b[d]) : 0;
+        REAL* par[4] = {&loc[d], &rho[d], learn_a ? &w[d] : NULL, wb ? &wb[d] : NULL};
+        for (int k = 0; k < 4; ++k) {
           REAL gk = gr[k];
           if (gk != gk) gk = 0;
           m1[k * D + d] = (REAL)0.9 * m1[k * D + d] + (REAL)0.1 * gk;

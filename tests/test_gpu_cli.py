@@ -1,0 +1,83 @@
+"""GPU: the reference's CLI flow end to end on the engine (BASELINE config 1 shape:
+8schools, CP, 4 chains, 4 leapfrog steps; plus cVIP -> dVIP and the interleaved run),
+checking the files and JSON keys of reference main.py:277-290, 376-391, 512-521."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(args):
+    from autoreparam_amd import flags as flags_mod
+    from autoreparam_amd import main as cli
+    f = flags_mod.FlagValues()
+    return cli.main(args, flags=f)
+
+
+def test_config1_eight_schools_cp(gpu, tmp_path):
+    d = str(tmp_path)
+    common = ["--model=8schools", "--method=CP", "--results_dir=" + d, "--num_chains=4"]
+    _run(common + ["--inference=VI", "--num_optimization_steps=600"])
+    r = json.load(open(os.path.join(d, "CP_tied.json")))
+    for k in ("elbo", "variational_fit_time_secs", "actual_num_variational_steps", "estimated_elbo_std",
+              "learning_rate", "initial_step_size", "learned_reparam", "learned_variational_params"):
+        assert k in r
+    assert r["actual_num_variational_steps"] == 600 and -45 < r["elbo"] < -30
+    assert set(r["learned_variational_params"]) == {"mu_loc", "mu_scale", "log_tau_loc", "log_tau_scale",
+                                                    "theta_loc", "theta_scale"}
+    assert len(r["initial_step_size"]) == 3 and len(r["initial_step_size"][2]) == 8
+    # VI is skipped when the file exists
+    assert _run(common + ["--inference=VI", "--num_optimization_steps=600"]) is None
+    hm = ["--num_samples=1000", "--num_burnin_steps=1000", "--num_adaptation_steps=600"]
+    _run(common + ["--inference=HMCtuning", "--num_leapfrog_steps=4"] + hm)
+    _run(common + ["--inference=HMCtuning", "--num_leapfrog_steps=8"] + hm)
+    _run(common + ["--inference=HMCtuning", "--num_leapfrog_steps=8"] + hm)   # already recorded: skipped
+    r = json.load(open(os.path.join(d, "CP_tied.json")))
+    assert [t["num_leapfrog_steps"] for t in r["tuning_runs"]] == [4, 8]
+    for t in r["tuning_runs"]:
+        assert set(t) == {"num_leapfrog_steps", "ess_min", "sem_min", "acceptance_rate", "mcmc_time", "num_samples",
+                          "num_burnin_steps"}
+        assert 30 < t["acceptance_rate"] <= 100 and t["ess_min"] > 0
+    _run(common + ["--inference=HMC", "--num_chains_to_save=2"] + hm)         # L from the tuning runs
+    r = json.load(open(os.path.join(d, "CP_tied.json")))
+    for k in ("ess_min", "sem_min", "acceptance_rate", "mcmc_time_sec"):
+        assert isinstance(r[k], list) and len(r[k]) == 1
+    ess = np.load(os.path.join(d, "CP_tied_ess.npz"))
+    assert ess["theta"].shape == (4, 8) and ess["mu"].shape == (4,)
+    tr = np.load(os.path.join(d, "CP_tied_traces.npz"))
+    assert tr["theta"].shape == (1000, 2, 8)
+    assert os.path.exists(os.path.join(d, "CP_tied_ess.txt"))
+    # posterior sanity (8 schools): E[mu] ~ 4.4
+    assert 2.0 < tr["mu"].mean() < 7.0
+
+
+def test_cvip_then_dvip_and_interleaved(gpu, tmp_path):
+    d = str(tmp_path)
+    base = ["--model=radon", "--dataset=MN", "--results_dir=" + d, "--num_chains=64", "--num_optimization_steps=400",
+            "--learning_rates=0.05,0.1"]
+    with pytest.raises(Exception):
+        _run(base + ["--inference=VI", "--method=dVIP"])                      # needs cVIP first
+    _run(base + ["--inference=VI", "--method=cVIP"])
+    r = json.load(open(os.path.join(d, "cVIP_eig_tied.json")))
+    assert set(r["learned_reparam"]) == {"mua_a", "b1_a", "b2_a", "m_a"} and len(r["learned_reparam"]["m_a"]) == 85
+    _run(base + ["--inference=VI", "--method=dVIP"])
+    r = json.load(open(os.path.join(d, "dVIP_eig_tied.json")))
+    assert set(np.unique(r["learned_reparam"]["m_a"])) <= {0.0, 1.0}
+    hm = ["--num_samples=300", "--num_burnin_steps=300", "--num_adaptation_steps=200"]
+    _run(base + ["--inference=HMCtuning", "--method=dVIP", "--num_leapfrog_steps=4"] + hm)
+    r = json.load(open(os.path.join(d, "dVIP_eig_tied.json")))
+    assert r["tuning_runs"][0]["acceptance_rate"] > 40
+    with pytest.raises(Exception):
+        _run(base + ["--inference=HMC", "--method=i"] + hm)                   # needs CP and NCP runs first
+    for m in ("CP", "NCP"):
+        _run(base + ["--inference=VI", "--method=" + m])
+        _run(base + ["--inference=HMCtuning", "--method=" + m, "--num_leapfrog_steps=4"] + hm)
+    _run(base + ["--inference=HMC", "--method=i"] + hm)
+    r = json.load(open(os.path.join(d, "i_tied.json")))
+    for k in ("initial_step_size_ncp", "initial_step_size_cp", "num_leapfrog_steps", "ess_min", "sem_min",
+              "acceptance_rate_cp", "acceptance_rate_ncp", "mcmc_time_sec"):
+        assert k in r and len(r[k]) == 1
+    assert r["num_leapfrog_steps"] == [4] and r["acceptance_rate_cp"][0] > 30 and r["acceptance_rate_ncp"][0] > 30
