@@ -43,6 +43,7 @@ static const std::vector<LaneOps>* family(const arp_model* m) {
     case ARP_MODEL_RADON: return &radon_ops();
     case ARP_MODEL_EIGHT_SCHOOLS: return &schools_ops();
     case ARP_MODEL_ELECTION: return &election_ops();
+    case ARP_MODEL_GERMAN_CREDIT: return &german_ops();
     default: return nullptr;
   }
 }
@@ -51,6 +52,7 @@ static const void* family_args(const arp_model* m) {
     case ARP_MODEL_RADON: return &m->radon;
     case ARP_MODEL_EIGHT_SCHOOLS: return &m->schools;
     case ARP_MODEL_ELECTION: return &m->election;
+    case ARP_MODEL_GERMAN_CREDIT: return &m->german;
     default: return nullptr;
   }
 }
@@ -150,6 +152,28 @@ static int build_election(arp_model* m, const arp_dataset* d) {
   return 0;
 }
 
+// reference models.py:860-904: X = [N][F] design matrix (intercept, standardised
+// numerics, one-hot blocks), y = 0/1 outcomes
+static int build_german(arp_model* m, const arp_dataset* d) {
+  const int N = d->n_obs, F = d->n_features;
+  if (!d->X_host || !d->y_host || N <= 0 || F <= 0 || F > kGermanCols) {
+    set_error("german_credit: X, y, n_obs and 0 < n_features <= 64 are required");
+    return 1;
+  }
+  m->D = 1 + 2 * F; m->n_groups = F;
+  m->host_tables.assign((size_t)N * kGermanCols + N, 0.0f);
+  for (int n = 0; n < N; ++n)
+    for (int f = 0; f < F; ++f) m->host_tables[(size_t)n * kGermanCols + f] = d->X_host[(size_t)n * F + f];
+  for (int n = 0; n < N; ++n) m->host_tables[(size_t)N * kGermanCols + n] = d->y_host[n];
+  if (upload_tables(m)) return 1;
+  m->german.X = m->dev_tables;
+  m->german.y = m->dev_tables + (size_t)N * kGermanCols;
+  m->german.N = N; m->german.F = F;
+  m->const_base = -(1.0 + 2.0 * F) * kHalfLog2Pi;
+  m->top_scale = {{0, log(10.0)}};
+  return 0;
+}
+
 }  // namespace arp
 
 using namespace arp;
@@ -169,6 +193,7 @@ int arp_model_create(const arp_dataset* data, arp_model** out) {
     case ARP_MODEL_RADON: rc = build_radon(m.get(), data); break;
     case ARP_MODEL_EIGHT_SCHOOLS: rc = build_schools(m.get(), data); break;
     case ARP_MODEL_ELECTION: rc = build_election(m.get(), data); break;
+    case ARP_MODEL_GERMAN_CREDIT: rc = build_german(m.get(), data); break;
     default: set_error("arp_model_create: unknown model id"); return 1;
   }
   if (rc) return rc;

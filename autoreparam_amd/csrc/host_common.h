@@ -11,6 +11,7 @@
 #include "model_radon.h"
 #include "model_schools.h"
 #include "model_election.h"
+#include "model_german.h"
 
 namespace arp {
 
@@ -71,6 +72,7 @@ struct Launch {
 const std::vector<LaneOps>& radon_ops();
 const std::vector<LaneOps>& schools_ops();
 const std::vector<LaneOps>& election_ops();
+const std::vector<LaneOps>& german_ops();
 
 }  // namespace arp
 
@@ -86,6 +88,7 @@ struct arp_model {
   arp::RadonArgs radon{};
   arp::SchoolsArgs schools{};
   arp::ElectionArgs election{};
+  arp::GermanArgs german{};
   std::vector<float> host_tables;
   double const_base = 0.0;                       // parameterisation independent part of the dropped constant
   std::vector<std::pair<int, double>> top_scale; // (flattened index, log prior scale) of top-level latents

@@ -34,16 +34,17 @@ struct HmcParams {
 
 // ---------------------------------------------------------------------------
 // Row I/O in the reference layout [C][D].  Lane `slot` of a chain owns the
-// replicated globals (flattened index Lane::gg(i)) and the slices
-// LBASE + slot + K*i, i < nloc: one 64-bit base per row, compile-time offsets.
+// replicated globals (flattened index M.gg(i)) and NL sliced elements at
+// flattened index M.lidx(i) (valid when M.lvalid(i)); the lane models express
+// lidx as slot-dependent base + compile-time offset, so one 64-bit base per row
+// and immediate offsets are enough.
 // ---------------------------------------------------------------------------
 template <class Lane>
 ARP_DEV void load_row(const Lane& M, const float* __restrict__ row, float (&v)[Lane::ND]) {
 #pragma unroll
   for (int i = 0; i < Lane::NG; ++i) v[i] = row[M.gg(i)];
-  const float* lb = row + Lane::LBASE + M.slot;
 #pragma unroll
-  for (int i = 0; i < Lane::NL; ++i) v[Lane::NG + i] = (i < M.nloc) ? lb[Lane::K * i] : 0.0f;
+  for (int i = 0; i < Lane::NL; ++i) v[Lane::NG + i] = M.lvalid(i) ? row[M.lidx(i)] : 0.0f;
 }
 template <class Lane>
 ARP_DEV void store_row(const Lane& M, float* __restrict__ row, const float (&v)[Lane::ND], bool live) {
@@ -51,10 +52,9 @@ ARP_DEV void store_row(const Lane& M, float* __restrict__ row, const float (&v)[
 #pragma unroll
     for (int i = 0; i < Lane::NG; ++i) row[M.gg(i)] = v[i];
   }
-  float* lb = row + Lane::LBASE + M.slot;
 #pragma unroll
   for (int i = 0; i < Lane::NL; ++i)
-    if (live && i < M.nloc) lb[Lane::K * i] = v[Lane::NG + i];
+    if (live && M.lvalid(i)) row[M.lidx(i)] = v[Lane::NG + i];
 }
 
 // ---------------------------------------------------------------------------
@@ -132,7 +132,7 @@ ARP_DEV float hmc_transition(const Lane& M, Rng& rng, int L, const float (&eps)[
       p[i] = group_bcast0<K>(p[i], M.slot);
       keg0 = fmaf(p[i], p[i], keg0);
     } else {
-      p[i] = (i - NG) < M.nloc ? p[i] : 0.0f;
+      p[i] = M.lvalid(i - NG) ? p[i] : 0.0f;
       ke0 = fmaf(p[i], p[i], ke0);
     }
   }
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
           eps[i] = group_bcast0<K>(eps[i], slot);
           entg += fmaf(0.5f * eps[i], eps[i], ls[i]);
         } else {
-          bool ok = (i - NG) < M.nloc;
+          bool ok = M.lvalid(i - NG);
           eps[i] = ok ? eps[i] : 0.f;
           ent += ok ? fmaf(0.5f * eps[i], eps[i], ls[i]) : 0.f;
         }
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
         float v = chain_sum<K>(acc[k][i]);
         if ((tid & 63) < K) {
           if (i < NG) { if (slot == 0) atomicAdd(&s_acc[k][M.gg(i)], v); }
-          else if ((i - NG) < M.nloc) atomicAdd(&s_acc[k][Lane::LBASE + slot + K * (i - NG)], v);
+          else if (M.lvalid(i - NG)) atomicAdd(&s_acc[k][M.lidx(i - NG)], v);
         }
       }
     }

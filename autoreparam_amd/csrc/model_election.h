@@ -28,6 +28,9 @@ struct ElectionLane {
   static constexpr int NL = NL_; // groups owned by this lane: t = slot + K*i, t <= S
   static constexpr int ND = NG + NL;
   static constexpr int LBASE = 2;
+  // sliced element i of this lane: flattened index and validity
+  ARP_DEV int lidx(int i) const { return LBASE + slot + K * i; }
+  ARP_DEV bool lvalid(int i) const { return i < nloc; }
   using Args = ElectionArgs;
 
   float cn[NL][4], cy[NL][4], al[NL], be[NL], lat[NL];

@@ -32,6 +32,9 @@ struct RadonLane {
   static constexpr int NG = 3;   // mua, b1, b2 replicated in every lane of the chain
   static constexpr int NL = NL_; // counties owned by this lane: j = slot + K*i
   static constexpr int ND = NG + NL;
+  // sliced element i of this lane: flattened index and validity
+  ARP_DEV int lidx(int i) const { return LBASE + slot + K * i; }
+  ARP_DEV bool lvalid(int i) const { return i < nloc; }
   using Args = RadonArgs;
 
   static constexpr int LBASE = 3; // flattened index of m_0 (parts: mua, b1, b2, m[J])

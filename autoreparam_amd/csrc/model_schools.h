@@ -25,6 +25,9 @@ struct SchoolsLane {
   static constexpr int NL = NL_; // schools owned by this lane: k = slot + K*i
   static constexpr int ND = NG + NL;
   static constexpr int LBASE = 2;
+  // sliced element i of this lane: flattened index and validity
+  ARP_DEV int lidx(int i) const { return LBASE + slot + K * i; }
+  ARP_DEV bool lvalid(int i) const { return i < nloc; }
   using Args = SchoolsArgs;
 
   float y[NL], is2[NL], a[NL], b[NL];

@@ -26,6 +26,7 @@ typedef struct orc_model {
   int n_glob;      /* replicated top-level scalars (RNG stream layout) */
   int n_groups;    /* sliced axis length (RNG stream layout) */
   int n_local_parts; /* latent parts sliced along that axis (german: beta_log_scales and beta) */
+  int contig;      /* 1: slot s owns consecutive elements s*per_lane + i (german); 0: s + lanes*i */
   int glob_idx[8]; /* flattened index of each top-level scalar */
   int* group_idx;  /* [n_local_parts][n_groups] flattened index of element j, -1 if it has no latent */
   /* radon sufficient statistics */
@@ -180,7 +181,7 @@ orc_model* orc_german_create(int N, int F, const float* X, const float* y) {
   M->model = 2; M->N = N; M->F = F; M->D = 1 + 2 * F;
   /* RNG stream layout: overall_log_scale is the top-level scalar; feature d owns
    * beta_log_scales[d] and beta[d] (two sliced parts, see draw_momentum) */
-  M->n_glob = 1; M->n_groups = F; M->n_local_parts = 2; M->glob_idx[0] = 0;
+  M->n_glob = 1; M->n_groups = F; M->n_local_parts = 2; M->contig = 1; M->glob_idx[0] = 0;
   M->group_idx = (int*)malloc(sizeof(int) * 2 * F);
   for (int d = 0; d < F; ++d) { M->group_idx[d] = 1 + d; M->group_idx[F + d] = 1 + F + d; }
   M->X = (float*)malloc(sizeof(float) * (size_t)N * F); memcpy(M->X, X, sizeof(float) * (size_t)N * F);

@@ -330,7 +330,7 @@ static void FN(draw_momentum)(const orc_model* M, orc_rng* streams, int lanes, R
           if (s == 0) p[M->glob_idx[ii]] = (REAL)z;
         } else {
           int part = (ii - NG) / per_lane;
-          int j = s + lanes * ((ii - NG) % per_lane);
+          int j = M->contig ? s * per_lane + (ii - NG) % per_lane : s + lanes * ((ii - NG) % per_lane);
           if (j < G && M->group_idx[part * G + j] >= 0) p[M->group_idx[part * G + j]] = (REAL)z;
         }
       }
@@ -636,7 +636,8 @@ int FN(orc_vi_run)(const orc_model* M, const float* a_in, const float* b_in, int
                 if (ii >= nd) break;
                 if (ii < NG) { if (s == 0) eps[M->glob_idx[ii]] = (REAL)zz; }
                 else {
-                  int part = (ii - NG) / per_lane, j = s + lanes * ((ii - NG) % per_lane);
+                  int part = (ii - NG) / per_lane;
+                  int j = M->contig ? s * per_lane + (ii - NG) % per_lane : s + lanes * ((ii - NG) % per_lane);
                   if (j < G && M->group_idx[part * G + j] >= 0) eps[M->group_idx[part * G + j]] = (REAL)zz;
                 }
               }
