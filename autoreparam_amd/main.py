@@ -20,7 +20,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from . import graphs, inference, models, util
+from . import graphs, inference, models, parallel, util
 from .flags import FLAGS
 
 
@@ -153,15 +153,21 @@ def run_hmc(model_config, results_dir, file_path, tuning=False, flags=FLAGS):
         flags.num_burnin_steps = int(flags.num_burnin_steps / float(flags.num_leapfrog_steps))
         flags.num_adaptation_steps = int(flags.num_adaptation_steps / float(flags.num_leapfrog_steps))
     target, _, elbo, vp, lp, actual_reparam = create_target_graph(model_config, results_dir, flags)
+    # one process per GPU: every rank draws the same initial population and keeps its block of chains
+    rank, ws = parallel.world()
+    initial_states, chain_offset = parallel.shard_states(initial_states, rank, ws)
     start_time = time.time()
     states_orig, kernel_results, samples, ess_final = inference.hmc(
-        target, model_config, initial_step_size, initial_states=initial_states, reparam=actual_reparam, flags=flags)
+        target, model_config, initial_step_size, initial_states=initial_states, reparam=actual_reparam, flags=flags,
+        chain_offset=chain_offset)
     is_accepted = kernel_results.inner_results.is_accepted
     mcmc_time = time.time() - start_time
     normalized_ess_final = [1000 * e / (flags.num_samples * flags.num_leapfrog_steps) for e in ess_final]
-    ess_min, sem_min = util.get_min_ess(normalized_ess_final)
+    ess_min, sem_min, acceptance_rate, _ = parallel.summarize(
+        normalized_ess_final, is_accepted, flags.num_samples, flags.num_chains, device=flags.device if ws > 1 else None)
     util.print_("ESS per 1000 gradients: {} +/- {}".format(ess_min, sem_min))
-    acceptance_rate = np.sum(is_accepted) * 100.0 / float(flags.num_samples * flags.num_chains)
+    if rank != 0:
+        return ess_min, sem_min, acceptance_rate, mcmc_time
     if tuning:
         save_hmc_results(file_path=file_path,
                          tuning_runs={"num_leapfrog_steps": flags.num_leapfrog_steps, "ess_min": float(ess_min),
@@ -182,20 +188,25 @@ def run_interleaved_hmc_with_leapfrog_steps(model_config, results_dir, num_leapf
     """reference main.py:401-449"""
     target, model, elbo, vp, lp, actual_reparam = create_target_graph(model_config, results_dir, flags)
     target_cp, target_ncp = target
+    rank, ws = parallel.world()
+    initial_states_cp, chain_offset = parallel.shard_states(list(initial_states_cp), rank, ws)
     start_time = time.time()
     states, kernel_results, ess_final = inference.hmc_interleaved(
         model_config, target_cp, target_ncp, num_leapfrog_steps_cp=num_leapfrog_steps_cp,
         num_leapfrog_steps_ncp=num_leapfrog_steps_ncp, step_size_cp=initial_step_size_cp,
-        step_size_ncp=initial_step_size_ncp, initial_states_cp=initial_states_cp, flags=flags)
+        step_size_ncp=initial_step_size_ncp, initial_states_cp=initial_states_cp, flags=flags,
+        chain_offset=chain_offset)
     mcmc_time = time.time() - start_time
     is_accepted_cp = kernel_results.cp_results.inner_results.is_accepted
     is_accepted_ncp = kernel_results.ncp_results.inner_results.is_accepted
     normalized_ess_final = [1000 * e / (flags.num_samples * flags.num_leapfrog_steps) for e in ess_final]
-    ess_min, sem_min = util.get_min_ess(normalized_ess_final)
+    dev = flags.device if ws > 1 else None
+    ess_min, sem_min, acc_cp, _ = parallel.summarize(normalized_ess_final, is_accepted_cp, flags.num_samples,
+                                                     flags.num_chains, device=dev)
+    acc_ncp = float(parallel.all_reduce_sum(float(np.sum(is_accepted_ncp)), dev).item()) * 100.0 / float(
+        flags.num_samples * flags.num_chains)
     util.print_("ESS: {} +/- {}".format(ess_min, sem_min))
-    denom = float(flags.num_samples * flags.num_chains)
-    return (ess_min, sem_min, np.sum(is_accepted_cp) * 100.0 / denom, np.sum(is_accepted_ncp) * 100.0 / denom,
-            mcmc_time, states, normalized_ess_final)
+    return (ess_min, sem_min, acc_cp, acc_ncp, mcmc_time, states, normalized_ess_final)
 
 
 def _first_existing(results_dir, names):
@@ -239,6 +250,8 @@ def run_interleaved_hmc(model_config, results_dir, file_path, flags=FLAGS):
             best_ess_min, best_num_ls, results = float(res[0]), num_ls, res
     ess_min, sem_min, acceptance_rate_cp, acceptance_rate_ncp, mcmc_time, samples, normalized_ess_final = results
     flags.num_leapfrog_steps = best_num_ls + best_num_ls
+    if parallel.world()[0] != 0:
+        return results
     save_hmc_results(file_path=file_path, initial_step_size_ncp=initial_step_size_ncp,
                      initial_step_size_cp=initial_step_size_cp, num_leapfrog_steps=best_num_ls,
                      ess_min=float(ess_min), sem_min=float(sem_min), acceptance_rate_cp=float(acceptance_rate_cp),
@@ -290,6 +303,20 @@ def main(argv=None, flags=FLAGS):
     """reference main.py:190-231"""
     if argv is not None:
         flags.parse(list(argv))
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws > 1:
+        # launched by torch.distributed.run: one rank per GPU, RCCL for the statistics exchange
+        import torch
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        flags.device = "cuda:%d" % local
+        torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=torch.device(flags.device))
+        if flags.inference == "VI" and dist.get_rank() != 0:
+            dist.barrier()      # VI is a single-workgroup-per-learning-rate job: rank 0 runs it
+            return None
     util.print_("Loading model {} with dataset {}.".format(flags.model, flags.dataset))
     model_config = models.get_model_by_name(flags.model, dataset=flags.dataset)
     results_dir = flags.results_dir if flags.results_dir != "" else flags.model + "_" + flags.dataset
@@ -303,7 +330,11 @@ def main(argv=None, flags=FLAGS):
         ("_discrete_prior" if "VIP" in flags.method and flags.discrete_prior else ""))
     file_path = os.path.join(results_dir, filename)
     if flags.inference == "VI":
-        return run_vi(model_config, results_dir, file_path, flags)
+        out = run_vi(model_config, results_dir, file_path, flags)
+        if ws > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        return out
     elif flags.inference == "HMC":
         if flags.method == "i":
             return run_interleaved_hmc(model_config, results_dir, file_path, flags)

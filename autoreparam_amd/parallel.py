@@ -1,0 +1,72 @@
+"""Multi-GPU sharding of the chain axis (one process per GPU, torch.distributed;
+backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+Chains never interact inside a transition and the reference adapts the step size
+per chain, so ranks own contiguous blocks of chains, the RNG
+is keyed by the global chain id, and the only communication is the end-of-run
+exchange of per-chain statistics: one all-gather of the per-chain minimum ESS
+(<= 4 bytes per chain) and one all-reduce of the acceptance counts.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n, rank, world_size):
+    """Contiguous block [lo, hi) of `n` chains owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_states(parts, rank, world_size):
+    """Slice a list of [C, *event] arrays along the chain axis; returns (local parts, chain_offset)."""
+    n = parts[0].shape[0]
+    lo, hi = shard_bounds(n, rank, world_size)
+    return [p[lo:hi] for p in parts], lo
+
+
+def all_gather_chains(local, n_total, device=None):
+    """Concatenate per-chain values (first axis = local chains) from all ranks, in rank order."""
+    rank, ws = world()
+    t = torch.as_tensor(local)
+    if ws == 1:
+        return t
+    if device is not None:
+        t = t.to(device)
+    sizes = [shard_bounds(n_total, r, ws)[1] - shard_bounds(n_total, r, ws)[0] for r in range(ws)]
+    mx = max(sizes)
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    out = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(out, pad)
+    return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
+
+
+def all_reduce_sum(value, device=None):
+    rank, ws = world()
+    t = torch.as_tensor(value, dtype=torch.float64)
+    if ws == 1:
+        return t
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def summarize(normalized_ess_parts, is_accepted, num_samples, num_chains_total, device=None):
+    """ess_min, sem_min (reference util.get_min_ess) and acceptance rate in percent
+    (main.py:372-373) over ALL chains, from each rank's local chains."""
+    local_min = np.min(np.stack([np.nan_to_num(np.asarray(e)).reshape(np.asarray(e).shape[0], -1).min(axis=1)
+                                 for e in normalized_ess_parts]), axis=0)
+    mins = all_gather_chains(torch.as_tensor(local_min, dtype=torch.float32), num_chains_total, device).cpu().numpy()
+    acc = float(all_reduce_sum(float(np.sum(is_accepted)), device).item())
+    ess_min = float(np.mean(mins))
+    sem_min = float(np.std(mins) / np.sqrt(len(mins)))
+    return ess_min, sem_min, acc * 100.0 / float(num_samples * num_chains_total), mins
