@@ -225,6 +225,12 @@ int arp_model_set_param(arp_model* m, int which, const float* a_host, const floa
   ARP_HIP_OK(hipMemcpy(m->dev_ab[which], a_host, m->D * sizeof(float), hipMemcpyHostToDevice));
   ARP_HIP_OK(hipMemcpy(m->dev_ab[which] + m->D, b_host, m->D * sizeof(float), hipMemcpyHostToDevice));
   m->has_param[which] = true;
+  bool all1 = true, all0 = true;
+  for (int d = 0; d < m->D; ++d) {
+    all1 = all1 && a_host[d] == 1.0f && b_host[d] == 1.0f;
+    all0 = all0 && a_host[d] == 0.0f && b_host[d] == 0.0f;
+  }
+  m->param_kind[which] = all1 ? kModeCP : (all0 ? kModeNCP : kModeVIP);
   // dropped constant: -sum_i b_i log(prior scale_i) over the top-level latents, plus the base
   double c = m->const_base;
   for (const auto& ts : m->top_scale) c -= (double)b_host[ts.first] * ts.second;
@@ -312,7 +318,10 @@ int arp_hmc_run(arp_model* m, int which, const arp_hmc_config* cfg, const arp_hm
   if (cfg->n_steps == 0) return 0;
   const LaneOps* o = select_ops(m, cfg->lanes_per_chain, cfg->n_chains);
   if (!o) return 1;
-  o->hmc(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, (hipStream_t)stream);
+  auto fn = o->hmc;
+  if (m->param_kind[which] == kModeCP && o->hmc_cp) fn = o->hmc_cp;
+  if (m->param_kind[which] == kModeNCP && o->hmc_ncp) fn = o->hmc_ncp;
+  fn(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, (hipStream_t)stream);
   ARP_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -332,8 +341,9 @@ int arp_interleaved_run(arp_model* m, const arp_hmc_config* cfg, int n_leapfrog_
   if (cfg->n_steps == 0) return 0;
   const LaneOps* o = select_ops(m, cfg->lanes_per_chain, cfg->n_chains);
   if (!o) return 1;
-  o->interleaved(family_args(m), m->dev_ab[0], m->dev_ab[0] + m->D, m->dev_ab[1], m->dev_ab[1] + m->D, P,
-                 (hipStream_t)stream);
+  auto fn = o->interleaved;
+  if (m->param_kind[0] == kModeCP && m->param_kind[1] == kModeNCP && o->interleaved_cp_ncp) fn = o->interleaved_cp_ncp;
+  fn(family_args(m), m->dev_ab[0], m->dev_ab[0] + m->D, m->dev_ab[1], m->dev_ab[1] + m->D, P, (hipStream_t)stream);
   ARP_HIP_OK(hipGetLastError());
   return 0;
 }

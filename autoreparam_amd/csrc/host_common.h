@@ -37,6 +37,12 @@ struct LaneOps {
   void (*interleaved)(const void* args, const float* a0, const float* b0, const float* a1, const float* b1,
                       const HmcParams& P, hipStream_t s);
   void (*vi)(const void* args, const float* a, const float* b, const ViParams& P, int n_lr, hipStream_t s);
+  // compile-time parameterisations (nullptr when the lane model has none): hmc for CP / NCP,
+  // interleaved for the (CP, NCP) pair
+  void (*hmc_cp)(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s);
+  void (*hmc_ncp)(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s);
+  void (*interleaved_cp_ncp)(const void* args, const float* a0, const float* b0, const float* a1, const float* b1,
+                             const HmcParams& P, hipStream_t s);
 };
 
 template <class Lane>
@@ -65,7 +71,25 @@ struct Launch {
     hipLaunchKernelGGL(vi_kernel<Lane>, dim3(n_lr), dim3(kViBlock), 0, s,
                        *(const typename Lane::Args*)args, a, b, P);
   }
-  static LaneOps ops() { return LaneOps{Lane::K, Lane::NL, &logp_grad, &transform, &hmc, &interleaved, &vi}; }
+  template <int MODE>
+  static void hmc_m(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s) {
+    hipLaunchKernelGGL((hmc_kernel<Lane, MODE>), dim3(blocks(P.C)), dim3(kBlock), 0, s,
+                       *(const typename Lane::Args*)args, a, b, P);
+  }
+  static void interleaved_m(const void* args, const float* a0, const float* b0, const float* a1, const float* b1,
+                            const HmcParams& P, hipStream_t s) {
+    hipLaunchKernelGGL((interleaved_kernel<Lane, kModeCP, kModeNCP>), dim3(blocks(P.C)), dim3(kBlock), 0, s,
+                       *(const typename Lane::Args*)args, a0, b0, a1, b1, P);
+  }
+  static LaneOps ops() {
+    LaneOps o{Lane::K, Lane::NL, &logp_grad, &transform, &hmc, &interleaved, &vi, nullptr, nullptr, nullptr};
+    if constexpr (Lane::HAS_MODES) {
+      o.hmc_cp = &hmc_m<kModeCP>;
+      o.hmc_ncp = &hmc_m<kModeNCP>;
+      o.interleaved_cp_ncp = &interleaved_m;
+    }
+    return o;
+  }
 };
 
 // per-family tables (defined in inst_*.hip)
@@ -84,6 +108,7 @@ struct arp_model {
   float* dev_tables = nullptr;   // one allocation holding all frozen tables
   float* dev_ab[2] = {nullptr, nullptr};  // [2][D]: a then b, per parameterisation
   bool has_param[2] = {false, false};
+  int param_kind[2] = {0, 0};   // kModeVIP / kModeCP / kModeNCP, detected in arp_model_set_param
   double logp_const[2] = {0.0, 0.0};
   arp::RadonArgs radon{};
   arp::SchoolsArgs schools{};

@@ -1,0 +1,10 @@
+// Chain-kernel instantiations for the radon model, 16 lanes per chain: per-lane slice
+// sizes NL = ceil(J / K) for the county counts of the reference's radon datasets
+// (MN 85, PA 68, IN 91, MO 115, ND 53) plus round-ups.
+#include "host_common.h"
+
+namespace arp {
+std::vector<LaneOps> radon_ops_k16() {
+  return {Launch<RadonLane<16, 4>>::ops(), Launch<RadonLane<16, 5>>::ops(), Launch<RadonLane<16, 6>>::ops(), Launch<RadonLane<16, 8>>::ops()};
+}
+}  // namespace arp

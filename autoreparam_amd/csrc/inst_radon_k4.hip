@@ -1,0 +1,10 @@
+// Chain-kernel instantiations for the radon model, 4 lanes per chain: per-lane slice
+// sizes NL = ceil(J / K) for the county counts of the reference's radon datasets
+// (MN 85, PA 68, IN 91, MO 115, ND 53) plus round-ups.
+#include "host_common.h"
+
+namespace arp {
+std::vector<LaneOps> radon_ops_k4() {
+  return {Launch<RadonLane<4, 14>>::ops(), Launch<RadonLane<4, 17>>::ops(), Launch<RadonLane<4, 22>>::ops(), Launch<RadonLane<4, 23>>::ops(), Launch<RadonLane<4, 29>>::ops()};
+}
+}  // namespace arp

@@ -58,6 +58,31 @@ ARP_DEV void store_row(const Lane& M, float* __restrict__ row, const float (&v)[
 }
 
 // ---------------------------------------------------------------------------
+// Parameterisation modes.  MODE 0 evaluates the general VIP form with per-element
+// (a,b) held in registers; lane models that set HAS_MODES also provide
+// compile-time specialisations for the two parameterisations every run uses,
+// MODE 1 = centred (a=b=1) and MODE 2 = non-centred (a=b=0): fewer VALU ops per
+// group and no (a,b) registers.
+// ---------------------------------------------------------------------------
+constexpr int kModeVIP = 0, kModeCP = 1, kModeNCP = 2;
+
+template <int MODE, bool LOGP, class Lane>
+ARP_DEV float lane_grad(const Lane& M, const float (&q)[Lane::ND], float (&g)[Lane::ND]) {
+  if constexpr (MODE != kModeVIP && Lane::HAS_MODES) return M.template grad_m<LOGP, MODE>(q, g);
+  else return M.template grad<LOGP>(q, g);
+}
+template <int MODE, class Lane>
+ARP_DEV void lane_to_centered(const Lane& M, const float (&q)[Lane::ND], float (&x)[Lane::ND]) {
+  if constexpr (MODE != kModeVIP && Lane::HAS_MODES) M.template to_centered_m<MODE>(q, x);
+  else M.to_centered(q, x);
+}
+template <int MODE, class Lane>
+ARP_DEV void lane_from_centered(const Lane& M, const float (&x)[Lane::ND], float (&q)[Lane::ND]) {
+  if constexpr (MODE != kModeVIP && Lane::HAS_MODES) M.template from_centered_m<MODE>(x, q);
+  else M.from_centered(x, q);
+}
+
+// ---------------------------------------------------------------------------
 // logp + grad for a batch of states (test hook and bootstrap of the cached
 // gradient; reference: vectorized target + tf.gradients, inference.py:172-195)
 // ---------------------------------------------------------------------------
@@ -105,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void transform_kernel(
 // half kicks of consecutive steps merged, Metropolis test.  Returns the log
 // acceptance ratio; q/g/lp are replaced in place when the proposal is accepted.
 // ---------------------------------------------------------------------------
-template <class Lane>
+template <class Lane, int MODE = kModeVIP>
 ARP_DEV float hmc_transition(const Lane& M, Rng& rng, int L, const float (&eps)[Lane::ND],
                              float (&q)[Lane::ND], float (&g)[Lane::ND], float& lp,
                              bool& accepted) {
@@ -147,13 +172,13 @@ ARP_DEV float hmc_transition(const Lane& M, Rng& rng, int L, const float (&eps)[
   for (int l = 1; l < L; ++l) {
 #pragma unroll
     for (int i = 0; i < ND; ++i) q1[i] = fmaf(eps[i], p[i], q1[i]);
-    M.template grad<false>(q1, g1);
+    lane_grad<MODE, false>(M, q1, g1);
 #pragma unroll
     for (int i = 0; i < ND; ++i) p[i] = fmaf(eps[i], g1[i], p[i]);
   }
 #pragma unroll
   for (int i = 0; i < ND; ++i) q1[i] = fmaf(eps[i], p[i], q1[i]);
-  const float lp1 = M.template grad<true>(q1, g1);
+  const float lp1 = lane_grad<MODE, true>(M, q1, g1);
 #pragma unroll
   for (int i = 0; i < ND; ++i) p[i] = fmaf(0.5f * eps[i], g1[i], p[i]);
   float ke1 = 0.0f, keg1 = 0.0f;
@@ -204,7 +229,7 @@ ARP_DEV void adapt_update(int kind, long long n, int n_adapt, float target, floa
   }
 }
 
-template <class Lane>
+template <class Lane, int MODE = kModeVIP>
 __global__ __launch_bounds__(kBlock) void hmc_kernel(
     typename Lane::Args A, const float* __restrict__ av, const float* __restrict__ bv, HmcParams P) {
   constexpr int K = Lane::K, ND = Lane::ND, NG = Lane::NG;
@@ -223,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void hmc_kernel(
   load_row(M, qrow, q);
   float lp;
   if (P.step_base == 0) {
-    lp = M.template grad<true>(q, g);
+    lp = lane_grad<MODE, true>(M, q, g);
   } else {
     load_row(M, grow, g);
     lp = P.logp[c];
@@ -247,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void hmc_kernel(
 #pragma unroll
     for (int i = 0; i < ND; ++i) eps[i] *= kappa;
     bool acc;
-    float la = hmc_transition<Lane>(M, rng, P.L, eps, q, g, lp, acc);
+    float la = hmc_transition<Lane, MODE>(M, rng, P.L, eps, q, g, lp, acc);
     nacc += acc ? 1u : 0u;
     const long long n = P.step_base + s + 1;
     adapt_update(P.adapt_kind, n, P.n_adapt, P.adapt_target, P.adapt_rate, la, kappa, esum, logavg);
@@ -258,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void hmc_kernel(
         float* row = P.trace + ((size_t)rec_row * P.C + c) * D;
         if (P.trace_centered) {
           float x[ND];
-          M.to_centered(q, x);
+          lane_to_centered<MODE>(M, q, x);
           store_row(M, row, x, live);
         } else {
           store_row(M, row, q, live);
@@ -292,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void hmc_kernel(
 //   survives the re-bootstrap because it lives outside the HMC results
 //   (inference.py:288-306).  2*(L+1) gradient evaluations per step.
 // ---------------------------------------------------------------------------
-template <class Lane>
+template <class Lane, int M0 = kModeVIP, int M1 = kModeVIP>
 __global__ __launch_bounds__(kBlock) void interleaved_kernel(
     typename Lane::Args A, const float* __restrict__ av0, const float* __restrict__ bv0,
     const float* __restrict__ av1, const float* __restrict__ bv1, HmcParams P) {
@@ -329,27 +354,27 @@ __global__ __launch_bounds__(kBlock) void interleaved_kernel(
     const long long n = P.step_base + s + 1;
     bool acc0, acc1;
     // --- parameterisation 0 ---
-    float lp = M.template grad<true>(q, g);
+    float lp = lane_grad<M0, true>(M, q, g);
     load_row(M, P.eps0, eps);
 #pragma unroll
     for (int i = 0; i < ND; ++i) eps[i] *= kap[0];
-    float la = hmc_transition<Lane>(M, rng, P.L, eps, q, g, lp, acc0);
+    float la = hmc_transition<Lane, M0>(M, rng, P.L, eps, q, g, lp, acc0);
     nacc0 += acc0 ? 1u : 0u;
     adapt_update(P.adapt_kind, n, P.n_adapt, P.adapt_target, P.adapt_rate, la, kap[0], es[0], la_[0]);
-    M.to_centered(q, x);
+    lane_to_centered<M0>(M, q, x);
     // --- parameterisation 1 ---
-    M.set_param(av1, bv1);
-    M.from_centered(x, q);
-    lp = M.template grad<true>(q, g);
+    if (M1 == kModeVIP || !Lane::HAS_MODES) M.set_param(av1, bv1);
+    lane_from_centered<M1>(M, x, q);
+    lp = lane_grad<M1, true>(M, q, g);
     load_row(M, P.eps0_1, eps);
 #pragma unroll
     for (int i = 0; i < ND; ++i) eps[i] *= kap[1];
-    la = hmc_transition<Lane>(M, rng, P.L1, eps, q, g, lp, acc1);
+    la = hmc_transition<Lane, M1>(M, rng, P.L1, eps, q, g, lp, acc1);
     nacc1 += acc1 ? 1u : 0u;
     adapt_update(P.adapt_kind, n, P.n_adapt, P.adapt_target, P.adapt_rate, la, kap[1], es[1], la_[1]);
-    M.to_centered(q, x);
-    M.set_param(av0, bv0);
-    M.from_centered(x, q);
+    lane_to_centered<M1>(M, q, x);
+    if (M0 == kModeVIP || !Lane::HAS_MODES) M.set_param(av0, bv0);
+    lane_from_centered<M0>(M, x, q);
 
     if (s == next_rec && rec_row < P.n_samples) {
       if (P.trace) {

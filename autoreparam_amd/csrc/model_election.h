@@ -31,6 +31,7 @@ struct ElectionLane {
   // sliced element i of this lane: flattened index and validity
   ARP_DEV int lidx(int i) const { return LBASE + slot + K * i; }
   ARP_DEV bool lvalid(int i) const { return i < nloc; }
+  static constexpr bool HAS_MODES = false;
   using Args = ElectionArgs;
 
   float cn[NL][4], cy[NL][4], al[NL], be[NL], lat[NL];

@@ -37,6 +37,7 @@ struct GermanLane {
   static constexpr int NL = 2 * NLS;    // local elements: bls slices, then beta slices
   static constexpr int ND = NG + NL;
   static_assert(K_ * NLS_ == kGermanCols, "lanes x features per lane must cover the padded row");
+  static constexpr bool HAS_MODES = false;
   using Args = GermanArgs;
 
   float a[NLS], b[NLS];     // a of bls_d, b of beta_d (the only ones that matter)

@@ -35,6 +35,7 @@ struct RadonLane {
   // sliced element i of this lane: flattened index and validity
   ARP_DEV int lidx(int i) const { return LBASE + slot + K * i; }
   ARP_DEV bool lvalid(int i) const { return i < nloc; }
+  static constexpr bool HAS_MODES = true;  // grad_m / to_centered_m / from_centered_m below
   using Args = RadonArgs;
 
   static constexpr int LBASE = 3; // flattened index of m_0 (parts: mua, b1, b2, m[J])
@@ -107,6 +108,74 @@ struct RadonLane {
       lp += -0.5f * (mua * mua + b1 * b1 + b2 * b2) + b2 * (sxy - 0.5f * b2 * sxx);
     }
     return lp;
+  }
+
+  // ---- compile-time parameterisations (kernels.h: kModeCP = 1, kModeNCP = 2) ----
+  // CP (a = 1):  r_j = mt_j - mu_j, m_j = mt_j, h_j = r_j.
+  // NCP (a = 0): r_j = mt_j, m_j = mt_j + mu_j, h_j = l_j.
+  // 8 VALU ops per county instead of 10, and no `a` registers.  Only the last
+  // slice of a lane can be padding (j >= J); CP masks its r there.
+  template <bool LOGP, int MODE>
+  ARP_DEV float grad_m(const float (&q)[ND], float (&g)[ND]) const {
+    const float mua = q[0], b1 = q[1], b2 = q[2];
+    float acc_h = 0.0f, acc_uh = 0.0f, acc_ms = 0.0f, lp = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const float mt = q[NG + i];
+      const float mu = fmaf(u[i], b1, mua);
+      const float t = fmaf(-b2, sx[i], sy[i]);
+      float r, m, h;
+      if (MODE == 1) {
+        r = mt - mu;
+        if (i == NL - 1) r = (i < nloc) ? r : 0.0f;
+        m = mt;
+      } else {
+        r = mt;
+        m = mt + mu;
+      }
+      const float l = fmaf(-n[i], m, t);
+      g[NG + i] = l - r;
+      h = (MODE == 1) ? r : l;
+      acc_h += h;
+      acc_uh = fmaf(u[i], h, acc_uh);
+      acc_ms = fmaf(m, sx[i], acc_ms);
+      if (LOGP) {
+        lp = fmaf(-0.5f * r, r, lp);
+        lp = fmaf(-0.5f * m, fmaf(n[i], m, -2.0f * t), lp);
+      }
+    }
+    acc_h = group_sum<K>(acc_h);
+    acc_uh = group_sum<K>(acc_uh);
+    acc_ms = group_sum<K>(acc_ms);
+    g[0] = acc_h - mua;
+    g[1] = acc_uh - b1;
+    g[2] = fmaf(-b2, sxx, sxy) - acc_ms - b2;
+    if (LOGP) {
+      lp = group_sum<K>(lp);
+      lp += -0.5f * (mua * mua + b1 * b1 + b2 * b2) + b2 * (sxy - 0.5f * b2 * sxx);
+    }
+    return lp;
+  }
+  template <int MODE>
+  ARP_DEV void to_centered_m(const float (&q)[ND], float (&x)[ND]) const {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) x[i] = q[i];
+    if (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) x[NG + i] = q[NG + i] + fmaf(u[i], q[1], q[0]);
+    }
+  }
+  template <int MODE>
+  ARP_DEV void from_centered_m(const float (&x)[ND], float (&q)[ND]) const {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) q[i] = x[i];
+    if (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) q[NG + i] = (i < nloc) ? x[NG + i] - fmaf(u[i], x[1], x[0]) : 0.0f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) q[NG + i] = (i < nloc) ? x[NG + i] : 0.0f;
+    }
   }
 
   // d logp / d a_i and d logp / d b_i from the state gradient g (cVIP learns a):

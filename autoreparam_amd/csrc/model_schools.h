@@ -28,6 +28,7 @@ struct SchoolsLane {
   // sliced element i of this lane: flattened index and validity
   ARP_DEV int lidx(int i) const { return LBASE + slot + K * i; }
   ARP_DEV bool lvalid(int i) const { return i < nloc; }
+  static constexpr bool HAS_MODES = false;
   using Args = SchoolsArgs;
 
   float y[NL], is2[NL], a[NL], b[NL];

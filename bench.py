@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """Headline benchmark: leapfrog-steps/sec over all chains, radon(PA), 65 536 chains
-per GPU (BASELINE.json metric), on the fused HIP HMC kernel.
+per GPU (BASELINE.json metric; workload = configs[3]: radon --dataset=PA --method=i,
+interleaved CP/NCP, 4 + 4 = "8 leapfrog steps" per step, main.py:493), on the fused
+HIP kernels.
 
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one launch of the hot path over the whole chain batch: `--transitions`
-HMC transitions (each `--leapfrog` leapfrog steps + Metropolis test + step-size
-adaptation) for every chain on the rank.  Chains are independent, so ranks shard
+sampler steps for every chain on the rank.  With --method i (default) a sampler
+step is one interleaved step: bootstrap + num_ls leapfrogs in CP coordinates,
+to_ncp, bootstrap + num_ls leapfrogs in NCP coordinates, to_cp, two Metropolis
+tests, two simple step-size adaptations (counted as 2*num_ls leapfrog steps, the
+two bootstrap gradient evaluations are extra work that is not counted).  With
+--method CP it is one plain HMC transition of `--leapfrog` steps with dual averaging.  Chains are independent, so ranks shard
 them with no data-path collective (weak scaling: the per-GPU batch is fixed); one
 RCCL all-gather of the acceptance statistics runs after the timed region.
 
@@ -26,30 +32,38 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def algorithmic_bytes_per_transition(D):
-    # read q, grad, logp, 3 adaptation scalars; write the same + accept byte + trace row
-    return 4 * (5 * D + 8) + 1
+def algorithmic_bytes_per_transition(D, trace=True):
+    # read q, grad, logp, 3 adaptation scalars; write the same + accept byte (+ trace row)
+    return 4 * ((5 if trace else 4) * D + 8) + 1
 
 
-def cpu_baseline(spec, L, n_chains, n_trans, eps0, lanes):
+def cpu_baseline(spec, L, n_chains, n_trans, eps0, lanes, inter):
     """The C oracle (oracle/, a port of the same algorithm) timed on this host's cores."""
     import oracle
     orc = oracle.OracleModel(spec)
-    a, b = spec.ab_from_reparam("CP")
+    cp, ncp = spec.ab_from_reparam("CP"), spec.ab_from_reparam("NCP")
     rs = np.random.RandomState(0)
     q0 = (0.1 * rs.randn(n_chains, spec.D)).astype(np.float32)
     st = oracle.new_state(q0, np.float32)
+
+    def run(n):
+        if inter:
+            orc.interleaved_run(st, cp, ncp, eps0, eps0, L, L, n, seed=1, adapt_kind=2, n_adapt=10 ** 6, lanes=lanes)
+        else:
+            orc.hmc_run(st, cp[0], cp[1], eps0, L, n, seed=1, adapt_kind=1, n_adapt=10 ** 6, lanes=lanes)
     t0 = time.time()
-    orc.hmc_run(st, a, b, eps0, L, 16, seed=1, adapt_kind=1, n_adapt=10 ** 6, lanes=lanes)  # warm-up + calibration
-    rate = 16.0 / (time.time() - t0)
+    run(8)                                                 # warm-up + calibration
+    rate = 8.0 / (time.time() - t0)
     n_trans = int(min(max(n_trans, 12.0 * rate), 4096))   # about 12 s of CPU work
     t0 = time.time()
-    orc.hmc_run(st, a, b, eps0, L, n_trans, seed=1, adapt_kind=1, n_adapt=10 ** 6, lanes=lanes)
+    run(n_trans)
     dt = time.time() - t0
     cores = len(os.sched_getaffinity(0))
-    return {"value": n_chains * n_trans * L / dt, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d chains x %d transitions x L=%d, float32 C oracle with OpenMP over chains, %.1f s"
-                      % (n_chains, n_trans, L, dt)}
+    LL = 2 * L if inter else L
+    return {"value": n_chains * n_trans * LL / dt, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d chains x %d %s x %d leapfrogs, float32 C oracle (oracle/oracle.c) with OpenMP over chains "
+                      "on %d threads, %.1f s" % (n_chains, n_trans, "interleaved steps" if inter else "transitions",
+                                                 LL, cores, dt)}
 
 
 def main():
@@ -58,7 +72,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
-    ap.add_argument("--leapfrog", type=int, default=8)
+    ap.add_argument("--method", default="i", choices=["i", "CP"])
+    ap.add_argument("--leapfrog", type=int, default=8, help="leapfrog steps per sampler step (i: split CP/NCP)")
     ap.add_argument("--transitions", type=int, default=32, help="HMC transitions per launch (= per step)")
     ap.add_argument("--dataset", default="PA")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default)")
@@ -82,7 +97,10 @@ def main():
     spec = models._spec_radon(args.dataset)
     eng = engine.Engine(spec, dev)
     eng.set_param(0, "CP")
+    eng.set_param(1, "NCP")
     C, L, T, D = args.chains, args.leapfrog, args.transitions, spec.D
+    inter = args.method == "i"
+    num_ls = L // 2
 
     # synthetic chain population: i.i.d. draws keyed by the global chain id
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -93,11 +111,20 @@ def main():
     S = args.steps * T  # every timed transition appends a trace row
     trace = torch.empty(min(S, 64), C, D, dtype=torch.float32, device=dev)  # ring of rows that gets overwritten
 
-    def launch(record):
+    eps_i = np.full(D, 0.08 / (max(num_ls, 1) / 4.0) ** 2, np.float32)   # interleaved: eps0/(num_ls/4)^2
+    eps_i[2] = 0.02 / (max(num_ls, 1) / 4.0) ** 2
+
+    def launch(record, plain=False):
         # trace rows cycle through a bounded buffer so a long bench does not need S*C*D floats
-        eng.hmc_run(st, eps0, L, T, seed=7, chain_offset=rank * C, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9,
-                    n_burnin=st.step, thin=1, trace=trace[:T] if record else None, trace_centered=True,
-                    lanes=args.lanes)
+        if inter and not plain:
+            eng.interleaved_run(st, eps_i, eps_i, num_ls, num_ls, T, seed=7, chain_offset=rank * C,
+                                adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=10 ** 9, adapt_target=0.75, adapt_rate=0.05,
+                                n_burnin=st.step, thin=1, trace=trace[:T] if record else None, trace_centered=False,
+                                lanes=args.lanes)
+        else:
+            eng.hmc_run(st, eps0, L, T, seed=7, chain_offset=rank * C, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9,
+                        n_burnin=st.step, thin=1, trace=trace[:T] if record else None, trace_centered=True,
+                        lanes=args.lanes)
 
     for _ in range(args.warmup):
         launch(True)
@@ -133,9 +160,30 @@ def main():
     assert torch.isfinite(st.q).all(), "non-finite chain state"
     accept_rate = float(acc.mean().item())
 
+    # secondary figure, same run: the plain fused HMC kernel (CP, dual averaging, L leapfrogs)
+    plain = None
+    if inter and world == 1:
+        st2, st = st, engine.ChainState(q0)
+        for _ in range(2):
+            launch(True, plain=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            launch(True, plain=True)
+        e1.record(); torch.cuda.synchronize()
+        pms = e0.elapsed_time(e1) / 5
+        plain = {"kernel": "hmc_kernel<RadonLane,CP>", "kernel_ms": pms,
+                 "leapfrog_steps_per_s": C * T * L / (pms * 1e-3),
+                 "achieved_GBps": C * T * algorithmic_bytes_per_transition(D) / (pms * 1e-3) / 1e9}
+        st = st2
+
     if rank == 0:
-        value = world * C * T * args.steps * L / elapsed
-        BT = algorithmic_bytes_per_transition(D)
+        LL = 2 * num_ls if inter else L
+        value = world * C * T * args.steps * LL / elapsed
+        # interleaved step = one transition with a trace row + one without (per transition)
+        BT = (algorithmic_bytes_per_transition(D, True) + algorithmic_bytes_per_transition(D, False)) if inter \
+            else algorithmic_bytes_per_transition(D)
         achieved = C * T * BT / (kern_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -149,20 +197,26 @@ def main():
             "value": value, "unit": "leapfrog-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "radon --dataset=%s --method=CP --inference=HMC, %d chains/GPU, L=%d, "
-                                   "%d transitions per launch, dual-averaging adaptation, centred trace row "
-                                   "every transition" % (args.dataset, C, L, T),
-                       "chains_per_gpu": C, "num_leapfrog_steps": L, "transitions_per_step": T, "D": D,
+            "config": {"workload": ("radon --dataset=%s --method=i --inference=HMC (interleaved CP/NCP), %d chains/GPU, "
+                                    "num_ls=%d+%d leapfrog steps, %d interleaved steps per launch, simple step-size "
+                                    "adaptation on both kernels, CP trace row every step" % (args.dataset, C, num_ls,
+                                                                                            num_ls, T)) if inter else
+                                   ("radon --dataset=%s --method=CP --inference=HMC, %d chains/GPU, L=%d, "
+                                    "%d transitions per launch, dual-averaging adaptation, centred trace row "
+                                    "every transition" % (args.dataset, C, L, T)),
+                       "chains_per_gpu": C, "num_leapfrog_steps": LL, "transitions_per_step": T, "D": D,
                        "lanes_per_chain": args.lanes, "parallelism": "chains sharded, %d rank(s)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "hmc_kernel<RadonLane>", "kernel_ms": kern_ms,
+                         "kernel": "interleaved_kernel<RadonLane,CP,NCP>" if inter else "hmc_kernel<RadonLane,CP>",
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_step_per_chain": BT,
                          "algorithmic_bytes_per_launch": C * T * BT},
-            "accept_rate": accept_rate, "stats_allgather_s": t_coll,
+            "accept_rate": accept_rate, "stats_allgather_s": t_coll, "plain_hmc": plain,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(spec, L, 4096, 64, eps0, 8)
+                out["cpu_baseline"] = cpu_baseline(spec, num_ls if inter else L, 8192, 64, eps_i if inter else eps0, 8,
+                                                   inter)
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))
