@@ -15,11 +15,13 @@ static const double kHalfLog2Pi = 0.9189385332046727;
 
 // pick the instantiation: requested lanes-per-chain (or a default from the chain
 // count) and the smallest slice size that covers `groups`.
-static const LaneOps* pick(const std::vector<LaneOps>& ops, int groups, int K_req, int C) {
+// `exact`: the family needs NL == ceil(groups / K) (only a lane's last slice may be padding).
+static const LaneOps* pick(const std::vector<LaneOps>& ops, int groups, int K_req, int C, bool exact) {
   auto best_for = [&](int K) -> const LaneOps* {
     const LaneOps* best = nullptr;
     for (const auto& o : ops)
-      if (o.K == K && (long long)o.NL * K >= groups && (!best || o.NL < best->NL)) best = &o;
+      if (o.K == K && (long long)o.NL * K >= groups && (!exact || (o.NL - 1) * K < groups) &&
+          (!best || o.NL < best->NL)) best = &o;
     return best;
   };
   if (K_req > 0) return best_for(K_req);
@@ -245,8 +247,8 @@ static const LaneOps* select_ops(arp_model* m, int K_req, int C) {
     set_error("lanes_per_chain must be 0,1,2,4,8 or 16");
     return nullptr;
   }
-  const LaneOps* o = pick(*fam, m->n_groups, K_req, C);
-  if (!o) set_error("no kernel instantiation covers this (lanes_per_chain, group count)");
+  const LaneOps* o = pick(*fam, m->n_groups, K_req, C, m->model != ARP_MODEL_GERMAN_CREDIT);
+  if (!o) set_error("no kernel instantiation for this (lanes_per_chain, group count): add RadonLane<K, ceil(J/K)> to inst_radon_k*.hip");
   return o;
 }
 
@@ -282,11 +284,14 @@ static int fill_params(arp_model* m, const arp_hmc_config* cfg, const arp_hmc_io
     return 1;
   }
   if (cfg->adapt_kind < ARP_ADAPT_NONE || cfg->adapt_kind > ARP_ADAPT_SIMPLE) { set_error("bad adapt_kind"); return 1; }
+  if (m->D > kMaxD) { set_error("state dimension exceeds the chain kernels' limit (128)"); return 1; }
   HmcParams& P = *Pp;
   P.C = cfg->n_chains; P.L = cfg->n_leapfrog; P.n_steps = cfg->n_steps;
   P.step_base = cfg->step_base; P.chain_offset = cfg->chain_offset; P.seed = cfg->seed;
   P.adapt_kind = cfg->adapt_kind; P.n_adapt = cfg->n_adapt;
   P.adapt_target = cfg->adapt_target; P.adapt_rate = cfg->adapt_rate;
+  P.adapt_log_target = logf(cfg->adapt_target > 0.f ? cfg->adapt_target : 1e-30f);
+  P.adapt_inv_opr = 1.0f / (1.0f + cfg->adapt_rate);
   P.n_burnin = cfg->n_burnin; P.thin = cfg->thin;
   P.n_samples = (io->trace || io->trace_accept) ? cfg->n_samples : 0;
   P.trace_centered = cfg->trace_centered;
@@ -364,7 +369,7 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   // the VI kernel wants the smallest per-lane slice: the widest lanes-per-chain instantiation
   int Kmax = 0;
   for (const auto& o : *fam) Kmax = std::max(Kmax, o.K);
-  const LaneOps* o = pick(*fam, m->n_groups, Kmax, 1 << 30);
+  const LaneOps* o = pick(*fam, m->n_groups, Kmax, 1 << 30, m->model != ARP_MODEL_GERMAN_CREDIT);
   if (!o) { set_error("no kernel instantiation covers this group count"); return 1; }
   ViParams P;
   P.n_steps = cfg->n_steps; P.n_mc = cfg->n_mc; P.learn_a = cfg->learn_a; P.tied_b = cfg->tied_b; P.D = m->D;

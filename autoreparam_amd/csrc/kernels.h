@@ -11,6 +11,7 @@ namespace arp {
 
 constexpr int kBlock = 256;      // 4 waves per workgroup
 constexpr int kRngSlots = 16;    // rng buffer stride per chain (max lanes per chain)
+constexpr int kMaxD = 128;       // largest state dimension the chain kernels stage in LDS
 
 struct HmcParams {
   int C, L, n_steps;
@@ -19,6 +20,7 @@ struct HmcParams {
   unsigned long long seed;
   int adapt_kind, n_adapt;
   float adapt_target, adapt_rate;
+  float adapt_log_target, adapt_inv_opr;   // log(target), 1/(1+rate): host-computed, live in SGPRs
   int n_burnin, thin, n_samples, trace_centered;
   int rec_step, rec_row;   // first in-launch step (0-based) that records, and its trace row
   int D;
@@ -35,16 +37,27 @@ struct HmcParams {
 // ---------------------------------------------------------------------------
 // Row I/O in the reference layout [C][D].  Lane `slot` of a chain owns the
 // replicated globals (flattened index M.gg(i)) and NL sliced elements at
-// flattened index M.lidx(i) (valid when M.lvalid(i)); the lane models express
-// lidx as slot-dependent base + compile-time offset, so one 64-bit base per row
-// and immediate offsets are enough.
+// flattened index M.lidx(i) = M.lbase(i) + Lane::loff(i) (valid when M.lvalid(i)):
+// lbase is a per-lane base shared by all slices of a part, loff a compile-time
+// offset, so one 64-bit base per row and part plus immediate offsets are enough.
+// In the slot + K*i models only the LAST slice of a lane can be padding (the host
+// picks NL == ceil(groups / K) exactly), so lvalid folds to `true` for the others.
 // ---------------------------------------------------------------------------
 template <class Lane>
 ARP_DEV void load_row(const Lane& M, const float* __restrict__ row, float (&v)[Lane::ND]) {
 #pragma unroll
   for (int i = 0; i < Lane::NG; ++i) v[i] = row[M.gg(i)];
 #pragma unroll
-  for (int i = 0; i < Lane::NL; ++i) v[Lane::NG + i] = M.lvalid(i) ? row[M.lidx(i)] : 0.0f;
+  for (int i = 0; i < Lane::NL; ++i) v[Lane::NG + i] = M.lvalid(i) ? (row + M.lbase(i))[Lane::loff(i)] : 0.0f;
+}
+// same from LDS, through a volatile pointer so that the loads stay inside the sampling loop
+// (hoisted out they would sit in VGPRs, or in scratch, for the whole launch)
+template <class Lane>
+ARP_DEV void load_row_lds(const Lane& M, const volatile float* row, float (&v)[Lane::ND]) {
+#pragma unroll
+  for (int i = 0; i < Lane::NG; ++i) v[i] = row[M.gg(i)];
+#pragma unroll
+  for (int i = 0; i < Lane::NL; ++i) v[Lane::NG + i] = M.lvalid(i) ? (row + M.lbase(i))[Lane::loff(i)] : 0.0f;
 }
 template <class Lane>
 ARP_DEV void store_row(const Lane& M, float* __restrict__ row, const float (&v)[Lane::ND], bool live) {
@@ -54,7 +67,7 @@ ARP_DEV void store_row(const Lane& M, float* __restrict__ row, const float (&v)[
   }
 #pragma unroll
   for (int i = 0; i < Lane::NL; ++i)
-    if (live && M.lvalid(i)) row[M.lidx(i)] = v[Lane::NG + i];
+    if (live && M.lvalid(i)) (row + M.lbase(i))[Lane::loff(i)] = v[Lane::NG + i];
 }
 
 // ---------------------------------------------------------------------------
@@ -70,6 +83,24 @@ template <int MODE, bool LOGP, class Lane>
 ARP_DEV float lane_grad(const Lane& M, const float (&q)[Lane::ND], float (&g)[Lane::ND]) {
   if constexpr (MODE != kModeVIP && Lane::HAS_MODES) return M.template grad_m<LOGP, MODE>(q, g);
   else return M.template grad<LOGP>(q, g);
+}
+// One interior leapfrog step: gradient at q, full kick, drift -- q and p updated in place.
+// Lane models with HAS_FUSED do it in a single pass over their groups (the gradient of a
+// group is consumed as soon as it is formed, so no gradient array stays live in the loop).
+template <int MODE, class Lane>
+ARP_DEV void lane_kick_drift(const Lane& M, float (&q)[Lane::ND], float (&p)[Lane::ND],
+                             const float (&eps)[Lane::ND]) {
+  if constexpr (Lane::HAS_FUSED) {
+    M.template kick_drift<MODE>(q, p, eps);
+  } else {
+    float g[Lane::ND];
+    lane_grad<MODE, false>(M, q, g);
+#pragma unroll
+    for (int i = 0; i < Lane::ND; ++i) {
+      p[i] = fmaf(eps[i], g[i], p[i]);
+      q[i] = fmaf(eps[i], p[i], q[i]);
+    }
+  }
 }
 template <int MODE, class Lane>
 ARP_DEV void lane_to_centered(const Lane& M, const float (&q)[Lane::ND], float (&x)[Lane::ND]) {
@@ -128,14 +159,17 @@ __global__ __launch_bounds__(kBlock) void transform_kernel(
 // One HMC transition on the lane slice (mcmc.HamiltonianMonteCarlo.one_step as
 // wired at inference.py:218-222): momentum draw, L leapfrog steps with the two
 // half kicks of consecutive steps merged, Metropolis test.  Returns the log
-// acceptance ratio; q/g/lp are replaced in place when the proposal is accepted.
+// acceptance ratio.  The trajectory is integrated in place in q/g; the starting
+// state is parked in the lane's LDS column (`save[i * kBlock]`, conflict free) and
+// only the rejecting lanes read it back, so no second copy of the state lives in
+// VGPRs and acceptance needs no per-element select.
 // ---------------------------------------------------------------------------
 template <class Lane, int MODE = kModeVIP>
 ARP_DEV float hmc_transition(const Lane& M, Rng& rng, int L, const float (&eps)[Lane::ND],
                              float (&q)[Lane::ND], float (&g)[Lane::ND], float& lp,
-                             bool& accepted) {
+                             bool& accepted, float* save) {
   constexpr int K = Lane::K, ND = Lane::ND, NG = Lane::NG;
-  float p[ND], q1[ND], g1[ND];
+  float p[ND];
   // momenta: every lane draws ND normals from its own stream; the replicated
   // globals take slot 0's draw, padding slots get none.
 #pragma unroll
@@ -165,22 +199,17 @@ ARP_DEV float hmc_transition(const Lane& M, Rng& rng, int L, const float (&eps)[
 
 #pragma unroll
   for (int i = 0; i < ND; ++i) {
-    q1[i] = q[i];
+    save[i * kBlock] = q[i];
+    save[(ND + i) * kBlock] = g[i];
     p[i] = fmaf(0.5f * eps[i], g[i], p[i]);
   }
-  // L-1 full steps, then the last position update with the closing half kick
-  for (int l = 1; l < L; ++l) {
+  // first drift, L-1 interior steps (gradient, full kick, drift), then the closing half kick
 #pragma unroll
-    for (int i = 0; i < ND; ++i) q1[i] = fmaf(eps[i], p[i], q1[i]);
-    lane_grad<MODE, false>(M, q1, g1);
+  for (int i = 0; i < ND; ++i) q[i] = fmaf(eps[i], p[i], q[i]);
+  for (int l = 1; l < L; ++l) lane_kick_drift<MODE>(M, q, p, eps);
+  const float lp1 = lane_grad<MODE, true>(M, q, g);
 #pragma unroll
-    for (int i = 0; i < ND; ++i) p[i] = fmaf(eps[i], g1[i], p[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < ND; ++i) q1[i] = fmaf(eps[i], p[i], q1[i]);
-  const float lp1 = lane_grad<MODE, true>(M, q1, g1);
-#pragma unroll
-  for (int i = 0; i < ND; ++i) p[i] = fmaf(0.5f * eps[i], g1[i], p[i]);
+  for (int i = 0; i < ND; ++i) p[i] = fmaf(0.5f * eps[i], g[i], p[i]);
   float ke1 = 0.0f, keg1 = 0.0f;
 #pragma unroll
   for (int i = 0; i < ND; ++i) {
@@ -192,10 +221,12 @@ ARP_DEV float hmc_transition(const Lane& M, Rng& rng, int L, const float (&eps)[
   float la = (lp1 - lp) + (ke0 - ke1);
   if (!(fabsf(la) <= 3.0e38f)) la = -INFINITY;
   accepted = fast_log(u) < la;
+  if (!accepted) {
 #pragma unroll
-  for (int i = 0; i < ND; ++i) {
-    q[i] = accepted ? q1[i] : q[i];
-    g[i] = accepted ? g1[i] : g[i];
+    for (int i = 0; i < ND; ++i) {
+      q[i] = save[i * kBlock];
+      g[i] = save[(ND + i) * kBlock];
+    }
   }
   lp = accepted ? lp1 : lp;
   return la;
@@ -205,8 +236,10 @@ ARP_DEV float hmc_transition(const Lane& M, Rng& rng, int L, const float (&eps)[
 // kappa scales the per-element base step eps0 (all elements of a chain see the
 // same acceptance probability, so the reference's per-element adaptation state
 // collapses to one scalar per chain).
-ARP_DEV void adapt_update(int kind, long long n, int n_adapt, float target, float rate, float la,
+ARP_DEV void adapt_update(const HmcParams& P, long long n, float la,
                           float& kappa, float& esum, float& logavg) {
+  const int kind = P.adapt_kind, n_adapt = P.n_adapt;
+  const float target = P.adapt_target, rate = P.adapt_rate;
   if (kind == ARP_ADAPT_NONE) return;
   float lacc = fminf(la, 0.0f);
   if (kind == ARP_ADAPT_DUAL) {
@@ -224,13 +257,13 @@ ARP_DEV void adapt_update(int kind, long long n, int n_adapt, float target, floa
   } else {  // ARP_ADAPT_SIMPLE
     if (n <= n_adapt) {
       float opr = 1.0f + rate;
-      kappa *= lacc > fast_log(target) ? opr : __builtin_amdgcn_rcpf(opr);
+      kappa *= lacc > P.adapt_log_target ? opr : P.adapt_inv_opr;
     }
   }
 }
 
 template <class Lane, int MODE = kModeVIP>
-__global__ __launch_bounds__(kBlock) void hmc_kernel(
+__global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
     typename Lane::Args A, const float* __restrict__ av, const float* __restrict__ bv, HmcParams P) {
   constexpr int K = Lane::K, ND = Lane::ND, NG = Lane::NG;
   long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
@@ -241,6 +274,14 @@ __global__ __launch_bounds__(kBlock) void hmc_kernel(
   const int D = P.D;
   Lane M;
   M.init(A, av, bv, slot);
+
+  // base step sizes stay in LDS for the whole launch: re-reading them from global
+  // memory every transition would queue behind the trace stores (vmcnt is in order)
+  __shared__ float s_eps[kMaxD];
+  __shared__ float s_save[2 * ND * kBlock];   // parked start-of-trajectory state, one column per lane
+  float* save = s_save + threadIdx.x;
+  for (int d = threadIdx.x; d < D; d += kBlock) s_eps[d] = P.eps0[d];
+  __syncthreads();
 
   float q[ND], g[ND], eps[ND];
   float* qrow = P.q + c * D;
@@ -266,16 +307,18 @@ __global__ __launch_bounds__(kBlock) void hmc_kernel(
   uint32_t nacc = (P.step_base == 0) ? 0u : P.accept_count[c];
 
   int next_rec = P.rec_step, rec_row = P.rec_row;
+  // everything loaded so far has landed: no load result is awaited inside the loop, so the
+  // in-order vmcnt never makes a wave wait for its own trace stores
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   for (int s = 0; s < P.n_steps; ++s) {
-    // eps0 is re-read (L1/L2 resident, [D] floats) instead of living in VGPRs
-    load_row(M, P.eps0, eps);
+    load_row(M, s_eps, eps);
 #pragma unroll
     for (int i = 0; i < ND; ++i) eps[i] *= kappa;
     bool acc;
-    float la = hmc_transition<Lane, MODE>(M, rng, P.L, eps, q, g, lp, acc);
+    float la = hmc_transition<Lane, MODE>(M, rng, P.L, eps, q, g, lp, acc, save);
     nacc += acc ? 1u : 0u;
     const long long n = P.step_base + s + 1;
-    adapt_update(P.adapt_kind, n, P.n_adapt, P.adapt_target, P.adapt_rate, la, kappa, esum, logavg);
+    adapt_update(P, n, la, kappa, esum, logavg);
 
     // sample_chain schedule: result r is the state after transition 1 + burnin + r*thin
     if (s == next_rec && rec_row < P.n_samples) {
@@ -295,14 +338,20 @@ __global__ __launch_bounds__(kBlock) void hmc_kernel(
     }
   }
 
-  store_row(M, qrow, q, live);
-  store_row(M, grow, g, live);
+  // recompute the per-lane row addresses here instead of keeping 64-bit pointers alive (in VGPR
+  // pairs) across the whole sampling loop
+  long long c2 = c;
+  asm volatile("" : "+v"(c2));
+  store_row(M, P.q + c2 * D, q, live);
+  store_row(M, P.grad + c2 * D, g, live);
+  uint32_t* rs2 = P.rng + ((size_t)c2 * kRngSlots + slot) * 4;
   if (live) {
+    rs = rs2;
     rs[0] = rng.s0; rs[1] = rng.s1; rs[2] = rng.s2; rs[3] = rng.s3;
     if (slot == 0) {
-      P.logp[c] = lp;
-      P.adapt[c * 4 + 0] = kappa; P.adapt[c * 4 + 1] = esum; P.adapt[c * 4 + 2] = logavg;
-      P.accept_count[c] = nacc;
+      P.logp[c2] = lp;
+      P.adapt[c2 * 4 + 0] = kappa; P.adapt[c2 * 4 + 1] = esum; P.adapt[c2 * 4 + 2] = logavg;
+      P.accept_count[c2] = nacc;
     }
   }
 }
@@ -318,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void hmc_kernel(
 //   (inference.py:288-306).  2*(L+1) gradient evaluations per step.
 // ---------------------------------------------------------------------------
 template <class Lane, int M0 = kModeVIP, int M1 = kModeVIP>
-__global__ __launch_bounds__(kBlock) void interleaved_kernel(
+__global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
     typename Lane::Args A, const float* __restrict__ av0, const float* __restrict__ bv0,
     const float* __restrict__ av1, const float* __restrict__ bv1, HmcParams P) {
   constexpr int K = Lane::K, ND = Lane::ND;
@@ -330,6 +379,12 @@ __global__ __launch_bounds__(kBlock) void interleaved_kernel(
   const int D = P.D;
   Lane M;
   M.init(A, av0, bv0, slot);
+
+  __shared__ float s_eps[2][kMaxD];
+  __shared__ float s_save[2 * ND * kBlock];
+  float* save = s_save + threadIdx.x;
+  for (int d = threadIdx.x; d < D; d += kBlock) { s_eps[0][d] = P.eps0[d]; s_eps[1][d] = P.eps0_1[d]; }
+  __syncthreads();
 
   float q[ND], g[ND], eps[ND], x[ND];
   float* qrow = P.q + c * D;
@@ -350,28 +405,29 @@ __global__ __launch_bounds__(kBlock) void interleaved_kernel(
   }
 
   int next_rec = P.rec_step, rec_row = P.rec_row;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see hmc_kernel
   for (int s = 0; s < P.n_steps; ++s) {
     const long long n = P.step_base + s + 1;
     bool acc0, acc1;
     // --- parameterisation 0 ---
     float lp = lane_grad<M0, true>(M, q, g);
-    load_row(M, P.eps0, eps);
+    load_row(M, s_eps[0], eps);
 #pragma unroll
     for (int i = 0; i < ND; ++i) eps[i] *= kap[0];
-    float la = hmc_transition<Lane, M0>(M, rng, P.L, eps, q, g, lp, acc0);
+    float la = hmc_transition<Lane, M0>(M, rng, P.L, eps, q, g, lp, acc0, save);
     nacc0 += acc0 ? 1u : 0u;
-    adapt_update(P.adapt_kind, n, P.n_adapt, P.adapt_target, P.adapt_rate, la, kap[0], es[0], la_[0]);
+    adapt_update(P, n, la, kap[0], es[0], la_[0]);
     lane_to_centered<M0>(M, q, x);
     // --- parameterisation 1 ---
     if (M1 == kModeVIP || !Lane::HAS_MODES) M.set_param(av1, bv1);
     lane_from_centered<M1>(M, x, q);
     lp = lane_grad<M1, true>(M, q, g);
-    load_row(M, P.eps0_1, eps);
+    load_row(M, s_eps[1], eps);
 #pragma unroll
     for (int i = 0; i < ND; ++i) eps[i] *= kap[1];
-    la = hmc_transition<Lane, M1>(M, rng, P.L1, eps, q, g, lp, acc1);
+    la = hmc_transition<Lane, M1>(M, rng, P.L1, eps, q, g, lp, acc1, save);
     nacc1 += acc1 ? 1u : 0u;
-    adapt_update(P.adapt_kind, n, P.n_adapt, P.adapt_target, P.adapt_rate, la, kap[1], es[1], la_[1]);
+    adapt_update(P, n, la, kap[1], es[1], la_[1]);
     lane_to_centered<M1>(M, q, x);
     if (M0 == kModeVIP || !Lane::HAS_MODES) M.set_param(av0, bv0);
     lane_from_centered<M0>(M, x, q);
@@ -391,13 +447,17 @@ __global__ __launch_bounds__(kBlock) void interleaved_kernel(
     }
   }
 
-  store_row(M, qrow, q, live);
+  long long c2 = c;
+  asm volatile("" : "+v"(c2));
+  store_row(M, P.q + c2 * D, q, live);
+  uint32_t* rs2 = P.rng + ((size_t)c2 * kRngSlots + slot) * 4;
   if (live) {
+    rs = rs2;
     rs[0] = rng.s0; rs[1] = rng.s1; rs[2] = rng.s2; rs[3] = rng.s3;
     if (slot == 0) {
-      P.adapt[c * 4 + 0] = kap[0]; P.adapt[c * 4 + 1] = es[0]; P.adapt[c * 4 + 2] = la_[0];
-      P.adapt1[c * 4 + 0] = kap[1]; P.adapt1[c * 4 + 1] = es[1]; P.adapt1[c * 4 + 2] = la_[1];
-      P.accept_count[c] = nacc0; P.accept_count1[c] = nacc1;
+      P.adapt[c2 * 4 + 0] = kap[0]; P.adapt[c2 * 4 + 1] = es[0]; P.adapt[c2 * 4 + 2] = la_[0];
+      P.adapt1[c2 * 4 + 0] = kap[1]; P.adapt1[c2 * 4 + 1] = es[1]; P.adapt1[c2 * 4 + 2] = la_[1];
+      P.accept_count[c2] = nacc0; P.accept_count1[c2] = nacc1;
     }
   }
 }

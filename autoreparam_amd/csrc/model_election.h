@@ -29,9 +29,15 @@ struct ElectionLane {
   static constexpr int ND = NG + NL;
   static constexpr int LBASE = 2;
   // sliced element i of this lane: flattened index and validity
+  ARP_DEV int lbase(int) const { return LBASE + slot; }
+  static constexpr ARP_DEV int loff(int i) { return K * i; }
   ARP_DEV int lidx(int i) const { return LBASE + slot + K * i; }
-  ARP_DEV bool lvalid(int i) const { return i < nloc; }
+  // only the last slice can be padding: NL == ceil(groups / K) is enforced by the host
+  ARP_DEV bool lvalid(int i) const { return i < NL - 1 ? true : last_ok; }
+  bool last_ok;
   static constexpr bool HAS_MODES = false;
+  static constexpr bool HAS_FUSED = false;
+  static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
   using Args = ElectionArgs;
 
   float cn[NL][4], cy[NL][4], al[NL], be[NL], lat[NL];
@@ -47,6 +53,7 @@ struct ElectionLane {
     S = A.S;
     nloc = (S - slot + K - 1) / K;       // latents: t < S
     if (nloc < 0) nloc = 0;
+    last_ok = slot + K * (NL - 1) < S;   // latent validity (t < S); the extra cell group t == S has no latent
     ndraw = NG + (S + 1 + K - 1) / K;    // RNG layout counts the S+1 groups
     gmap[0] = 0; gmap[1] = 1; gmap[2] = 2 + S; gmap[3] = 3 + S;
 #pragma unroll
@@ -73,7 +80,7 @@ struct ElectionLane {
     }
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      bool has = i < nloc;
+      bool has = lvalid(i);
       al[i] = has ? av[LBASE + slot + K * i] : 0.0f;
       be[i] = has ? bv[LBASE + slot + K * i] : 0.0f;
     }
@@ -138,7 +145,7 @@ struct ElectionLane {
     for (int i = 0; i < 4; ++i) { da[i] = 0.0f; db[i] = -lns[i] * fmaf(q[i], g[i], 1.0f); }
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      bool ok = i < nloc;
+      bool ok = lvalid(i);
       da[NG + i] = ok ? -mua * g[NG + i] : 0.0f;
       db[NG + i] = ok ? -ls * fmaf(q[NG + i] - al[i] * mua, g[NG + i], 1.0f) : 0.0f;
     }
@@ -156,7 +163,7 @@ struct ElectionLane {
     q[0] = mua / cs[0]; q[1] = ls / cs[1]; q[2] = x[2] / cs[2]; q[3] = x[3] / cs[3];
 #pragma unroll
     for (int i = 0; i < NL; ++i)
-      q[NG + i] = (i < nloc) ? fmaf(x[NG + i] - mua, fast_exp(-(1.0f - be[i]) * ls), al[i] * mua) : 0.0f;
+      q[NG + i] = lvalid(i) ? fmaf(x[NG + i] - mua, fast_exp(-(1.0f - be[i]) * ls), al[i] * mua) : 0.0f;
   }
 };
 

@@ -38,6 +38,8 @@ struct GermanLane {
   static constexpr int ND = NG + NL;
   static_assert(K_ * NLS_ == kGermanCols, "lanes x features per lane must cover the padded row");
   static constexpr bool HAS_MODES = false;
+  static constexpr bool HAS_FUSED = false;
+  static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
   using Args = GermanArgs;
 
   float a[NLS], b[NLS];     // a of bls_d, b of beta_d (the only ones that matter)
@@ -46,6 +48,8 @@ struct GermanLane {
   int N, F, slot, ndraw, nown;
 
   static ARP_DEV int gg(int) { return 0; }
+  ARP_DEV int lbase(int i) const { return i < NLS ? 1 + slot * NLS : 1 + F + slot * NLS; }
+  static constexpr ARP_DEV int loff(int i) { return i < NLS ? i : i - NLS; }
   ARP_DEV int lidx(int i) const { return i < NLS ? 1 + slot * NLS + i : 1 + F + slot * NLS + (i - NLS); }
   ARP_DEV bool lvalid(int i) const { return (i < NLS ? i : i - NLS) < nown; }
 

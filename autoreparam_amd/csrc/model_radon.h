@@ -33,9 +33,16 @@ struct RadonLane {
   static constexpr int NL = NL_; // counties owned by this lane: j = slot + K*i
   static constexpr int ND = NG + NL;
   // sliced element i of this lane: flattened index and validity
+  ARP_DEV int lbase(int) const { return LBASE + slot; }
+  static constexpr ARP_DEV int loff(int i) { return K * i; }
   ARP_DEV int lidx(int i) const { return LBASE + slot + K * i; }
-  ARP_DEV bool lvalid(int i) const { return i < nloc; }
-  static constexpr bool HAS_MODES = true;  // grad_m / to_centered_m / from_centered_m below
+  // only the last slice can be padding: NL == ceil(groups / K) is enforced by the host
+  ARP_DEV bool lvalid(int i) const { return i < NL - 1 ? true : last_ok; }
+  bool last_ok;
+  // VALU issue needs two resident waves per SIMD: cap the allocation at 256 VGPRs where the slice fits
+  static constexpr int MINW = (NL_ <= 23) ? 2 : 1;
+  static constexpr bool HAS_MODES = true;
+  static constexpr bool HAS_FUSED = true;   // kick_drift below  // grad_m / to_centered_m / from_centered_m below
   using Args = RadonArgs;
 
   static constexpr int LBASE = 3; // flattened index of m_0 (parts: mua, b1, b2, m[J])
@@ -52,6 +59,7 @@ struct RadonLane {
     slot = slot_;
     const int J = A.J;
     nloc = (J - slot + K - 1) / K;
+    last_ok = slot + K * (NL - 1) < J;
     ndraw = NG + (J + K - 1) / K;
     sxy = A.sxy;
     sxx = A.sxx;
@@ -69,7 +77,7 @@ struct RadonLane {
   // (re)load the parameterisation-dependent slice (the interleaved kernel switches it twice per step)
   ARP_DEV void set_param(const float* av, const float* /*bv*/) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) a[i] = (i < nloc) ? av[LBASE + slot + K * i] : 0.0f;
+    for (int i = 0; i < NL; ++i) a[i] = lvalid(i) ? av[LBASE + slot + K * i] : 0.0f;
   }
 
   // Gradient of the log joint at q (and the log joint itself, additive
@@ -127,7 +135,7 @@ struct RadonLane {
       float r, m, h;
       if (MODE == 1) {
         r = mt - mu;
-        if (i == NL - 1) r = (i < nloc) ? r : 0.0f;
+        if (i == NL - 1) r = last_ok ? r : 0.0f;
         m = mt;
       } else {
         r = mt;
@@ -156,6 +164,49 @@ struct RadonLane {
     }
     return lp;
   }
+  // Interior leapfrog step in one pass (kernels.h: lane_kick_drift): for every county the
+  // gradient is formed, kicked into p and the position drifted at once; the three
+  // top-level scalars follow after the group sums.  MODE 0 uses the `a` table.
+  template <int MODE>
+  ARP_DEV void kick_drift(float (&q)[ND], float (&p)[ND], const float (&eps)[ND]) const {
+    const float mua = q[0], b1 = q[1], b2 = q[2];
+    float acc_h = 0.0f, acc_uh = 0.0f, acc_ms = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const float mt = q[NG + i];
+      const float mu = fmaf(u[i], b1, mua);
+      const float t = fmaf(-b2, sx[i], sy[i]);
+      float r, m, h;
+      if (MODE == 1) {
+        r = mt - mu;
+        if (i == NL - 1) r = last_ok ? r : 0.0f;
+        m = mt;
+      } else if (MODE == 2) {
+        r = mt;
+        m = mt + mu;
+      } else {
+        r = fmaf(-a[i], mu, mt);
+        m = r + mu;
+      }
+      const float l = fmaf(-n[i], m, t);
+      const float gm = l - r;
+      h = (MODE == 1) ? r : ((MODE == 2) ? l : fmaf(-a[i], gm, l));
+      acc_h += h;
+      acc_uh = fmaf(u[i], h, acc_uh);
+      acc_ms = fmaf(m, sx[i], acc_ms);
+      const float pn = fmaf(eps[NG + i], gm, p[NG + i]);
+      p[NG + i] = pn;
+      q[NG + i] = fmaf(eps[NG + i], pn, mt);
+    }
+    acc_h = group_sum<K>(acc_h);
+    acc_uh = group_sum<K>(acc_uh);
+    acc_ms = group_sum<K>(acc_ms);
+    const float g0 = acc_h - mua, g1 = acc_uh - b1, g2 = fmaf(-b2, sxx, sxy) - acc_ms - b2;
+    p[0] = fmaf(eps[0], g0, p[0]); q[0] = fmaf(eps[0], p[0], mua);
+    p[1] = fmaf(eps[1], g1, p[1]); q[1] = fmaf(eps[1], p[1], b1);
+    p[2] = fmaf(eps[2], g2, p[2]); q[2] = fmaf(eps[2], p[2], b2);
+  }
+
   template <int MODE>
   ARP_DEV void to_centered_m(const float (&q)[ND], float (&x)[ND]) const {
 #pragma unroll
@@ -171,10 +222,10 @@ struct RadonLane {
     for (int i = 0; i < ND; ++i) q[i] = x[i];
     if (MODE == 2) {
 #pragma unroll
-      for (int i = 0; i < NL; ++i) q[NG + i] = (i < nloc) ? x[NG + i] - fmaf(u[i], x[1], x[0]) : 0.0f;
+      for (int i = 0; i < NL; ++i) q[NG + i] = lvalid(i) ? x[NG + i] - fmaf(u[i], x[1], x[0]) : 0.0f;
     } else {
 #pragma unroll
-      for (int i = 0; i < NL; ++i) q[NG + i] = (i < nloc) ? x[NG + i] : 0.0f;
+      for (int i = 0; i < NL; ++i) q[NG + i] = lvalid(i) ? x[NG + i] : 0.0f;
     }
   }
 
@@ -203,7 +254,7 @@ struct RadonLane {
     for (int i = 0; i < NL; ++i) {
       float mu = fmaf(u[i], x[1], x[0]);
       // mt = m - (1-a) mu ; padding slots (a = 0, x = 0 on input) must stay 0
-      q[NG + i] = (i < nloc) ? x[NG + i] - (1.0f - a[i]) * mu : 0.0f;
+      q[NG + i] = lvalid(i) ? x[NG + i] - (1.0f - a[i]) * mu : 0.0f;
     }
   }
 };

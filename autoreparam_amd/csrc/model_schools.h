@@ -26,9 +26,15 @@ struct SchoolsLane {
   static constexpr int ND = NG + NL;
   static constexpr int LBASE = 2;
   // sliced element i of this lane: flattened index and validity
+  ARP_DEV int lbase(int) const { return LBASE + slot; }
+  static constexpr ARP_DEV int loff(int i) { return K * i; }
   ARP_DEV int lidx(int i) const { return LBASE + slot + K * i; }
-  ARP_DEV bool lvalid(int i) const { return i < nloc; }
+  // only the last slice can be padding: NL == ceil(groups / K) is enforced by the host
+  ARP_DEV bool lvalid(int i) const { return i < NL - 1 ? true : last_ok; }
+  bool last_ok;
   static constexpr bool HAS_MODES = false;
+  static constexpr bool HAS_FUSED = false;
+  static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
   using Args = SchoolsArgs;
 
   float y[NL], is2[NL], a[NL], b[NL];
@@ -41,6 +47,7 @@ struct SchoolsLane {
     slot = slot_;
     nloc = (8 - slot + K - 1) / K;
     if (nloc < 0) nloc = 0;
+    last_ok = slot + K * (NL - 1) < 8;
     ndraw = NG + (8 + K - 1) / K;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -60,7 +67,7 @@ struct SchoolsLane {
     c1 = 5.0f * s1i;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      bool ok = i < nloc;
+      bool ok = lvalid(i);
       a[i] = ok ? av[LBASE + slot + K * i] : 0.0f;
       b[i] = ok ? bv[LBASE + slot + K * i] : 0.0f;
     }
@@ -105,7 +112,7 @@ struct SchoolsLane {
     db[1] = -ln5 * fmaf(q[1], g[1], 1.0f);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      bool ok = i < nloc;
+      bool ok = lvalid(i);
       da[NG + i] = ok ? -mu * g[NG + i] : 0.0f;
       db[NG + i] = ok ? -lt * fmaf(q[NG + i] - a[i] * mu, g[NG + i], 1.0f) : 0.0f;
     }
@@ -123,7 +130,7 @@ struct SchoolsLane {
     q[0] = mu / c0; q[1] = lt / c1;
 #pragma unroll
     for (int i = 0; i < NL; ++i)
-      q[NG + i] = (i < nloc) ? fmaf(x[NG + i] - mu, fast_exp(-(1.0f - b[i]) * lt), a[i] * mu) : 0.0f;
+      q[NG + i] = lvalid(i) ? fmaf(x[NG + i] - mu, fast_exp(-(1.0f - b[i]) * lt), a[i] * mu) : 0.0f;
   }
 };
 

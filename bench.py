@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--dataset", default="PA")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-trace", action="store_true", help="diagnostic: do not record trace rows")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,8 +127,9 @@ def main():
                         n_burnin=st.step, thin=1, trace=trace[:T] if record else None, trace_centered=True,
                         lanes=args.lanes)
 
+    rec = not args.no_trace
     for _ in range(args.warmup):
-        launch(True)
+        launch(rec)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -136,7 +138,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        launch(True)
+        launch(rec)
         ev[k][1].record()
     torch.cuda.synchronize()
     if dist is not None:
