@@ -71,6 +71,47 @@ ARP_DEV void store_row(const Lane& M, float* __restrict__ row, const float (&v)[
 }
 
 // ---------------------------------------------------------------------------
+// Coalesced row stores.  The 64/K chains of a wave are consecutive, so their rows
+// form ONE contiguous block of (64/K)*D floats in a [C][D] array.  The lanes drop
+// their slices into the wave's LDS staging area (laid out like the memory image)
+// and the wave then streams the block out with 16-byte-per-lane stores, instead
+// of D/K dword stores per lane that each touch 64/K different cache lines.
+// LDS operations of one wave execute in order, so no barrier is needed.
+// ---------------------------------------------------------------------------
+template <class Lane>
+constexpr int stage_floats() { return (((64 / Lane::K) * Lane::DCAP) + 3) & ~3; }
+
+template <class Lane>
+ARP_DEV void store_row_wave(const Lane& M, float* stage, float* gdst, int cl, int D, int nvalid,
+                            const float (&v)[Lane::ND]) {
+  float* row = stage + cl * D;
+  if (M.slot == 0) {
+#pragma unroll
+    for (int i = 0; i < Lane::NG; ++i) row[M.gg(i)] = v[i];
+  }
+#pragma unroll
+  for (int i = 0; i < Lane::NL; ++i)
+    if (M.lvalid(i)) (row + M.lbase(i))[Lane::loff(i)] = v[Lane::NG + i];
+  __builtin_amdgcn_wave_barrier();
+  const int lane = threadIdx.x & 63;
+  if ((reinterpret_cast<uintptr_t>(gdst) & 15) == 0) {
+    for (int k = lane * 4; k < nvalid; k += 256) {
+      const float4 t = *reinterpret_cast<const float4*>(stage + k);
+      if (k + 3 < nvalid) {
+        *reinterpret_cast<float4*>(gdst + k) = t;
+      } else {
+        gdst[k] = t.x;
+        if (k + 1 < nvalid) gdst[k + 1] = t.y;
+        if (k + 2 < nvalid) gdst[k + 2] = t.z;
+      }
+    }
+  } else {
+    for (int k = lane; k < nvalid; k += 64) gdst[k] = stage[k];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------
 // Parameterisation modes.  MODE 0 evaluates the general VIP form with per-element
 // (a,b) held in registers; lane models that set HAS_MODES also provide
 // compile-time specialisations for the two parameterisations every run uses,
@@ -279,7 +320,13 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
   // memory every transition would queue behind the trace stores (vmcnt is in order)
   __shared__ float s_eps[kMaxD];
   __shared__ float s_save[2 * ND * kBlock];   // parked start-of-trajectory state, one column per lane
+  __shared__ __attribute__((aligned(16))) float s_stage[(kBlock / 64) * stage_floats<Lane>()];
   float* save = s_save + threadIdx.x;
+  float* stage = s_stage + (threadIdx.x >> 6) * stage_floats<Lane>();
+  // first chain of this wave, this lane's chain within the wave, floats of the wave's live chains
+  const long long cw0 = ((long long)blockIdx.x * kBlock + (threadIdx.x & ~63)) / K;
+  const int cl = (threadIdx.x & 63) / K;
+  const int nvalid = (int)(P.C - cw0 < 64 / K ? (P.C - cw0 > 0 ? P.C - cw0 : 0) : 64 / K) * D;
   for (int d = threadIdx.x; d < D; d += kBlock) s_eps[d] = P.eps0[d];
   __syncthreads();
 
@@ -323,13 +370,13 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
     // sample_chain schedule: result r is the state after transition 1 + burnin + r*thin
     if (s == next_rec && rec_row < P.n_samples) {
       if (P.trace) {
-        float* row = P.trace + ((size_t)rec_row * P.C + c) * D;
+        float* wrow = P.trace + ((size_t)rec_row * P.C + cw0) * D;
         if (P.trace_centered) {
           float x[ND];
           lane_to_centered<MODE>(M, q, x);
-          store_row(M, row, x, live);
+          store_row_wave(M, stage, wrow, cl, D, nvalid, x);
         } else {
-          store_row(M, row, q, live);
+          store_row_wave(M, stage, wrow, cl, D, nvalid, q);
         }
       }
       if (P.trace_accept && live && slot == 0) P.trace_accept[(size_t)rec_row * P.C + c] = acc ? 1 : 0;
@@ -342,8 +389,10 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
   // pairs) across the whole sampling loop
   long long c2 = c;
   asm volatile("" : "+v"(c2));
-  store_row(M, P.q + c2 * D, q, live);
-  store_row(M, P.grad + c2 * D, g, live);
+  long long cw2 = cw0;
+  asm volatile("" : "+v"(cw2));
+  store_row_wave(M, stage, P.q + cw2 * D, cl, D, nvalid, q);
+  store_row_wave(M, stage, P.grad + cw2 * D, cl, D, nvalid, g);
   uint32_t* rs2 = P.rng + ((size_t)c2 * kRngSlots + slot) * 4;
   if (live) {
     rs = rs2;
@@ -382,7 +431,12 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
 
   __shared__ float s_eps[2][kMaxD];
   __shared__ float s_save[2 * ND * kBlock];
+  __shared__ __attribute__((aligned(16))) float s_stage[(kBlock / 64) * stage_floats<Lane>()];
   float* save = s_save + threadIdx.x;
+  float* stage = s_stage + (threadIdx.x >> 6) * stage_floats<Lane>();
+  const long long cw0 = ((long long)blockIdx.x * kBlock + (threadIdx.x & ~63)) / K;
+  const int cl = (threadIdx.x & 63) / K;
+  const int nvalid = (int)(P.C - cw0 < 64 / K ? (P.C - cw0 > 0 ? P.C - cw0 : 0) : 64 / K) * D;
   for (int d = threadIdx.x; d < D; d += kBlock) { s_eps[0][d] = P.eps0[d]; s_eps[1][d] = P.eps0_1[d]; }
   __syncthreads();
 
@@ -434,9 +488,10 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
 
     if (s == next_rec && rec_row < P.n_samples) {
       if (P.trace) {
-        float* row = P.trace + ((size_t)rec_row * P.C + c) * D;
+        float* wrow = P.trace + ((size_t)rec_row * P.C + cw0) * D;
         // x already holds the centred state; q the parameterisation-0 state the reference records
-        if (P.trace_centered) store_row(M, row, x, live); else store_row(M, row, q, live);
+        if (P.trace_centered) store_row_wave(M, stage, wrow, cl, D, nvalid, x);
+        else store_row_wave(M, stage, wrow, cl, D, nvalid, q);
       }
       if (live && slot == 0) {
         if (P.trace_accept) P.trace_accept[(size_t)rec_row * P.C + c] = acc0 ? 1 : 0;
@@ -449,7 +504,9 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
 
   long long c2 = c;
   asm volatile("" : "+v"(c2));
-  store_row(M, P.q + c2 * D, q, live);
+  long long cw2 = cw0;
+  asm volatile("" : "+v"(cw2));
+  store_row_wave(M, stage, P.q + cw2 * D, cl, D, nvalid, q);
   uint32_t* rs2 = P.rng + ((size_t)c2 * kRngSlots + slot) * 4;
   if (live) {
     rs = rs2;
