@@ -180,6 +180,32 @@ def main():
                  "achieved_GBps": C * T * algorithmic_bytes_per_transition(D) / (pms * 1e-3) / 1e9}
         st = st2
 
+    # ESS/sec (second half of the BASELINE metric): a separate short run with the same kernel,
+    # S recorded samples at the reference's thinning, ESS by FFT on the device trace
+    ess_info = None
+    if world == 1:
+        from autoreparam_amd import util
+        S_ess, burn = 200, 200
+        Ce = min(C, 8192)
+        st3 = engine.ChainState(q0[:Ce])
+        tr3 = torch.empty(S_ess, Ce, D, dtype=torch.float32, device=dev)
+        tot = 1 + burn + 2 * (S_ess - 1)
+        util.effective_sample_size(tr3[:, :64])          # rocFFT plan creation is not part of the figure
+        torch.cuda.synchronize(); te = time.perf_counter()
+        if inter:
+            eng.interleaved_run(st3, eps_i, eps_i, num_ls, num_ls, tot, seed=11, adapt_kind=_lib.ADAPT_SIMPLE,
+                                n_adapt=burn, n_burnin=burn, thin=2, trace=tr3, trace_centered=False, lanes=args.lanes)
+        else:
+            eng.hmc_run(st3, eps0, L, tot, seed=11, adapt_kind=_lib.ADAPT_DUAL, n_adapt=burn, n_burnin=burn, thin=2,
+                        trace=tr3, trace_centered=True, lanes=args.lanes)
+        torch.cuda.synchronize(); t_samp = time.perf_counter() - te
+        ess = util.effective_sample_size(tr3)
+        torch.cuda.synchronize(); t_all = time.perf_counter() - te
+        min_ess = ess.nan_to_num().min(dim=1).values
+        ess_info = {"chains": Ce, "samples": S_ess, "burnin": burn, "mean_min_ess_per_chain": float(min_ess.mean()),
+                    "sampling_s": t_samp, "sampling_plus_ess_s": t_all,
+                    "min_ess_per_sec_all_chains": float(min_ess.sum()) / t_all}
+
     if rank == 0:
         LL = 2 * num_ls if inter else L
         value = world * C * T * args.steps * LL / elapsed
@@ -213,7 +239,7 @@ def main():
                          "kernel": "interleaved_kernel<RadonLane,CP,NCP>" if inter else "hmc_kernel<RadonLane,CP>",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_step_per_chain": BT,
                          "algorithmic_bytes_per_launch": C * T * BT},
-            "accept_rate": accept_rate, "stats_allgather_s": t_coll, "plain_hmc": plain,
+            "accept_rate": accept_rate, "stats_allgather_s": t_coll, "plain_hmc": plain, "ess": ess_info,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -33,19 +33,21 @@ with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as f:
     w = csv.DictWriter(f, fieldnames=list(stats[0].keys()))
     w.writeheader()
     w.writerows(stats)
-dom = max(stats, key=lambda r: float(r["TotalDurationNs"]))
+ours = [r for r in stats if "arp::" in r["Name"]]
+dom = max(ours, key=lambda r: float(r["TotalDurationNs"]))
 kname = dom["Name"]
+short = kname.split("(")[0].replace("void ", "")
 
 
 def pmc(pattern, counter):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(one(pattern)))
-            if r["Counter_Name"] == counter and r["Kernel_Name"] == kname]
+            if r["Counter_Name"] == counter and short in r["Kernel_Name"]]
     return vals
 
 
 fetch = pmc("pmc_fetch/*/*_counter_collection.csv", "FETCH_SIZE")
 write = pmc("pmc_write/*/*_counter_collection.csv", "WRITE_SIZE")
-vg = [r for r in csv.DictReader(open(one("trace/*/*_kernel_trace.csv"))) if r["Kernel_Name"] == kname][0]
+vg = [r for r in csv.DictReader(open(one("trace/*/*_kernel_trace.csv"))) if short in r["Kernel_Name"]][0]
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 fk, wk = sum(fetch) / len(fetch), sum(write) / len(write)
 summary = {
