@@ -215,11 +215,10 @@ ARP_DEV float hmc_transition(const Lane& M, Rng& rng, int L, const float (&eps)[
   // globals take slot 0's draw, padding slots get none.
 #pragma unroll
   for (int i = 0; i < ND; i += 2) {
-    float z0 = 0.0f, z1 = 0.0f;
-    if (i < M.ndraw) {  // wave-uniform: slices beyond ceil(groups/K) draw nothing
-      uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
-      normal_pair(w0, w1, z0, z1);
-    }
+    // every slot draws ND = NG + ceil(groups / K) normals (the host picks NL == ceil(groups / K))
+    float z0, z1;
+    uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
+    normal_pair(w0, w1, z0, z1);
     p[i] = z0;
     if (i + 1 < ND) p[i + 1] = z1;
   }
@@ -605,11 +604,9 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
       float eps[ND], z[ND], g[ND];
 #pragma unroll
       for (int i = 0; i < ND; i += 2) {
-        float z0 = 0.f, z1 = 0.f;
-        if (i < M.ndraw) {
-          uint32_t w0 = rng_next(rng[0]), w1 = rng_next(rng[0]);
-          normal_pair(w0, w1, z0, z1);
-        }
+        float z0, z1;
+        uint32_t w0 = rng_next(rng[0]), w1 = rng_next(rng[0]);
+        normal_pair(w0, w1, z0, z1);
         eps[i] = z0;
         if (i + 1 < ND) eps[i + 1] = z1;
       }
