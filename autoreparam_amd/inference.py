@@ -118,6 +118,101 @@ class _LazyOriginalStates(object):
         return len(self._args[1].part_names)
 
 
+
+class StreamingStats(object):
+    """Statistics of a trace that is produced chunk by chunk (and then discarded):
+    running first/second moments per (chain, element) and means of consecutive
+    batches of `batch` samples, from which ESS is estimated by batch means,
+    ESS = S * var / (batch * var(batch means)).  Used when the reference's
+    [S, C, D] trace (inference.py:228-240 keeps it whole) does not fit in HBM."""
+
+    def __init__(self, C, D, batch, device):
+        self.batch = int(batch)
+        self.n = 0
+        self.s1 = torch.zeros(C, D, dtype=torch.float64, device=device)
+        self.s2 = torch.zeros(C, D, dtype=torch.float64, device=device)
+        self.bmeans = []
+        self._carry = None
+
+    def update(self, chunk):
+        x = chunk.to(torch.float64)
+        self.n += x.shape[0]
+        self.s1 += x.sum(dim=0)
+        self.s2 += (x * x).sum(dim=0)
+        if self._carry is not None:
+            x = torch.cat([self._carry, x], dim=0)
+        nb = x.shape[0] // self.batch
+        if nb:
+            self.bmeans.append(x[: nb * self.batch].reshape(nb, self.batch, *x.shape[1:]).mean(dim=1).to(torch.float32))
+        self._carry = x[nb * self.batch:] if x.shape[0] > nb * self.batch else None
+
+    def mean(self):
+        return self.s1 / self.n
+
+    def var(self):
+        m = self.mean()
+        return (self.s2 / self.n - m * m).clamp_min(0) * (self.n / max(self.n - 1, 1))
+
+    def ess(self):
+        bm = torch.cat(self.bmeans, dim=0).to(torch.float64)
+        if bm.shape[0] < 2:
+            raise ValueError("batch-means ESS needs at least two complete batches")
+        vb = bm.var(dim=0, unbiased=True)
+        ess = self.n * self.var() / (self.batch * vb)
+        return torch.minimum(ess, torch.full_like(ess, float(self.n))).to(torch.float32)
+
+
+def _trace_plan(S, C, D, dev, force_chunk=None):
+    """(rows per chunk, streaming?) -- the whole trace if it fits in 60 % of the free HBM."""
+    free, _ = torch.cuda.mem_get_info(dev)
+    row = 4.0 * C * D + C
+    if force_chunk:
+        return int(force_chunk), True
+    if S * row <= 0.6 * free:
+        return S, False
+    rows = int(0.25 * free // row)
+    if rows < 64:
+        raise MemoryError("not even 64 trace rows of [C=%d, D=%d] fit in HBM" % (C, D))
+    return min(rows, S), True
+
+
+def _sample(run_segment, st, S, B, thin, C, D, dev, keep_chains, n_acc, chunk_rows=None):
+    """Drive `run_segment(n_steps, n_burnin, trace, accept_buffers)` over the whole
+    sample_chain schedule (result r after transition 1 + B + r*thin), whole-trace or
+    chunked.  Returns (trace or None, kept host trace, accept arrays, ess [C, D], estimator)."""
+    rows, streaming = _trace_plan(S, C, D, dev, chunk_rows)
+    trace = torch.empty(rows, C, D, dtype=torch.float32, device=dev)
+    accs = [torch.empty(rows, C, dtype=torch.uint8, device=dev) for _ in range(n_acc)]
+    if not streaming:
+        total = 1 + B + thin * (S - 1)
+        done = 0
+        while done < total:
+            n = min(_MAX_STEPS_PER_LAUNCH, total - done)
+            run_segment(n, B, trace, accs)
+            done += n
+        ess = util.effective_sample_size(trace)
+        return trace, None, [a.cpu().numpy().astype(bool) for a in accs], ess, "fft"
+    batch = max(8, min(rows, S) // 8)
+    stats = StreamingStats(C, D, batch, dev)
+    kept = np.empty((S, keep_chains, D), np.float32)
+    acc_counts = [torch.zeros(C, dtype=torch.int64, device=dev) for _ in range(n_acc)]
+    r0 = 0
+    while r0 < S:
+        nr = min(rows, S - r0)
+        last = 1 + B + thin * (r0 + nr - 1)           # transition index of the chunk's last sample
+        while st.step < last:
+            n = min(_MAX_STEPS_PER_LAUNCH, last - st.step)
+            # shifting the burn-in makes row 0 of the buffer the chunk's first sample
+            run_segment(n, B + thin * r0, trace[:nr], [a[:nr] for a in accs])
+        stats.update(trace[:nr])
+        kept[r0:r0 + nr] = trace[:nr, :keep_chains].cpu().numpy()
+        for k in range(n_acc):
+            acc_counts[k] += accs[k][:nr].sum(dim=0, dtype=torch.int64)
+        r0 += nr
+    ess = stats.ess()
+    return None, kept, [a.cpu().numpy()[np.newaxis, :] for a in acc_counts], ess, "batch_means(%d)" % batch
+
+
 def _check_trace_fits(S, C, D, dev):
     need = 4.0 * S * C * D
     free, _ = torch.cuda.mem_get_info(dev)
@@ -144,26 +239,30 @@ def hmc(target, model_config, step_size_init, initial_states, reparam, flags=FLA
     S, B = int(flags.num_samples), int(flags.num_burnin_steps)
     eps0 = _flat_step(spec, step_size_init, L)
     thin = 2                                      # num_steps_between_results=1 (inference.py:234)
-    total = 1 + B + thin * (S - 1)
-    _check_trace_fits(S, C, spec.D, dev)
-    trace = torch.empty(S, C, spec.D, dtype=torch.float32, device=dev)
-    tacc = torch.empty(S, C, dtype=torch.uint8, device=dev)
     st = _engine.ChainState(q0)
-    done = 0
-    while done < total:
-        n = min(_MAX_STEPS_PER_LAUNCH, total - done)
+
+    def run_segment(n, n_burnin, trace, accs):
         eng.hmc_run(st, eps0, L, n, which=0, seed=flags.seed, chain_offset=chain_offset,
                     adapt_kind=_lib.ADAPT_DUAL, n_adapt=int(flags.num_adaptation_steps), adapt_target=0.75,
-                    n_burnin=B, thin=thin, trace=trace, trace_accept=tacc, trace_centered=True,
+                    n_burnin=n_burnin, thin=thin, trace=trace, trace_accept=accs[0], trace_centered=True,
                     lanes=flags.lanes_per_chain)
-        done += n
-    ess_flat = util.effective_sample_size(trace)
+
+    keep = max(1, int(flags.num_chains_to_save))
+    trace, kept, accs, ess_flat, estimator = _sample(run_segment, st, S, B, thin, C, spec.D, dev, min(keep, C), 1,
+                                                    getattr(flags, "trace_chunk_rows", None))
     torch.cuda.synchronize(dev)
-    states_transformed = spec.unpack(trace.cpu().numpy())
     ess = spec.unpack(ess_flat.cpu().numpy())
     step_mult = st.adapt[:, 0].cpu().numpy()
-    kernel_results = KernelResults(HmcInnerResults(tacc.cpu().numpy().astype(bool)), step_mult, st.step)
-    states_orig = _LazyOriginalStates(eng, spec, trace, 0)
+    kernel_results = KernelResults(HmcInnerResults(accs[0]), step_mult, st.step)
+    if trace is not None:
+        states_transformed = spec.unpack(trace.cpu().numpy())
+        states_orig = _LazyOriginalStates(eng, spec, trace, 0)
+    else:
+        # streaming run: only the first `num_chains_to_save` chains keep their trace, is_accepted
+        # holds per-chain counts ([1, C]; np.sum is unchanged) and ESS comes from batch means
+        states_transformed = spec.unpack(kept)
+        states_orig = None
+    hmc.last_ess_estimator = estimator
     return states_orig, kernel_results, states_transformed, ess
 
 
@@ -184,26 +283,23 @@ def hmc_interleaved(model_config, target_cp, target_ncp, num_leapfrog_steps_cp, 
     e_cp = _flat_step(spec, step_size_cp, num_leapfrog_steps_cp)
     e_ncp = _flat_step(spec, step_size_ncp, num_leapfrog_steps_ncp)
     thin = 2
-    total = 1 + B + thin * (S - 1)
-    _check_trace_fits(S, C, spec.D, dev)
-    trace = torch.empty(S, C, spec.D, dtype=torch.float32, device=dev)
-    t0 = torch.empty(S, C, dtype=torch.uint8, device=dev)
-    t1 = torch.empty(S, C, dtype=torch.uint8, device=dev)
     st = _engine.ChainState(q0)
-    done = 0
-    while done < total:
-        n = min(_MAX_STEPS_PER_LAUNCH, total - done)
+
+    def run_segment(n, n_burnin, trace, accs):
         eng.interleaved_run(st, e_cp, e_ncp, int(num_leapfrog_steps_cp), int(num_leapfrog_steps_ncp), n,
                             seed=flags.seed, chain_offset=chain_offset, adapt_kind=_lib.ADAPT_SIMPLE,
                             n_adapt=int(flags.num_adaptation_steps), adapt_target=0.75, adapt_rate=0.05,
-                            n_burnin=B, thin=thin, trace=trace, trace_accept0=t0, trace_accept1=t1,
+                            n_burnin=n_burnin, thin=thin, trace=trace, trace_accept0=accs[0], trace_accept1=accs[1],
                             trace_centered=False, lanes=flags.lanes_per_chain)
-        done += n
-    ess_flat = util.effective_sample_size(trace)
+
+    keep = max(1, int(flags.num_chains_to_save))
+    trace, kept, accs, ess_flat, estimator = _sample(run_segment, st, S, B, thin, C, spec.D, dev, min(keep, C), 2,
+                                                    getattr(flags, "trace_chunk_rows", None))
     torch.cuda.synchronize(dev)
-    states = spec.unpack(trace.cpu().numpy())
+    states = spec.unpack(trace.cpu().numpy() if trace is not None else kept)
     ess = spec.unpack(ess_flat.cpu().numpy())
     kr = InterleavedKernelResults(
-        cp_results=KernelResults(HmcInnerResults(t0.cpu().numpy().astype(bool)), st.adapt[:, 0].cpu().numpy(), st.step),
-        ncp_results=KernelResults(HmcInnerResults(t1.cpu().numpy().astype(bool)), st.adapt1[:, 0].cpu().numpy(), st.step))
+        cp_results=KernelResults(HmcInnerResults(accs[0]), st.adapt[:, 0].cpu().numpy(), st.step),
+        ncp_results=KernelResults(HmcInnerResults(accs[1]), st.adapt1[:, 0].cpu().numpy(), st.step))
+    hmc_interleaved.last_ess_estimator = estimator
     return states, kr, ess

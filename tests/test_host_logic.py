@@ -95,3 +95,22 @@ def test_save_hmc_results_appends(tmp_path):
     r = json.load(open(p))
     assert r["elbo"] == 1.0 and len(r["tuning_runs"]) == 2 and r["ess_min"] == [2.0]
     assert cli.get_best_num_leapfrog_steps_from_tuning_runs(r["tuning_runs"]) == 8
+
+
+def test_streaming_stats_match_whole_trace():
+    """Chunked moments are exact; batch-means ESS agrees with the FFT estimator on AR(1)."""
+    from autoreparam_amd.inference import StreamingStats
+    torch.manual_seed(1)
+    S, C, D, rho = 6000, 40, 3, 0.6
+    x = torch.randn(S, C, D)
+    for t in range(1, S):
+        x[t] = rho * x[t - 1] + (1 - rho ** 2) ** 0.5 * x[t]
+    st = StreamingStats(C, D, batch=150, device="cpu")
+    for lo in range(0, S, 700):                 # ragged chunks: batches straddle chunk boundaries
+        st.update(x[lo:lo + 700])
+    assert st.n == S
+    assert torch.allclose(st.mean(), x.double().mean(0), atol=1e-10)
+    assert torch.allclose(st.var(), x.double().var(0, unbiased=True), rtol=1e-9)
+    e_bm = st.ess().mean().item() / S
+    e_fft = (util.effective_sample_size(x) / S).mean().item()
+    assert abs(e_bm - (1 - rho) / (1 + rho)) < 0.04 and abs(e_bm - e_fft) < 0.04
