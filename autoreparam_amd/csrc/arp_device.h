@@ -30,6 +30,15 @@ ARP_DEV float group_sum(float v) {
   return v;
 }
 
+template <int K>
+ARP_DEV float group_max(float v) {
+  if (K >= 2) v = fmaxf(v, dpp_mov<0xB1>(v));
+  if (K >= 4) v = fmaxf(v, dpp_mov<0x4E>(v));
+  if (K >= 8) v = fmaxf(v, dpp_mov<0x141>(v));
+  if (K >= 16) v = fmaxf(v, dpp_mov<0x140>(v));
+  return v;
+}
+
 // Value held by slot 0 of the chain, broadcast to all of its K lanes.
 template <int K>
 ARP_DEV float group_bcast0(float v, int slot) {

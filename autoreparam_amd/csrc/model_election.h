@@ -37,12 +37,13 @@ struct ElectionLane {
   ARP_DEV bool lvalid(int i) const { return i < NL - 1 ? true : last_ok; }
   bool last_ok;
   static constexpr bool HAS_MODES = false;
-  static constexpr bool HAS_FUSED = false;
+  static constexpr bool HAS_FUSED = true;    // kick_drift below
   static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
   using Args = ElectionArgs;
 
   float cn[NL][4], cy[NL][4], al[NL], be[NL], lat[NL];
   float si[4], cs[4];   // 1/s^b and s^(1-b) for mua, lsa, b1, b2
+  float bbar; bool buni; // every state shares one b (always so for CP, NCP and the reference's tied cVIP/dVIP)
   int nloc, slot, ndraw, S;
 
   // flattened index of replicated global i (b1 -> 2+S, b2 -> 3+S: S is a run-time value)
@@ -79,11 +80,62 @@ struct ElectionLane {
       si[i] = __builtin_amdgcn_exp2f(-bv[gmap[i]] * lg[i]);
       cs[i] = sc[i] * si[i];
     }
+    bbar = bv[LBASE + slot];     // slice 0 is a latent in every lane
+    float lo = bbar, hi = bbar;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       bool has = lvalid(i);
       al[i] = has ? av[LBASE + slot + K * i] : 0.0f;
       be[i] = has ? bv[LBASE + slot + K * i] : 0.0f;
+      lo = has ? fminf(lo, be[i]) : lo;
+      hi = has ? fmaxf(hi, be[i]) : hi;
+    }
+    buni = group_max<K>(hi) == -group_max<K>(-lo);
+  }
+
+  // Interior leapfrog step in one pass (kernels.h: lane_kick_drift).  The four cells of a
+  // state share exp(-a_t): exp(-eta) = exp(-a_t) {1, e^-b2, e^-b1, e^-b1-b2}, so a state costs
+  // one exp and four reciprocals instead of four of each, and with a shared b the prior's
+  // exp(-b lsa) is formed once per gradient.  (The closing gradient of a transition, which
+  // also needs the log density, uses the overflow-proof form in grad<>.)
+  template <int MODE>
+  ARP_DEV void kick_drift(float (&q)[ND], float (&p)[ND], const float (&eps)[ND]) const {
+    const float mua = cs[0] * q[0], ls = cs[1] * q[1], b1 = cs[2] * q[2], b2 = cs[3] * q[3];
+    const float sig = fast_exp(ls);
+    const float E1 = fast_exp(-b1), E2 = fast_exp(-b2), E12 = E1 * E2;
+    const float eu = fast_exp(-bbar * ls);
+    float g_mua = 0.0f, g_ls = 0.0f, g_b1 = 0.0f, g_b2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const float qt = q[NG + i];
+      const float e = buni ? eu : fast_exp(-be[i] * ls);
+      const float z = (qt - al[i] * mua) * e;
+      const float as = lat[i] * fmaf(sig, z, mua);
+      const float t = fast_exp(-as);
+      const float w0 = fmaf(-cn[i][0], __builtin_amdgcn_rcpf(1.0f + t), cy[i][0]);
+      const float w1 = fmaf(-cn[i][1], __builtin_amdgcn_rcpf(fmaf(t, E2, 1.0f)), cy[i][1]);
+      const float w2 = fmaf(-cn[i][2], __builtin_amdgcn_rcpf(fmaf(t, E1, 1.0f)), cy[i][2]);
+      const float w3 = fmaf(-cn[i][3], __builtin_amdgcn_rcpf(fmaf(t, E12, 1.0f)), cy[i][3]);
+      const float W = (w0 + w1) + (w2 + w3);
+      g_b2 += w1 + w3;
+      g_b1 += w2 + w3;
+      const float gt = lat[i] * e * fmaf(sig, W, -z);
+      g_mua += lat[i] * fmaf(-al[i], gt, W);
+      g_ls += fmaf(be[i], fmaf(z, z, -1.0f), lat[i] * W * sig * z * (1.0f - be[i]));
+      const float pn = fmaf(eps[NG + i], gt, p[NG + i]);
+      p[NG + i] = pn;
+      q[NG + i] = fmaf(eps[NG + i], pn, qt);
+    }
+    g_mua = group_sum<K>(g_mua);
+    g_ls = group_sum<K>(g_ls);
+    g_b1 = group_sum<K>(g_b1);
+    g_b2 = group_sum<K>(g_b2);
+    const float gs[4] = {g_mua, g_ls, g_b1, g_b2};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float gi = fmaf(cs[i], gs[i], -(q[i] * si[i]) * si[i]);
+      p[i] = fmaf(eps[i], gi, p[i]);
+      q[i] = fmaf(eps[i], p[i], q[i]);
     }
   }
 
