@@ -1,0 +1,93 @@
+"""GPU: edge cases of the C ABI -- empty / tiny / ragged batches, zero-step calls,
+non-finite proposals, bad arguments, the largest BASELINE chain count."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _eng(mname, gpu):
+    from autoreparam_amd import engine
+    return engine.Engine(helpers.spec(mname), gpu)
+
+
+def test_bad_arguments_raise(gpu):
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec("radon_MN")
+    eng = _eng("radon_MN", gpu)
+    x0 = torch.zeros(0, sp.D, device=gpu)
+    with pytest.raises(RuntimeError):
+        eng.logp_grad(x0)                               # empty batch
+    st = engine.ChainState(torch.zeros(4, sp.D, device=gpu))
+    eps = np.full(sp.D, 0.1, np.float32)
+    with pytest.raises(RuntimeError):
+        eng.hmc_run(st, eps, 0, 1)                      # zero leapfrog steps
+    with pytest.raises(RuntimeError):
+        eng.hmc_run(st, eps, 2, 1, thin=0)
+    with pytest.raises(RuntimeError):
+        eng.hmc_run(st, eps, 2, 1, adapt_kind=7)
+    with pytest.raises(RuntimeError):
+        eng.hmc_run(st, eps, 2, 1, lanes=3)
+    eng.hmc_run(st, eps, 2, 0)                          # zero transitions: a no-op
+    assert st.step == 0 and torch.equal(st.q, torch.zeros_like(st.q))
+
+
+@pytest.mark.parametrize("mname", ["8schools", "radon_PA", "election", "german"])
+def test_single_chain_and_ragged_tail(oracle_lib, gpu, mname):
+    """C = 1 and C = 67 (neither a multiple of the chains per wave) run and agree with the oracle."""
+    from autoreparam_amd import engine
+    sp = helpers.spec(mname)
+    eng = _eng(mname, gpu)
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "NCP")
+    eng.set_param(0, (a, b))
+    eps = np.full(sp.D, 1e-3, np.float32)
+    lanes = {"8schools": 8, "radon_PA": 8, "election": 16, "german": 16}[mname]
+    for Cn in (1, 67):
+        q0 = helpers.states(sp, Cn, seed=Cn, scale=0.05)
+        st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+        tr = torch.full((2, Cn, sp.D), 7.0, device=gpu)
+        eng.hmc_run(st, eps, 2, 3, seed=3, n_burnin=0, thin=2, trace=tr, lanes=lanes)
+        so = oracle_lib.new_state(q0, np.float32)
+        tro = np.zeros((2, Cn, sp.D), np.float32)
+        orc.hmc_run(so, a, b, eps, 2, 3, seed=3, n_burnin=0, thin=2, trace=tro, lanes=lanes)
+        scale = np.abs(so["q"]).max() + 1
+        assert np.abs(st.q.cpu().numpy() - so["q"]).max() <= 1e-4 * scale
+        assert np.abs(tr.cpu().numpy() - tro).max() <= 1e-4 * scale      # every row written, nothing else
+
+
+def test_non_finite_proposals_are_rejected(gpu):
+    """inference.py:323-324: numerical failure becomes NaN -> the proposal is rejected."""
+    from autoreparam_amd import engine
+    sp = helpers.spec("8schools")
+    eng = _eng("8schools", gpu)
+    eng.set_param(0, "CP")
+    q0 = helpers.states(sp, 256, seed=1)
+    st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+    eng.hmc_run(st, np.full(sp.D, 80.0, np.float32), 4, 6, seed=2)   # exp(log_tau) overflows on the way
+    assert torch.isfinite(st.q).all() and torch.isfinite(st.logp).all()
+    assert (st.accept_count <= 6).all()
+    # most proposals blow up, so most chains never move
+    assert (st.q.cpu().numpy() == q0).all(axis=1).mean() > 0.5
+
+
+def test_election_at_config5_size(gpu):
+    """BASELINE config 5 shape: election, 131 072 chains (VIP parameterisation), finite and mixing."""
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec("election")
+    eng = _eng("election", gpu)
+    a = np.full(sp.D, 0.5, np.float32); b = np.ones(sp.D, np.float32)   # the reference's tied cVIP: b = 1
+    eng.set_param(0, (a, b))
+    Cn = 131072
+    q0 = helpers.states(sp, Cn, seed=3, scale=0.05)
+    st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+    eps = np.full(sp.D, 0.01, np.float32); eps[[0, 1, 53, 54]] = 1e-3
+    eng.hmc_run(st, eps, 8, 60, seed=5, adapt_kind=_lib.ADAPT_DUAL, n_adapt=50)
+    assert torch.isfinite(st.q).all()
+    acc = st.accept_count.double().mean().item() / st.step
+    assert 0.4 < acc < 0.98
