@@ -114,3 +114,22 @@ def test_streaming_stats_match_whole_trace():
     e_bm = st.ess().mean().item() / S
     e_fft = (util.effective_sample_size(x) / S).mean().item()
     assert abs(e_bm - (1 - rho) / (1 + rho)) < 0.04 and abs(e_bm - e_fft) < 0.04
+
+
+def test_analyze_reports(tmp_path):
+    from autoreparam_amd import analyze
+    d = os.path.join(str(tmp_path), "radon_MN"); os.makedirs(d)
+    json.dump({"elbo": -1164.4, "estimated_elbo_std": 0.31, "variational_fit_time_secs": 2.0,
+               "tuning_runs": [{"num_leapfrog_steps": 4, "ess_min": 1.0}, {"num_leapfrog_steps": 8, "ess_min": 2.0}],
+               "ess_min": [3.5], "sem_min": [0.1], "mcmc_time_sec": [1.5]}, open(os.path.join(d, "CP_tied.json"), "w"))
+    json.dump({"elbo": -1170.0, "estimated_elbo_std": 0.5, "learned_reparam": {"m_a": [0.2, 0.9]}},
+              open(os.path.join(d, "cVIP_eig_tied.json"), "w"))
+    json.dump({"num_leapfrog_steps": [4], "ess_min": [5.0], "sem_min": [0.2], "mcmc_time_sec": [2.0]},
+              open(os.path.join(d, "i_tied.json"), "w"))
+    res = analyze.load(str(tmp_path), "radon_MN")
+    assert analyze.leapfrog_steps(res["CP_tied"]) == 8 and analyze.leapfrog_steps(res["i_tied"]) == 4
+    assert any("-1164.4000 +/- 0.31" in l for l in analyze.report_elbos(res))
+    assert any("m_a" in l for l in analyze.report_reparams(res))
+    lines = analyze.report_ess(res, normalize_times=True)
+    assert len(lines) == 2 and "8 leapfrog steps" in lines[0]
+    analyze.main(["--results_dir", str(tmp_path), "--elbos", "--ess", "--reparams"])
