@@ -48,7 +48,10 @@ struct RadonLane {
 
   static constexpr int LBASE = 3; // flattened index of m_0 (parts: mua, b1, b2, m[J])
 
-  float n[NL], sx[NL], sy[NL], u[NL], a[NL];
+  // tables are held as register pairs so that the packed (v_pk_*_f32) leapfrog pass can use
+  // them without shuffles; scalar code reads element i as T[i >> 1][i & 1] (a sub-register)
+  static constexpr int NP = (NL + 1) / 2;
+  v2f n2[NP], sx2[NP], sy2[NP], u2[NP], a2[NP];
   float sxy, sxx;
   int nloc, slot;                // nloc: slices of this lane that map to a real county
   int ndraw;                     // NG + ceil(J/K): normals every RNG slot draws per transition
@@ -68,17 +71,17 @@ struct RadonLane {
     for (int i = 0; i < NL; ++i) {
       int j = slot + K * i;
       bool ok = j < J;
-      n[i] = ok ? A.n[j] : 0.0f;
-      sx[i] = ok ? A.sx[j] : 0.0f;
-      sy[i] = ok ? A.sy[j] : 0.0f;
-      u[i] = ok ? A.u[j] : 0.0f;
+      n2[i >> 1][i & 1] = ok ? A.n[j] : 0.0f;
+      sx2[i >> 1][i & 1] = ok ? A.sx[j] : 0.0f;
+      sy2[i >> 1][i & 1] = ok ? A.sy[j] : 0.0f;
+      u2[i >> 1][i & 1] = ok ? A.u[j] : 0.0f;
     }
     set_param(av, bv);
   }
   // (re)load the parameterisation-dependent slice (the interleaved kernel switches it twice per step)
   ARP_DEV void set_param(const float* av, const float* /*bv*/) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) a[i] = lvalid(i) ? av[LBASE + slot + K * i] : 0.0f;
+    for (int i = 0; i < NL; ++i) a2[i >> 1][i & 1] = lvalid(i) ? av[LBASE + slot + K * i] : 0.0f;
   }
 
   // Gradient of the log joint at q (and the log joint itself, additive
@@ -90,20 +93,20 @@ struct RadonLane {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       float mt = q[NG + i];
-      float mu = fmaf(u[i], b1, mua);
-      float r = fmaf(-a[i], mu, mt);
+      float mu = fmaf(u2[i >> 1][i & 1], b1, mua);
+      float r = fmaf(-a2[i >> 1][i & 1], mu, mt);
       float m = r + mu;
-      float t = fmaf(-b2, sx[i], sy[i]);
-      float l = fmaf(-n[i], m, t);
+      float t = fmaf(-b2, sx2[i >> 1][i & 1], sy2[i >> 1][i & 1]);
+      float l = fmaf(-n2[i >> 1][i & 1], m, t);
       float gm = l - r;
       g[NG + i] = gm;
-      float h = fmaf(-a[i], gm, l);
+      float h = fmaf(-a2[i >> 1][i & 1], gm, l);
       acc_h += h;
-      acc_uh = fmaf(u[i], h, acc_uh);
-      acc_ms = fmaf(m, sx[i], acc_ms);
+      acc_uh = fmaf(u2[i >> 1][i & 1], h, acc_uh);
+      acc_ms = fmaf(m, sx2[i >> 1][i & 1], acc_ms);
       if (LOGP) {
         lp = fmaf(-0.5f * r, r, lp);
-        lp = fmaf(-0.5f * m, fmaf(n[i], m, -2.0f * t), lp);
+        lp = fmaf(-0.5f * m, fmaf(n2[i >> 1][i & 1], m, -2.0f * t), lp);
       }
     }
     acc_h = group_sum<K>(acc_h);
@@ -131,8 +134,8 @@ struct RadonLane {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const float mt = q[NG + i];
-      const float mu = fmaf(u[i], b1, mua);
-      const float t = fmaf(-b2, sx[i], sy[i]);
+      const float mu = fmaf(u2[i >> 1][i & 1], b1, mua);
+      const float t = fmaf(-b2, sx2[i >> 1][i & 1], sy2[i >> 1][i & 1]);
       float r, m, h;
       if (MODE == 1) {
         r = mt - mu;
@@ -142,15 +145,15 @@ struct RadonLane {
         r = mt;
         m = mt + mu;
       }
-      const float l = fmaf(-n[i], m, t);
+      const float l = fmaf(-n2[i >> 1][i & 1], m, t);
       g[NG + i] = l - r;
       h = (MODE == 1) ? r : l;
       acc_h += h;
-      acc_uh = fmaf(u[i], h, acc_uh);
-      acc_ms = fmaf(m, sx[i], acc_ms);
+      acc_uh = fmaf(u2[i >> 1][i & 1], h, acc_uh);
+      acc_ms = fmaf(m, sx2[i >> 1][i & 1], acc_ms);
       if (LOGP) {
         lp = fmaf(-0.5f * r, r, lp);
-        lp = fmaf(-0.5f * m, fmaf(n[i], m, -2.0f * t), lp);
+        lp = fmaf(-0.5f * m, fmaf(n2[i >> 1][i & 1], m, -2.0f * t), lp);
       }
     }
     acc_h = group_sum<K>(acc_h);
@@ -171,38 +174,64 @@ struct RadonLane {
   template <int MODE>
   ARP_DEV void kick_drift(float (&q)[ND], float (&p)[ND], const float (&eps)[ND]) const {
     const float mua = q[0], b1 = q[1], b2 = q[2];
-    float acc_h = 0.0f, acc_uh = 0.0f, acc_ms = 0.0f;
+    const v2f vmua = {mua, mua}, vb1 = {b1, b1}, vnb2 = {-b2, -b2};
+    v2f acc_h = {0.0f, 0.0f}, acc_uh = {0.0f, 0.0f}, acc_ms = {0.0f, 0.0f};
+    // counties in pairs: every operation below is one v_pk_fma_f32 / v_pk_add_f32 on a register pair
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const float mt = q[NG + i];
-      const float mu = fmaf(u[i], b1, mua);
-      const float t = fmaf(-b2, sx[i], sy[i]);
-      float r, m, h;
+    for (int k = 0; k < NL / 2; ++k) {
+      const int i = 2 * k;
+      const v2f mt = {q[NG + i], q[NG + i + 1]};
+      const v2f ev = {eps[NG + i], eps[NG + i + 1]};
+      const v2f pv = {p[NG + i], p[NG + i + 1]};
+      const v2f mu = vfma(u2[k], vb1, vmua);
+      const v2f t = vfma(vnb2, sx2[k], sy2[k]);
+      v2f r, m, h;
       if (MODE == 1) {
         r = mt - mu;
-        if (i == NL - 1) r = last_ok ? r : 0.0f;
+        if (i + 1 == NL - 1) r[1] = last_ok ? r[1] : 0.0f;
         m = mt;
       } else if (MODE == 2) {
         r = mt;
         m = mt + mu;
       } else {
-        r = fmaf(-a[i], mu, mt);
+        r = vfma(-a2[k], mu, mt);
         m = r + mu;
       }
-      const float l = fmaf(-n[i], m, t);
-      const float gm = l - r;
-      h = (MODE == 1) ? r : ((MODE == 2) ? l : fmaf(-a[i], gm, l));
+      const v2f l = vfma(-n2[k], m, t);
+      const v2f gm = l - r;
+      h = (MODE == 1) ? r : ((MODE == 2) ? l : vfma(-a2[k], gm, l));
       acc_h += h;
-      acc_uh = fmaf(u[i], h, acc_uh);
-      acc_ms = fmaf(m, sx[i], acc_ms);
+      acc_uh = vfma(u2[k], h, acc_uh);
+      acc_ms = vfma(m, sx2[k], acc_ms);
+      const v2f pn = vfma(ev, gm, pv);
+      const v2f qn = vfma(ev, pn, mt);
+      p[NG + i] = pn[0]; p[NG + i + 1] = pn[1];
+      q[NG + i] = qn[0]; q[NG + i + 1] = qn[1];
+    }
+    float s_h = acc_h[0] + acc_h[1], s_uh = acc_uh[0] + acc_uh[1], s_ms = acc_ms[0] + acc_ms[1];
+    if (NL & 1) {   // odd slice count: the last county on its own
+      constexpr int i = NL - 1;
+      const float mt = q[NG + i];
+      const float mu = fmaf(u2[i >> 1][0], b1, mua);
+      const float t = fmaf(-b2, sx2[i >> 1][0], sy2[i >> 1][0]);
+      float r, m, h;
+      if (MODE == 1) { r = last_ok ? mt - mu : 0.0f; m = mt; }
+      else if (MODE == 2) { r = mt; m = mt + mu; }
+      else { r = fmaf(-a2[i >> 1][0], mu, mt); m = r + mu; }
+      const float l = fmaf(-n2[i >> 1][0], m, t);
+      const float gm = l - r;
+      h = (MODE == 1) ? r : ((MODE == 2) ? l : fmaf(-a2[i >> 1][0], gm, l));
+      s_h += h;
+      s_uh = fmaf(u2[i >> 1][0], h, s_uh);
+      s_ms = fmaf(m, sx2[i >> 1][0], s_ms);
       const float pn = fmaf(eps[NG + i], gm, p[NG + i]);
       p[NG + i] = pn;
       q[NG + i] = fmaf(eps[NG + i], pn, mt);
     }
-    acc_h = group_sum<K>(acc_h);
-    acc_uh = group_sum<K>(acc_uh);
-    acc_ms = group_sum<K>(acc_ms);
-    const float g0 = acc_h - mua, g1 = acc_uh - b1, g2 = fmaf(-b2, sxx, sxy) - acc_ms - b2;
+    s_h = group_sum<K>(s_h);
+    s_uh = group_sum<K>(s_uh);
+    s_ms = group_sum<K>(s_ms);
+    const float g0 = s_h - mua, g1 = s_uh - b1, g2 = fmaf(-b2, sxx, sxy) - s_ms - b2;
     p[0] = fmaf(eps[0], g0, p[0]); q[0] = fmaf(eps[0], p[0], mua);
     p[1] = fmaf(eps[1], g1, p[1]); q[1] = fmaf(eps[1], p[1], b1);
     p[2] = fmaf(eps[2], g2, p[2]); q[2] = fmaf(eps[2], p[2], b2);
@@ -214,7 +243,7 @@ struct RadonLane {
     for (int i = 0; i < ND; ++i) x[i] = q[i];
     if (MODE == 2) {
 #pragma unroll
-      for (int i = 0; i < NL; ++i) x[NG + i] = q[NG + i] + fmaf(u[i], q[1], q[0]);
+      for (int i = 0; i < NL; ++i) x[NG + i] = q[NG + i] + fmaf(u2[i >> 1][i & 1], q[1], q[0]);
     }
   }
   template <int MODE>
@@ -223,7 +252,7 @@ struct RadonLane {
     for (int i = 0; i < ND; ++i) q[i] = x[i];
     if (MODE == 2) {
 #pragma unroll
-      for (int i = 0; i < NL; ++i) q[NG + i] = lvalid(i) ? x[NG + i] - fmaf(u[i], x[1], x[0]) : 0.0f;
+      for (int i = 0; i < NL; ++i) q[NG + i] = lvalid(i) ? x[NG + i] - fmaf(u2[i >> 1][i & 1], x[1], x[0]) : 0.0f;
     } else {
 #pragma unroll
       for (int i = 0; i < NL; ++i) q[NG + i] = lvalid(i) ? x[NG + i] : 0.0f;
@@ -236,7 +265,7 @@ struct RadonLane {
 #pragma unroll
     for (int i = 0; i < ND; ++i) { da[i] = 0.0f; db[i] = 0.0f; }
 #pragma unroll
-    for (int i = 0; i < NL; ++i) da[NG + i] = -fmaf(u[i], q[1], q[0]) * g[NG + i];
+    for (int i = 0; i < NL; ++i) da[NG + i] = -fmaf(u2[i >> 1][i & 1], q[1], q[0]) * g[NG + i];
   }
 
   // reparameterised -> centred coordinates
@@ -244,8 +273,8 @@ struct RadonLane {
     x[0] = q[0]; x[1] = q[1]; x[2] = q[2];
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      float mu = fmaf(u[i], q[1], q[0]);
-      x[NG + i] = fmaf(-a[i], mu, q[NG + i]) + mu;
+      float mu = fmaf(u2[i >> 1][i & 1], q[1], q[0]);
+      x[NG + i] = fmaf(-a2[i >> 1][i & 1], mu, q[NG + i]) + mu;
     }
   }
   // centred -> reparameterised coordinates
@@ -253,9 +282,9 @@ struct RadonLane {
     q[0] = x[0]; q[1] = x[1]; q[2] = x[2];
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      float mu = fmaf(u[i], x[1], x[0]);
+      float mu = fmaf(u2[i >> 1][i & 1], x[1], x[0]);
       // mt = m - (1-a) mu ; padding slots (a = 0, x = 0 on input) must stay 0
-      q[NG + i] = lvalid(i) ? x[NG + i] - (1.0f - a[i]) * mu : 0.0f;
+      q[NG + i] = lvalid(i) ? x[NG + i] - (1.0f - a2[i >> 1][i & 1]) * mu : 0.0f;
     }
   }
 };
