@@ -130,44 +130,68 @@ struct RadonLane {
   template <bool LOGP, int MODE>
   ARP_DEV float grad_m(const float (&q)[ND], float (&g)[ND]) const {
     const float mua = q[0], b1 = q[1], b2 = q[2];
-    float acc_h = 0.0f, acc_uh = 0.0f, acc_ms = 0.0f, lp = 0.0f;
+    const v2f vmua = {mua, mua}, vb1 = {b1, b1}, vnb2 = {-b2, -b2}, mhalf = {-0.5f, -0.5f}, mtwo = {-2.0f, -2.0f};
+    v2f acc_h = {0.0f, 0.0f}, acc_uh = {0.0f, 0.0f}, acc_ms = {0.0f, 0.0f}, lpv = {0.0f, 0.0f};
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const float mt = q[NG + i];
-      const float mu = fmaf(u2[i >> 1][i & 1], b1, mua);
-      const float t = fmaf(-b2, sx2[i >> 1][i & 1], sy2[i >> 1][i & 1]);
-      float r, m, h;
+    for (int k = 0; k < NL / 2; ++k) {   // county pairs on the packed f32 pipe
+      const int i = 2 * k;
+      const v2f mt = {q[NG + i], q[NG + i + 1]};
+      const v2f mu = vfma(u2[k], vb1, vmua);
+      const v2f t = vfma(vnb2, sx2[k], sy2[k]);
+      v2f r, m;
       if (MODE == 1) {
         r = mt - mu;
-        if (i == NL - 1) r = last_ok ? r : 0.0f;
+        if (i + 1 == NL - 1) r[1] = last_ok ? r[1] : 0.0f;
         m = mt;
       } else {
         r = mt;
         m = mt + mu;
       }
-      const float l = fmaf(-n2[i >> 1][i & 1], m, t);
-      g[NG + i] = l - r;
-      h = (MODE == 1) ? r : l;
+      const v2f l = vfma(-n2[k], m, t);
+      const v2f gm = l - r;
+      g[NG + i] = gm[0]; g[NG + i + 1] = gm[1];
+      const v2f h = (MODE == 1) ? r : l;
       acc_h += h;
-      acc_uh = fmaf(u2[i >> 1][i & 1], h, acc_uh);
-      acc_ms = fmaf(m, sx2[i >> 1][i & 1], acc_ms);
+      acc_uh = vfma(u2[k], h, acc_uh);
+      acc_ms = vfma(m, sx2[k], acc_ms);
       if (LOGP) {
-        lp = fmaf(-0.5f * r, r, lp);
-        lp = fmaf(-0.5f * m, fmaf(n2[i >> 1][i & 1], m, -2.0f * t), lp);
+        lpv = vfma(mhalf * r, r, lpv);
+        lpv = vfma(mhalf * m, vfma(n2[k], m, mtwo * t), lpv);
       }
     }
-    acc_h = group_sum<K>(acc_h);
-    acc_uh = group_sum<K>(acc_uh);
-    acc_ms = group_sum<K>(acc_ms);
-    g[0] = acc_h - mua;
-    g[1] = acc_uh - b1;
-    g[2] = fmaf(-b2, sxx, sxy) - acc_ms - b2;
+    float s_h = acc_h[0] + acc_h[1], s_uh = acc_uh[0] + acc_uh[1], s_ms = acc_ms[0] + acc_ms[1];
+    float lp = lpv[0] + lpv[1];
+    if (NL & 1) {
+      constexpr int i = NL - 1;
+      const float mt = q[NG + i];
+      const float mu = fmaf(u2[i >> 1][0], b1, mua);
+      const float t = fmaf(-b2, sx2[i >> 1][0], sy2[i >> 1][0]);
+      float r, m;
+      if (MODE == 1) { r = last_ok ? mt - mu : 0.0f; m = mt; } else { r = mt; m = mt + mu; }
+      const float l = fmaf(-n2[i >> 1][0], m, t);
+      g[NG + i] = l - r;
+      const float h = (MODE == 1) ? r : l;
+      s_h += h;
+      s_uh = fmaf(u2[i >> 1][0], h, s_uh);
+      s_ms = fmaf(m, sx2[i >> 1][0], s_ms);
+      if (LOGP) {
+        lp = fmaf(-0.5f * r, r, lp);
+        lp = fmaf(-0.5f * m, fmaf(n2[i >> 1][0], m, -2.0f * t), lp);
+      }
+    }
+    s_h = group_sum<K>(s_h);
+    s_uh = group_sum<K>(s_uh);
+    s_ms = group_sum<K>(s_ms);
+    g[0] = s_h - mua;
+    g[1] = s_uh - b1;
+    g[2] = fmaf(-b2, sxx, sxy) - s_ms - b2;
     if (LOGP) {
       lp = group_sum<K>(lp);
       lp += -0.5f * (mua * mua + b1 * b1 + b2 * b2) + b2 * (sxy - 0.5f * b2 * sxx);
     }
     return lp;
   }
+
   // Interior leapfrog step in one pass (kernels.h: lane_kick_drift): for every county the
   // gradient is formed, kicked into p and the position drifted at once; the three
   // top-level scalars follow after the group sums.  MODE 0 uses the `a` table.
