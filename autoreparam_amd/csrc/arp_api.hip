@@ -46,6 +46,7 @@ static const std::vector<LaneOps>* family(const arp_model* m) {
     case ARP_MODEL_EIGHT_SCHOOLS: return &schools_ops();
     case ARP_MODEL_ELECTION: return &election_ops();
     case ARP_MODEL_GERMAN_CREDIT: return &german_ops();
+    case ARP_MODEL_RADON_STDDVS: return &radon_sd_ops();
     default: return nullptr;
   }
 }
@@ -55,6 +56,7 @@ static const void* family_args(const arp_model* m) {
     case ARP_MODEL_EIGHT_SCHOOLS: return &m->schools;
     case ARP_MODEL_ELECTION: return &m->election;
     case ARP_MODEL_GERMAN_CREDIT: return &m->german;
+    case ARP_MODEL_RADON_STDDVS: return &m->radon_sd;
     default: return nullptr;
   }
 }
@@ -154,6 +156,37 @@ static int build_election(arp_model* m, const arp_dataset* d) {
   return 0;
 }
 
+// reference models.py:763-806 (radon_stddvs): same inputs as radon; every county keeps all six
+// second-order sufficient statistics because its observation scale is a latent
+static int build_radon_sd(arp_model* m, const arp_dataset* d) {
+  const int J = d->n_groups, N = d->n_obs;
+  if (!d->group_host || !d->u_host || !d->x_host || !d->y_host || J <= 0 || N <= 0) {
+    set_error("radon_stddvs: group/u/x/y and n_groups/n_obs are required");
+    return 1;
+  }
+  std::vector<double> st(6 * (size_t)J, 0.0);
+  for (int i = 0; i < N; ++i) {
+    int j = d->group_host[i];
+    if (j < 0 || j >= J) {   // a zero one-hot row would give the observation a zero scale (models.py:785-786)
+      set_error("radon_stddvs: county index out of range");
+      return 1;
+    }
+    double x = d->x_host[i], y = d->y_host[i];
+    st[j] += 1; st[J + j] += x; st[2 * J + j] += y; st[3 * J + j] += x * x; st[4 * J + j] += x * y; st[5 * J + j] += y * y;
+  }
+  m->D = 3 + 2 * J; m->n_groups = J;
+  m->host_tables.resize(7 * (size_t)J);
+  for (size_t k = 0; k < 6 * (size_t)J; ++k) m->host_tables[k] = (float)st[k];
+  for (int j = 0; j < J; ++j) m->host_tables[6 * (size_t)J + j] = d->u_host[j];
+  if (upload_tables(m)) return 1;
+  float* t = m->dev_tables;
+  m->radon_sd.n = t; m->radon_sd.sx = t + J; m->radon_sd.sy = t + 2 * J; m->radon_sd.sxx = t + 3 * J;
+  m->radon_sd.sxy = t + 4 * J; m->radon_sd.syy = t + 5 * J; m->radon_sd.u = t + 6 * J;
+  m->radon_sd.J = J;
+  m->const_base = -(3.0 + 2.0 * J + N) * kHalfLog2Pi;
+  return 0;
+}
+
 // reference models.py:860-904: X = [N][F] design matrix (intercept, standardised
 // numerics, one-hot blocks), y = 0/1 outcomes
 static int build_german(arp_model* m, const arp_dataset* d) {
@@ -196,6 +229,7 @@ int arp_model_create(const arp_dataset* data, arp_model** out) {
     case ARP_MODEL_EIGHT_SCHOOLS: rc = build_schools(m.get(), data); break;
     case ARP_MODEL_ELECTION: rc = build_election(m.get(), data); break;
     case ARP_MODEL_GERMAN_CREDIT: rc = build_german(m.get(), data); break;
+    case ARP_MODEL_RADON_STDDVS: rc = build_radon_sd(m.get(), data); break;
     default: set_error("arp_model_create: unknown model id"); return 1;
   }
   if (rc) return rc;
@@ -284,7 +318,7 @@ static int fill_params(arp_model* m, const arp_hmc_config* cfg, const arp_hmc_io
     return 1;
   }
   if (cfg->adapt_kind < ARP_ADAPT_NONE || cfg->adapt_kind > ARP_ADAPT_SIMPLE) { set_error("bad adapt_kind"); return 1; }
-  if (m->D > kMaxD) { set_error("state dimension exceeds the chain kernels' limit (128)"); return 1; }
+  if (m->D > kMaxD) { set_error("state dimension exceeds the chain kernels' limit (256)"); return 1; }
   HmcParams& P = *Pp;
   P.C = cfg->n_chains; P.L = cfg->n_leapfrog; P.n_steps = cfg->n_steps;
   P.step_base = cfg->step_base; P.chain_offset = cfg->chain_offset; P.seed = cfg->seed;

@@ -12,6 +12,7 @@
 #include "model_schools.h"
 #include "model_election.h"
 #include "model_german.h"
+#include "model_radon_stddvs.h"
 
 namespace arp {
 
@@ -28,7 +29,7 @@ void set_error(const std::string& msg);
 
 // Launchers a model family exports for one (lanes-per-chain, slice-size) pair.
 struct LaneOps {
-  int K, NL;
+  int K, NL;   // lanes per chain; groups (counties, states, features ...) owned by one lane
   void (*logp_grad)(const void* args, const float* a, const float* b, const float* x, int C, int D,
                     float* logp, float* grad, hipStream_t s);
   void (*transform)(const void* args, const float* a, const float* b, int dir, const float* in,
@@ -82,7 +83,7 @@ struct Launch {
                        *(const typename Lane::Args*)args, a0, b0, a1, b1, P);
   }
   static LaneOps ops() {
-    LaneOps o{Lane::K, Lane::NL, &logp_grad, &transform, &hmc, &interleaved, &vi, nullptr, nullptr, nullptr};
+    LaneOps o{Lane::K, Lane::NGRP, &logp_grad, &transform, &hmc, &interleaved, &vi, nullptr, nullptr, nullptr};
     if constexpr (Lane::HAS_MODES) {
       o.hmc_cp = &hmc_m<kModeCP>;
       o.hmc_ncp = &hmc_m<kModeNCP>;
@@ -97,6 +98,7 @@ const std::vector<LaneOps>& radon_ops();
 const std::vector<LaneOps>& schools_ops();
 const std::vector<LaneOps>& election_ops();
 const std::vector<LaneOps>& german_ops();
+const std::vector<LaneOps>& radon_sd_ops();
 
 }  // namespace arp
 
@@ -114,6 +116,7 @@ struct arp_model {
   arp::SchoolsArgs schools{};
   arp::ElectionArgs election{};
   arp::GermanArgs german{};
+  arp::RadonSdArgs radon_sd{};
   std::vector<float> host_tables;
   double const_base = 0.0;                       // parameterisation independent part of the dropped constant
   std::vector<std::pair<int, double>> top_scale; // (flattened index, log prior scale) of top-level latents

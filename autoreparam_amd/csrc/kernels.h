@@ -11,7 +11,7 @@ namespace arp {
 
 constexpr int kBlock = 256;      // 4 waves per workgroup
 constexpr int kRngSlots = 16;    // rng buffer stride per chain (max lanes per chain)
-constexpr int kMaxD = 128;       // largest state dimension the chain kernels stage in LDS
+constexpr int kMaxD = 256;       // largest state dimension the chain kernels stage in LDS
 
 struct HmcParams {
   int C, L, n_steps;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
 // program_transformations.py:507-510).
 // ---------------------------------------------------------------------------
 constexpr int kViBlock = 512;
-constexpr int kViDmax = 128;
+constexpr int kViDmax = kMaxD;
 
 struct ViParams {
   int n_steps, n_mc, learn_a, tied_b, D;

@@ -27,6 +27,7 @@ struct ElectionLane {
   static constexpr int NG = 4;   // mua, lsa, b1, b2
   static constexpr int NL = NL_; // groups owned by this lane: t = slot + K*i, t <= S
   static constexpr int ND = NG + NL;
+  static constexpr int NGRP = NL_;   // groups owned by a lane (what the host matches against ceil(groups / K))
   static constexpr int DCAP = NG + K_ * NL_;   // upper bound of the flattened state dimension D
   static constexpr int LBASE = 2;
   // sliced element i of this lane: flattened index and validity

@@ -36,6 +36,7 @@ struct GermanLane {
   static constexpr int NLS = NLS_;      // features owned by this lane: d = slot*NLS + i
   static constexpr int NL = 2 * NLS;    // local elements: bls slices, then beta slices
   static constexpr int ND = NG + NL;
+  static constexpr int NGRP = NLS_;   // groups owned by a lane (what the host matches against ceil(groups / K))
   static constexpr int DCAP = 1 + 2 * kGermanCols;   // upper bound of the flattened state dimension D
   static_assert(K_ * NLS_ == kGermanCols, "lanes x features per lane must cover the padded row");
   static constexpr bool HAS_MODES = false;

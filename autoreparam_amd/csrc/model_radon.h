@@ -32,6 +32,7 @@ struct RadonLane {
   static constexpr int NG = 3;   // mua, b1, b2 replicated in every lane of the chain
   static constexpr int NL = NL_; // counties owned by this lane: j = slot + K*i
   static constexpr int ND = NG + NL;
+  static constexpr int NGRP = NL_;   // groups owned by a lane (what the host matches against ceil(groups / K))
   static constexpr int DCAP = NG + K_ * NL_;   // upper bound of the flattened state dimension D
   // sliced element i of this lane: flattened index and validity
   ARP_DEV int lbase(int) const { return LBASE + slot; }

@@ -24,6 +24,7 @@ struct SchoolsLane {
   static constexpr int NG = 2;   // mu, log_tau
   static constexpr int NL = NL_; // schools owned by this lane: k = slot + K*i
   static constexpr int ND = NG + NL;
+  static constexpr int NGRP = NL_;   // groups owned by a lane (what the host matches against ceil(groups / K))
   static constexpr int DCAP = 10;   // upper bound of the flattened state dimension D
   static constexpr int LBASE = 2;
   // sliced element i of this lane: flattened index and validity

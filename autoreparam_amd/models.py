@@ -92,7 +92,7 @@ class ModelSpec(object):
         d = _lib.Dataset()
         d.model = self.model_id
         r = self.raw
-        if self.model_id == _lib.MODEL_RADON:
+        if self.model_id in (_lib.MODEL_RADON, _lib.MODEL_RADON_STDDVS):
             d.n_obs = len(r["y"]); d.n_groups = len(r["u"])
             d.group_host = i32(r["county"]); d.u_host = f32(r["u"])
             d.x_host = f32(r["x"]); d.y_host = f32(r["y"])
@@ -132,6 +132,14 @@ def _spec_radon(state_code):
                      r, {"y": r["y"].reshape(-1, 1)})
 
 
+def _spec_radon_stddvs(state_code):
+    """radon with inferred per-county observation scales (reference models.py:763-806)."""
+    r = _load("radon_%s.npz" % state_code)
+    J = len(r["u"])
+    return ModelSpec("radon_stddvs", _lib.MODEL_RADON_STDDVS, ["mua", "b1", "b2", "m", "log_m_stddv"],
+                     [(), (), (), (J,), (J,)], r, {"y": r["y"].reshape(-1, 1)})
+
+
 def _spec_german():
     r = _load("german_credit.npz")
     F = r["X"].shape[1]
@@ -153,13 +161,15 @@ def get_model_by_name(model_name, dataset=None):
         spec = _spec_eight_schools()
     elif model_name == "radon":
         spec = _spec_radon(dataset if dataset else "MN")
+    elif model_name == "radon_stddvs":
+        spec = _spec_radon_stddvs(dataset if dataset else "MN")
     elif model_name == "german_credit_lognormalcentered":
         spec = _spec_german()
     elif model_name in ("election", "election88"):
         spec = _spec_election()
     else:
         raise Exception("unknown model {} (this build covers 8schools, radon, "
-                        "german_credit_lognormalcentered, election)".format(model_name))
+                        "radon_stddvs, german_credit_lognormalcentered, election)".format(model_name))
     from . import engine  # deferred: converters run on the device
 
     varnames = spec.part_names

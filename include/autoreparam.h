@@ -36,7 +36,8 @@ enum {
   ARP_MODEL_EIGHT_SCHOOLS = 0,
   ARP_MODEL_RADON = 1,
   ARP_MODEL_GERMAN_CREDIT = 2, /* german_credit_lognormalcentered */
-  ARP_MODEL_ELECTION = 3
+  ARP_MODEL_ELECTION = 3,
+  ARP_MODEL_RADON_STDDVS = 4  /* radon with per-county observation scales, models.py:763-806 */
 };
 
 /* Step-size adaptation wrapped around the HMC transition. */

@@ -114,6 +114,19 @@ def radon_program(r, raw):
     r.normal("y", y_mu, 1.0)
 
 
+def radon_stddvs_program(r, raw):
+    J = len(raw["u"])
+    mua = r.normal("mua", 0.0, 1.0)
+    b1 = r.normal("b1", 0.0, 1.0)
+    b2 = r.normal("b2", 0.0, 1.0)
+    m = r.normal("m", mua + _t(raw["u"]) * b1, torch.ones(J, dtype=F64))
+    Cm = one_hot(raw["county"], J)
+    lms = r.normal("log_m_stddv", torch.zeros(J, dtype=F64), torch.ones(J, dtype=F64))
+    y_mu = Cm @ m.unsqueeze(1) + _t(raw["x"]).unsqueeze(1) * b2
+    y_sd = Cm @ torch.exp(lms).unsqueeze(1)
+    r.normal("y", y_mu, y_sd)
+
+
 def german_program(r, raw):
     X = _t(raw["X"])
     F = X.shape[1]
@@ -136,7 +149,7 @@ def election_program(r, raw):
     r.bernoulli("y", y_hat)
 
 
-PROGRAMS = {"8schools": schools_program, "radon": radon_program,
+PROGRAMS = {"8schools": schools_program, "radon": radon_program, "radon_stddvs": radon_stddvs_program,
             "german_credit_lognormalcentered": german_program, "election": election_program}
 
 

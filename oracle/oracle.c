@@ -32,6 +32,7 @@ typedef struct orc_model {
   /* radon sufficient statistics */
   int J;
   float *n, *sx, *sy, *u;
+  float *sxx_j, *sxy_j, *syy_j;   /* radon_stddvs: per-county second moments */
   float sxy, sxx;
   /* schools: u = treatment stddevs, y = effects.  german: X [N][F], y [N].
    * election: cell tables [(S+1)][4] indexed (state, female + 2*black). */
@@ -142,6 +143,33 @@ orc_model* orc_radon_create(int N, int J, const int32_t* county, const float* u,
   return M;
 }
 
+orc_model* orc_radon_sd_create(int N, int J, const int32_t* county, const float* u, const float* x,
+                               const float* y) {
+  orc_model* M = (orc_model*)calloc(1, sizeof(orc_model));
+  M->model = 4; M->J = J; M->D = 3 + 2 * J;
+  M->n_glob = 3; M->n_groups = J; M->n_local_parts = 2;
+  M->glob_idx[0] = 0; M->glob_idx[1] = 1; M->glob_idx[2] = 2;
+  M->group_idx = (int*)malloc(sizeof(int) * 2 * J);
+  float** tabs[7] = {&M->n, &M->sx, &M->sy, &M->u, &M->sxx_j, &M->sxy_j, &M->syy_j};
+  for (int k = 0; k < 7; ++k) *tabs[k] = (float*)calloc(J, sizeof(float));
+  double* st = (double*)calloc(6 * (size_t)J, sizeof(double));
+  for (int i = 0; i < N; ++i) {
+    int j = county[i];
+    if (j < 0 || j >= J) continue;
+    st[j] += 1; st[J + j] += x[i]; st[2 * J + j] += y[i];
+    st[3 * J + j] += (double)x[i] * x[i]; st[4 * J + j] += (double)x[i] * y[i]; st[5 * J + j] += (double)y[i] * y[i];
+  }
+  for (int j = 0; j < J; ++j) {
+    M->group_idx[j] = 3 + j; M->group_idx[J + j] = 3 + J + j;
+    M->n[j] = (float)st[j]; M->sx[j] = (float)st[J + j]; M->sy[j] = (float)st[2 * J + j];
+    M->sxx_j[j] = (float)st[3 * J + j]; M->sxy_j[j] = (float)st[4 * J + j]; M->syy_j[j] = (float)st[5 * J + j];
+    M->u[j] = u[j];
+  }
+  M->logp_const = -(3.0 + 2.0 * J + N) * HALF_LOG_2PI;
+  free(st);
+  return M;
+}
+
 orc_model* orc_schools_create(const float* y, const float* sigma) {
   orc_model* M = (orc_model*)calloc(1, sizeof(orc_model));
   M->model = 0; M->D = 10; M->n_glob = 2; M->n_groups = 8; M->n_local_parts = 1;
@@ -194,6 +222,7 @@ void orc_model_destroy(orc_model* M) {
   if (!M) return;
   free(M->group_idx); free(M->n); free(M->sx); free(M->sy); free(M->u);
   free(M->y); free(M->X); free(M->cell_n); free(M->cell_y);
+  free(M->sxx_j); free(M->sxy_j); free(M->syy_j);
   free(M);
 }
 int orc_model_dim(const orc_model* M) { return M->D; }

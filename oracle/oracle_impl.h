@@ -259,6 +259,49 @@ static void FN(german_convert)(const orc_model* M, const float* a, const float* 
   }
 }
 
+/* radon_stddvs, reference models.py:763-806.  Parts: mua, b1, b2, m[J], log_m_stddv[J]. */
+static REAL FN(radon_sd_logp_grad)(const orc_model* M, const float* a, const float* b,
+                                   const REAL* x, REAL* g) {
+  (void)b;
+  const int J = M->J;
+  const REAL mua = x[0], b1 = x[1], b2 = x[2];
+  REAL lp = -(REAL)0.5 * (mua * mua + b1 * b1 + b2 * b2);
+  REAL g_mua = -mua, g_b1 = -b1, g_b2 = -b2;
+  for (int j = 0; j < J; ++j) {
+    const REAL aj = a[3 + j], s = x[3 + J + j];
+    const REAL mu = mua + (REAL)M->u[j] * b1;
+    const REAL r = x[3 + j] - aj * mu;
+    const REAL m = r + mu;
+    const REAL w = (REAL)exp(-2.0 * (double)s);
+    /* sum over the county of (y - m - b2 x)^2 and of (y - m - b2 x) */
+    const REAL resid = (REAL)M->sy[j] - b2 * (REAL)M->sx[j] - (REAL)M->n[j] * m;
+    const REAL Q = (REAL)M->syy_j[j] - 2 * m * (REAL)M->sy[j] - 2 * b2 * (REAL)M->sxy_j[j] + (REAL)M->n[j] * m * m +
+                   2 * m * b2 * (REAL)M->sx[j] + b2 * b2 * (REAL)M->sxx_j[j];
+    lp += -(REAL)0.5 * r * r - (REAL)0.5 * s * s - (REAL)M->n[j] * s - (REAL)0.5 * w * Q;
+    const REAL l = w * resid;
+    const REAL gm = l - r;
+    g[3 + j] = gm;
+    g[3 + J + j] = -s - (REAL)M->n[j] + w * Q;
+    const REAL h = l - aj * gm;
+    g_mua += h; g_b1 += (REAL)M->u[j] * h;
+    g_b2 += w * ((REAL)M->sxy_j[j] - m * (REAL)M->sx[j] - b2 * (REAL)M->sxx_j[j]);
+  }
+  g[0] = g_mua; g[1] = g_b1; g[2] = g_b2;
+  return lp;
+}
+static void FN(radon_sd_convert)(const orc_model* M, const float* a, const float* b, const REAL* x,
+                                 REAL* out, int to_centered) {
+  (void)b;
+  const int J = M->J;
+  out[0] = x[0]; out[1] = x[1]; out[2] = x[2];
+  for (int j = 0; j < J; ++j) {
+    REAL mu = x[0] + (REAL)M->u[j] * x[1];
+    REAL d = ((REAL)1 - (REAL)a[3 + j]) * mu;
+    out[3 + j] = to_centered ? x[3 + j] + d : x[3 + j] - d;
+    out[3 + J + j] = x[3 + J + j];
+  }
+}
+
 /* dispatch */
 static REAL FN(logp_grad)(const orc_model* M, const float* a, const float* b, const REAL* x, REAL* g) {
   switch (M->model) {
@@ -266,6 +309,7 @@ static REAL FN(logp_grad)(const orc_model* M, const float* a, const float* b, co
     case 1: return FN(radon_logp_grad)(M, a, b, x, g);
     case 2: return FN(german_logp_grad)(M, a, b, x, g);
     case 3: return FN(election_logp_grad)(M, a, b, x, g);
+    case 4: return FN(radon_sd_logp_grad)(M, a, b, x, g);
     default: return (REAL)NAN;
   }
 }
@@ -275,6 +319,7 @@ static void FN(to_centered)(const orc_model* M, const float* a, const float* b, 
     case 1: FN(radon_to_centered)(M, a, b, x, o); break;
     case 2: FN(german_convert)(M, a, b, x, o, 1); break;
     case 3: FN(election_convert)(M, a, b, x, o, 1); break;
+    case 4: FN(radon_sd_convert)(M, a, b, x, o, 1); break;
     default: break;
   }
 }
@@ -284,6 +329,7 @@ static void FN(from_centered)(const orc_model* M, const float* a, const float* b
     case 1: FN(radon_from_centered)(M, a, b, x, o); break;
     case 2: FN(german_convert)(M, a, b, x, o, 0); break;
     case 3: FN(election_convert)(M, a, b, x, o, 0); break;
+    case 4: FN(radon_sd_convert)(M, a, b, x, o, 0); break;
     default: break;
   }
 }
@@ -562,7 +608,7 @@ static void FN(dparam)(const orc_model* M, const float* a, const float* b, const
   FN(to_centered)(M, a, b, x, xc);
   switch (M->model) {
     case 0: ls[0] = ls[1] = (REAL)log(5.0); for (int k = 0; k < 8; ++k) { mu[2 + k] = xc[0]; ls[2 + k] = xc[1]; } break;
-    case 1: for (int j = 0; j < M->J; ++j) mu[3 + j] = xc[0] + (REAL)M->u[j] * xc[1]; break;
+    case 1: case 4: for (int j = 0; j < M->J; ++j) mu[3 + j] = xc[0] + (REAL)M->u[j] * xc[1]; break;
     case 2: ls[0] = (REAL)log(10.0);
       for (int d = 0; d < M->F; ++d) { mu[1 + d] = xc[0]; ls[1 + M->F + d] = xc[1 + d]; } break;
     case 3: ls[0] = (REAL)log(100.0); ls[1] = (REAL)log(10.0);

@@ -8,6 +8,7 @@ MODEL_SPECS = {
     "radon_MN": lambda: models._spec_radon("MN"),
     "radon_PA": lambda: models._spec_radon("PA"),
     "german": lambda: models._spec_german(),
+    "radon_sd_MN": lambda: models._spec_radon_stddvs("MN"),
     "election": lambda: models._spec_election(),
 }
 _cache = {}
