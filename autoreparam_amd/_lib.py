@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libautoreparam_hip.so")
 
 MODEL_EIGHT_SCHOOLS, MODEL_RADON, MODEL_GERMAN_CREDIT, MODEL_ELECTION, MODEL_RADON_STDDVS = 0, 1, 2, 3, 4
+MODEL_NEALS_FUNNEL = 5
 ADAPT_NONE, ADAPT_DUAL, ADAPT_SIMPLE = 0, 1, 2
 RNG_SLOTS = 16  # rng buffer is [C][16][4] uint32
 

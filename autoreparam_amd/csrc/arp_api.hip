@@ -47,6 +47,7 @@ static const std::vector<LaneOps>* family(const arp_model* m) {
     case ARP_MODEL_ELECTION: return &election_ops();
     case ARP_MODEL_GERMAN_CREDIT: return &german_ops();
     case ARP_MODEL_RADON_STDDVS: return &radon_sd_ops();
+    case ARP_MODEL_NEALS_FUNNEL: return &funnel_ops();
     default: return nullptr;
   }
 }
@@ -57,6 +58,7 @@ static const void* family_args(const arp_model* m) {
     case ARP_MODEL_ELECTION: return &m->election;
     case ARP_MODEL_GERMAN_CREDIT: return &m->german;
     case ARP_MODEL_RADON_STDDVS: return &m->radon_sd;
+    case ARP_MODEL_NEALS_FUNNEL: return &m->funnel;
     default: return nullptr;
   }
 }
@@ -230,6 +232,9 @@ int arp_model_create(const arp_dataset* data, arp_model** out) {
     case ARP_MODEL_ELECTION: rc = build_election(m.get(), data); break;
     case ARP_MODEL_GERMAN_CREDIT: rc = build_german(m.get(), data); break;
     case ARP_MODEL_RADON_STDDVS: rc = build_radon_sd(m.get(), data); break;
+    case ARP_MODEL_NEALS_FUNNEL:   // models.py:671-696: no data
+      m->D = 2; m->n_groups = 1; m->const_base = -2.0 * kHalfLog2Pi; m->top_scale = {{0, log(3.0)}};
+      rc = 0; break;
     default: set_error("arp_model_create: unknown model id"); return 1;
   }
   if (rc) return rc;
@@ -282,7 +287,7 @@ static const LaneOps* select_ops(arp_model* m, int K_req, int C) {
     return nullptr;
   }
   const LaneOps* o = pick(*fam, m->n_groups, K_req, C, m->model != ARP_MODEL_GERMAN_CREDIT);
-  if (!o) set_error("no kernel instantiation for this (lanes_per_chain, group count): add RadonLane<K, ceil(J/K)> to inst_radon_k*.hip");
+  if (!o) set_error("no kernel instantiation for this (lanes_per_chain, group count): add <Model>Lane<K, ceil(groups/K)> to the model's inst_*.hip");
   return o;
 }
 

@@ -13,6 +13,7 @@
 #include "model_election.h"
 #include "model_german.h"
 #include "model_radon_stddvs.h"
+#include "model_funnel.h"
 
 namespace arp {
 
@@ -99,6 +100,7 @@ const std::vector<LaneOps>& schools_ops();
 const std::vector<LaneOps>& election_ops();
 const std::vector<LaneOps>& german_ops();
 const std::vector<LaneOps>& radon_sd_ops();
+const std::vector<LaneOps>& funnel_ops();
 
 }  // namespace arp
 
@@ -117,6 +119,7 @@ struct arp_model {
   arp::ElectionArgs election{};
   arp::GermanArgs german{};
   arp::RadonSdArgs radon_sd{};
+  arp::FunnelArgs funnel{};
   std::vector<float> host_tables;
   double const_base = 0.0;                       // parameterisation independent part of the dropped constant
   std::vector<std::pair<int, double>> top_scale; // (flattened index, log prior scale) of top-level latents

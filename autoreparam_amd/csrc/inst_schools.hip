@@ -9,4 +9,8 @@ const std::vector<LaneOps>& schools_ops() {
   };
   return t;
 }
+const std::vector<LaneOps>& funnel_ops() {
+  static const std::vector<LaneOps> t = {Launch<FunnelLane<1, 1>>::ops()};
+  return t;
+}
 }  // namespace arp

@@ -103,6 +103,8 @@ class ModelSpec(object):
             d.n_obs = len(r["y"]); d.n_groups = int(r["n_state"])
             d.group_host = i32(r["state"]); d.x_host = f32(r["female"]); d.x2_host = f32(r["black"])
             d.y_host = f32(r["y"])
+        elif self.model_id == _lib.MODEL_NEALS_FUNNEL:
+            pass
         elif self.model_id == _lib.MODEL_GERMAN_CREDIT:
             d.n_obs = r["X"].shape[0]; d.n_features = r["X"].shape[1]
             d.X_host = f32(r["X"]); d.y_host = f32(r["y"])
@@ -140,6 +142,10 @@ def _spec_radon_stddvs(state_code):
                      [(), (), (), (J,), (J,)], r, {"y": r["y"].reshape(-1, 1)})
 
 
+def _spec_funnel():
+    return ModelSpec("neals_funnel", _lib.MODEL_NEALS_FUNNEL, ["x1", "x2"], [(), ()], {}, {})
+
+
 def _spec_german():
     r = _load("german_credit.npz")
     F = r["X"].shape[1]
@@ -161,6 +167,8 @@ def get_model_by_name(model_name, dataset=None):
         spec = _spec_eight_schools()
     elif model_name == "radon":
         spec = _spec_radon(dataset if dataset else "MN")
+    elif model_name == "neals_funnel":
+        spec = _spec_funnel()
     elif model_name == "radon_stddvs":
         spec = _spec_radon_stddvs(dataset if dataset else "MN")
     elif model_name == "german_credit_lognormalcentered":
@@ -169,7 +177,7 @@ def get_model_by_name(model_name, dataset=None):
         spec = _spec_election()
     else:
         raise Exception("unknown model {} (this build covers 8schools, radon, "
-                        "radon_stddvs, german_credit_lognormalcentered, election)".format(model_name))
+                        "radon_stddvs, neals_funnel, german_credit_lognormalcentered, election)".format(model_name))
     from . import engine  # deferred: converters run on the device
 
     varnames = spec.part_names

@@ -37,6 +37,7 @@ enum {
   ARP_MODEL_RADON = 1,
   ARP_MODEL_GERMAN_CREDIT = 2, /* german_credit_lognormalcentered */
   ARP_MODEL_ELECTION = 3,
+  ARP_MODEL_NEALS_FUNNEL = 5, /* models.py:671-696; no dataset fields are read */
   ARP_MODEL_RADON_STDDVS = 4  /* radon with per-county observation scales, models.py:763-806 */
 };
 

@@ -127,6 +127,11 @@ def radon_stddvs_program(r, raw):
     r.normal("y", y_mu, y_sd)
 
 
+def funnel_program(r, raw):
+    x1 = r.normal("x1", 0.0, 3.0)
+    r.normal("x2", 0.0, torch.exp(x1 / 2.0))
+
+
 def german_program(r, raw):
     X = _t(raw["X"])
     F = X.shape[1]
@@ -149,7 +154,7 @@ def election_program(r, raw):
     r.bernoulli("y", y_hat)
 
 
-PROGRAMS = {"8schools": schools_program, "radon": radon_program, "radon_stddvs": radon_stddvs_program,
+PROGRAMS = {"8schools": schools_program, "radon": radon_program, "radon_stddvs": radon_stddvs_program, "neals_funnel": funnel_program,
             "german_credit_lognormalcentered": german_program, "election": election_program}
 
 

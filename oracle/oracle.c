@@ -170,6 +170,16 @@ orc_model* orc_radon_sd_create(int N, int J, const int32_t* county, const float*
   return M;
 }
 
+orc_model* orc_funnel_create(void) {
+  orc_model* M = (orc_model*)calloc(1, sizeof(orc_model));
+  M->model = 5; M->D = 2; M->n_glob = 1; M->n_groups = 1; M->n_local_parts = 1;
+  M->glob_idx[0] = 0;
+  M->group_idx = (int*)malloc(sizeof(int));
+  M->group_idx[0] = 1;
+  M->logp_const = -2.0 * HALF_LOG_2PI - log(3.0);
+  return M;
+}
+
 orc_model* orc_schools_create(const float* y, const float* sigma) {
   orc_model* M = (orc_model*)calloc(1, sizeof(orc_model));
   M->model = 0; M->D = 10; M->n_glob = 2; M->n_groups = 8; M->n_local_parts = 1;

@@ -302,6 +302,24 @@ static void FN(radon_sd_convert)(const orc_model* M, const float* a, const float
   }
 }
 
+/* Neal's funnel, reference models.py:674-677.  Parts: x1, x2. */
+static REAL FN(funnel_logp_grad)(const orc_model* M, const float* a, const float* b, const REAL* x, REAL* g) {
+  (void)M; (void)a;
+  const REAL s1 = (REAL)pow(3.0, (double)b[0]), c1 = 3 / s1, b2 = b[1];
+  const REAL x1 = c1 * x[0];
+  const REAL e = (REAL)exp((double)(-(REAL)0.5 * b2 * x1));
+  const REAL z = x[1] * e, u1 = x[0] / s1;
+  g[1] = -z * e;
+  g[0] = -u1 / s1 + c1 * (REAL)0.5 * b2 * (z * z - 1);
+  return -(REAL)0.5 * u1 * u1 - (REAL)0.5 * z * z - (REAL)0.5 * b2 * x1;
+}
+static void FN(funnel_convert)(const orc_model* M, const float* a, const float* b, const REAL* x, REAL* out, int to_centered) {
+  (void)M; (void)a;
+  const REAL c1 = (REAL)pow(3.0, 1.0 - (double)b[0]);
+  if (to_centered) { out[0] = c1 * x[0]; out[1] = x[1] * (REAL)exp(0.5 * (1.0 - (double)b[1]) * (double)out[0]); }
+  else { out[0] = x[0] / c1; out[1] = x[1] * (REAL)exp(-0.5 * (1.0 - (double)b[1]) * (double)x[0]); }
+}
+
 /* dispatch */
 static REAL FN(logp_grad)(const orc_model* M, const float* a, const float* b, const REAL* x, REAL* g) {
   switch (M->model) {
@@ -310,6 +328,7 @@ static REAL FN(logp_grad)(const orc_model* M, const float* a, const float* b, co
     case 2: return FN(german_logp_grad)(M, a, b, x, g);
     case 3: return FN(election_logp_grad)(M, a, b, x, g);
     case 4: return FN(radon_sd_logp_grad)(M, a, b, x, g);
+    case 5: return FN(funnel_logp_grad)(M, a, b, x, g);
     default: return (REAL)NAN;
   }
 }
@@ -320,6 +339,7 @@ static void FN(to_centered)(const orc_model* M, const float* a, const float* b, 
     case 2: FN(german_convert)(M, a, b, x, o, 1); break;
     case 3: FN(election_convert)(M, a, b, x, o, 1); break;
     case 4: FN(radon_sd_convert)(M, a, b, x, o, 1); break;
+    case 5: FN(funnel_convert)(M, a, b, x, o, 1); break;
     default: break;
   }
 }
@@ -330,6 +350,7 @@ static void FN(from_centered)(const orc_model* M, const float* a, const float* b
     case 2: FN(german_convert)(M, a, b, x, o, 0); break;
     case 3: FN(election_convert)(M, a, b, x, o, 0); break;
     case 4: FN(radon_sd_convert)(M, a, b, x, o, 0); break;
+    case 5: FN(funnel_convert)(M, a, b, x, o, 0); break;
     default: break;
   }
 }
@@ -611,6 +632,7 @@ static void FN(dparam)(const orc_model* M, const float* a, const float* b, const
     case 1: case 4: for (int j = 0; j < M->J; ++j) mu[3 + j] = xc[0] + (REAL)M->u[j] * xc[1]; break;
     case 2: ls[0] = (REAL)log(10.0);
       for (int d = 0; d < M->F; ++d) { mu[1 + d] = xc[0]; ls[1 + M->F + d] = xc[1 + d]; } break;
+    case 5: ls[0] = (REAL)log(3.0); ls[1] = xc[0] / 2; break;
     case 3: ls[0] = (REAL)log(100.0); ls[1] = (REAL)log(10.0);
       ls[2 + M->S] = ls[3 + M->S] = (REAL)log(100.0);
       for (int t = 0; t < M->S; ++t) { mu[2 + t] = xc[0]; ls[2 + t] = xc[1]; } break;

@@ -9,6 +9,7 @@ MODEL_SPECS = {
     "radon_PA": lambda: models._spec_radon("PA"),
     "german": lambda: models._spec_german(),
     "radon_sd_MN": lambda: models._spec_radon_stddvs("MN"),
+    "funnel": lambda: models._spec_funnel(),
     "election": lambda: models._spec_election(),
 }
 _cache = {}
