@@ -211,3 +211,43 @@ def test_interleaved_matches_oracle(oracle_lib, gpu, mname):
         assert np.array_equal(t0.cpu().numpy()[:, ok], t0o[:, ok]) and np.array_equal(t1.cpu().numpy()[:, ok], t1o[:, ok])
         np.testing.assert_allclose(st.adapt.cpu().numpy()[ok, 0], so["adapt"][ok, 0], rtol=1e-5)
         np.testing.assert_allclose(st.adapt1.cpu().numpy()[ok, 0], so["adapt1"][ok, 0], rtol=1e-5)
+
+
+def _schools_quadrature():
+    """8 schools posterior moments by marginalising theta analytically and integrating
+    (mu, log_tau) on a grid: a known answer that does not involve the sampler."""
+    y = np.array([28, 8, -3, 7, -1, 1, 18, 12.0]); s = np.array([15, 10, 16, 11, 9, 11, 10, 18.0])
+    mu = np.linspace(-40, 50, 1801)[:, None, None]
+    lt = np.linspace(-22, 9, 1241)[None, :, None]
+    v = np.exp(2 * lt) + s ** 2
+    lp = (-0.5 * (y - mu) ** 2 / v - 0.5 * np.log(v)).sum(-1) - 0.5 * (mu[..., 0] / 5) ** 2 - 0.5 * (lt[..., 0] / 5) ** 2
+    w = np.exp(lp - lp.max()); w /= w.sum()
+    th = (y / s ** 2 + mu / np.exp(2 * lt)) / (1 / s ** 2 + 1 / np.exp(2 * lt))
+    e_mu, e_lt = (w * mu[..., 0]).sum(), (w * lt[..., 0]).sum()
+    sd_mu = np.sqrt((w * (mu[..., 0] - e_mu) ** 2).sum()); sd_lt = np.sqrt((w * (lt[..., 0] - e_lt) ** 2).sum())
+    e_th = (w[..., None] * th).sum((0, 1))
+    return e_mu, sd_mu, e_lt, sd_lt, e_th
+
+
+def test_eight_schools_posterior_against_quadrature(gpu):
+    """BASELINE config 1 model, non-Gaussian funnel geometry: NCP HMC (4 leapfrog steps, dual
+    averaging) reproduces the quadrature posterior means of mu, log_tau and theta."""
+    from autoreparam_amd import engine, _lib
+    e_mu, sd_mu, e_lt, sd_lt, e_th = _schools_quadrature()
+    sp = helpers.spec("8schools")
+    eng = _eng("8schools", gpu)
+    eng.set_param(0, "NCP")
+    Cn, S = 8192, 250
+    rs = np.random.RandomState(0)
+    q0 = (0.5 * rs.randn(Cn, sp.D)).astype(np.float32)
+    st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+    tr = torch.zeros(S, Cn, sp.D, device=gpu)
+    eps0 = np.full(sp.D, 0.25, np.float32)
+    eng.hmc_run(st, eps0, 4, 1 + 600 + 2 * (S - 1), seed=6, adapt_kind=_lib.ADAPT_DUAL, n_adapt=500, n_burnin=600,
+                thin=2, trace=tr, trace_centered=True, lanes=8)
+    acc = st.accept_count.double().mean().item() / st.step
+    assert 0.55 < acc < 0.95
+    m = tr.double().mean(dim=(0, 1)).cpu().numpy()
+    assert abs(m[0] - e_mu) < 0.05 * sd_mu + 0.05, (m[0], e_mu)
+    assert abs(m[1] - e_lt) < 0.05 * sd_lt + 0.05, (m[1], e_lt)
+    assert np.abs(m[2:] - e_th).max() < 0.25, (m[2:], e_th)
