@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Long float64 CPU runs of the oracle's HMC for the two models without a closed-form
+posterior (election, german credit): posterior means / sds of every coordinate with
+Monte-Carlo standard errors.  Written to posterior_golden.npz and used
+by the GPU tests as the known answer for the sampled posterior."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers  # noqa: E402
+import oracle  # noqa: E402
+
+
+def hess_scale(orc, sp, a, b, x0):
+    _, g0 = orc.logp_grad(x0[None], a, b)
+    h = 1e-4
+    d = np.zeros(sp.D)
+    for k in range(sp.D):
+        xp = x0.copy(); xp[k] += h
+        d[k] = -(orc.logp_grad(xp[None], a, b)[1][0, k] - g0[0, k]) / h
+    return 1.0 / np.sqrt(np.abs(d) + 1e-3)
+
+
+def find_mode(orc, sp, a, b, iters=6000, lr=0.02):
+    """Adam ascent on the log joint (robust to the badly scaled log-scale coordinates)."""
+    x = np.zeros(sp.D); m = np.zeros(sp.D); v = np.zeros(sp.D)
+    for it in range(1, iters + 1):
+        _, g = orc.logp_grad(x[None], a, b)
+        g = g[0]
+        m = 0.9 * m + 0.1 * g; v = 0.999 * v + 0.001 * g * g
+        x = x + lr * (m / (1 - 0.9 ** it)) / (np.sqrt(v / (1 - 0.999 ** it)) + 1e-8)
+    return x, hess_scale(orc, sp, a, b, x)
+
+
+out = {}
+for mname, kind, L, C, burn, S in (("election", "CP", 8, 256, 1500, 1500), ("german", "NCP", 8, 192, 1500, 1200)):
+    sp = helpers.spec(mname)
+    orc = oracle.OracleModel(sp)
+    a, b = helpers.params(sp, kind)
+    t0 = time.time()
+    mode, sc = find_mode(orc, sp, a, b)
+    rs = np.random.RandomState(0)
+    q0 = mode + 0.5 * sc * rs.randn(C, sp.D)
+    st = oracle.new_state(q0, np.float64)
+    trace = np.zeros((S, C, sp.D))
+    orc.hmc_run(st, a, b, (0.5 * sc).astype(np.float32), L, 1 + burn + 2 * (S - 1), seed=123, adapt_kind=1,
+                n_adapt=burn - 200, n_burnin=burn, thin=2, trace=trace, trace_centered=True, lanes=16)
+    cm = trace.mean(axis=0)                       # per-chain means [C, D]
+    mean = cm.mean(axis=0)
+    mcse = cm.std(axis=0, ddof=1) / np.sqrt(C)
+    sd = trace.reshape(-1, sp.D).std(axis=0)
+    acc = st["accept_count"].mean() / st["step"]
+    print("%s: %.0f s, accept %.2f, max mcse/sd %.3f" % (mname, time.time() - t0, acc, (mcse / sd).max()))
+    out[mname + "/mean"] = mean; out[mname + "/sd"] = sd; out[mname + "/mcse"] = mcse
+    out[mname + "/step_scale"] = sc; out[mname + "/mode"] = mode   # in the sampler's (kind) coordinates
+    # split check: first and second half of the recorded samples must agree (german in CP coordinates does not
+    # pass this -- its chains creep out of the funnel for thousands of transitions -- hence NCP there)
+    h1, h2 = trace[: S // 2].mean(axis=(0, 1)), trace[S // 2:].mean(axis=(0, 1))
+    print("   max |first half - second half| / sd = %.3f" % np.abs((h1 - h2) / sd).max())
+    assert np.abs((h1 - h2) / sd).max() < 0.25
+np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "posterior_golden.npz"), **out)

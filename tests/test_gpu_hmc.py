@@ -251,3 +251,39 @@ def test_eight_schools_posterior_against_quadrature(gpu):
     assert abs(m[0] - e_mu) < 0.05 * sd_mu + 0.05, (m[0], e_mu)
     assert abs(m[1] - e_lt) < 0.05 * sd_lt + 0.05, (m[1], e_lt)
     assert np.abs(m[2:] - e_th).max() < 0.25, (m[2:], e_th)
+
+
+@pytest.mark.parametrize("mname,kind,L,Cn", [("election", "CP", 8, 2048), ("german", "NCP", 8, 768)])
+def test_posterior_moments_against_long_cpu_run(gpu, mname, kind, L, Cn):
+    """election / german credit have no closed-form posterior: the known answer is a long float64
+    oracle run committed with Monte-Carlo error bars (tests/golden/posterior_golden.npz)."""
+    import os
+    from autoreparam_amd import engine, _lib
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "posterior_golden.npz"))
+    mean_g, sd_g, mcse_g = gold[mname + "/mean"], gold[mname + "/sd"], gold[mname + "/mcse"]
+    sc, mode = gold[mname + "/step_scale"], gold[mname + "/mode"]
+    sp = helpers.spec(mname)
+    eng = _eng(mname, gpu)
+    eng.set_param(0, kind)
+    rs = np.random.RandomState(1)
+    q0 = (mode + 0.5 * sc * rs.randn(Cn, sp.D)).astype(np.float32)     # mode / scale are in `kind` coordinates
+    st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+    burn, S = 1500, 300
+    tr = torch.zeros(S, Cn, sp.D, device=gpu)
+    eng.hmc_run(st, (0.5 * sc).astype(np.float32), L, 1 + burn + 2 * (S - 1), seed=77, adapt_kind=_lib.ADAPT_DUAL,
+                n_adapt=burn - 200, n_burnin=burn, thin=2, trace=tr, trace_centered=True)
+    acc = st.accept_count.double().mean().item() / st.step
+    assert 0.55 < acc < 0.95, acc
+    cm = tr.double().mean(dim=0).cpu().numpy()
+    mean = cm.mean(axis=0)
+    mcse = cm.std(axis=0, ddof=1) / np.sqrt(Cn)
+    sd = tr.double().reshape(-1, sp.D).std(dim=0).cpu().numpy()
+    z = np.abs(mean - mean_g) / (np.sqrt(mcse ** 2 + mcse_g ** 2) + 0.01 * sd_g)
+    assert z.max() < 5.0, (int(z.argmax()), z.max())
+    assert np.abs(sd / sd_g - 1).max() < 0.08
+    # "posterior means within 1 %" on the coordinates whose mean is well away from zero
+    # (where the Monte-Carlo error of the two runs allows a 1 % statement)
+    err = np.sqrt(mcse ** 2 + mcse_g ** 2)
+    big = (np.abs(mean_g) > 5 * sd_g) & (4 * err < 0.01 * np.abs(mean_g))
+    if big.any():
+        assert (np.abs(mean[big] / mean_g[big] - 1) < 0.01).all()
