@@ -50,15 +50,6 @@ ARP_DEV void load_row(const Lane& M, const float* __restrict__ row, float (&v)[L
 #pragma unroll
   for (int i = 0; i < Lane::NL; ++i) v[Lane::NG + i] = M.lvalid(i) ? (row + M.lbase(i))[Lane::loff(i)] : 0.0f;
 }
-// same from LDS, through a volatile pointer so that the loads stay inside the sampling loop
-// (hoisted out they would sit in VGPRs, or in scratch, for the whole launch)
-template <class Lane>
-ARP_DEV void load_row_lds(const Lane& M, const volatile float* row, float (&v)[Lane::ND]) {
-#pragma unroll
-  for (int i = 0; i < Lane::NG; ++i) v[i] = row[M.gg(i)];
-#pragma unroll
-  for (int i = 0; i < Lane::NL; ++i) v[Lane::NG + i] = M.lvalid(i) ? (row + M.lbase(i))[Lane::loff(i)] : 0.0f;
-}
 template <class Lane>
 ARP_DEV void store_row(const Lane& M, float* __restrict__ row, const float (&v)[Lane::ND], bool live) {
   if (live && M.slot == 0) {
@@ -457,39 +448,63 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
     rng = Rng{rs[0], rs[1], rs[2], rs[3]};
   }
 
+  // The reference re-bootstraps logp/grad after every change of coordinates
+  // (interleaved.py:120-123, 136-139).  Where the CP <-> NCP map is a shear with unit Jacobian
+  // (Lane::HAS_CARRY) the log density is unchanged and the gradient follows by the chain rule, so
+  // it is carried across the change of coordinates instead of being recomputed: 2*num_ls instead of
+  // 2*num_ls + 2 gradient evaluations per step.  The carried pair is kept in grad/logp between launches.
+  constexpr bool CARRY = Lane::HAS_CARRY && M0 == kModeCP && M1 == kModeNCP;
+  float lp = 0.0f;
+  if (CARRY) {
+    if (P.step_base == 0 || !P.grad) {
+      lp = lane_grad<M0, true>(M, q, g);
+    } else {
+      load_row(M, P.grad + c * D, g);
+      lp = P.logp[c];
+    }
+  }
   int next_rec = P.rec_step, rec_row = P.rec_row;
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see hmc_kernel
   for (int s = 0; s < P.n_steps; ++s) {
     const long long n = P.step_base + s + 1;
     bool acc0, acc1;
     // --- parameterisation 0 ---
-    float lp = lane_grad<M0, true>(M, q, g);
+    if (!CARRY) lp = lane_grad<M0, true>(M, q, g);
     load_row(M, s_eps[0], eps);
 #pragma unroll
     for (int i = 0; i < ND; ++i) eps[i] *= kap[0];
     float la = hmc_transition<Lane, M0>(M, rng, P.L, eps, q, g, lp, acc0, save);
     nacc0 += acc0 ? 1u : 0u;
     adapt_update(P, n, la, kap[0], es[0], la_[0]);
-    lane_to_centered<M0>(M, q, x);
     // --- parameterisation 1 ---
-    if (M1 == kModeVIP || !Lane::HAS_MODES) M.set_param(av1, bv1);
-    lane_from_centered<M1>(M, x, q);
-    lp = lane_grad<M1, true>(M, q, g);
+    if constexpr (CARRY) {
+      M.template carry<kModeCP>(q, g);
+    } else {
+      lane_to_centered<M0>(M, q, x);
+      if (M1 == kModeVIP || !Lane::HAS_MODES) M.set_param(av1, bv1);
+      lane_from_centered<M1>(M, x, q);
+      lp = lane_grad<M1, true>(M, q, g);
+    }
     load_row(M, s_eps[1], eps);
 #pragma unroll
     for (int i = 0; i < ND; ++i) eps[i] *= kap[1];
     la = hmc_transition<Lane, M1>(M, rng, P.L1, eps, q, g, lp, acc1, save);
     nacc1 += acc1 ? 1u : 0u;
     adapt_update(P, n, la, kap[1], es[1], la_[1]);
-    lane_to_centered<M1>(M, q, x);
-    if (M0 == kModeVIP || !Lane::HAS_MODES) M.set_param(av0, bv0);
-    lane_from_centered<M0>(M, x, q);
+    if constexpr (CARRY) {
+      M.template carry<kModeNCP>(q, g);
+    } else {
+      lane_to_centered<M1>(M, q, x);
+      if (M0 == kModeVIP || !Lane::HAS_MODES) M.set_param(av0, bv0);
+      lane_from_centered<M0>(M, x, q);
+    }
 
     if (s == next_rec && rec_row < P.n_samples) {
       if (P.trace) {
         float* wrow = P.trace + ((size_t)rec_row * P.C + cw0) * D;
-        // x already holds the centred state; q the parameterisation-0 state the reference records
-        if (P.trace_centered) store_row_wave(M, stage, wrow, cl, D, nvalid, x);
+        // x holds the centred state (CARRY: CP coordinates are the centred ones); q the
+        // parameterisation-0 state the reference records
+        if (P.trace_centered && !CARRY) store_row_wave(M, stage, wrow, cl, D, nvalid, x);
         else store_row_wave(M, stage, wrow, cl, D, nvalid, q);
       }
       if (live && slot == 0) {
@@ -506,11 +521,13 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
   long long cw2 = cw0;
   asm volatile("" : "+v"(cw2));
   store_row_wave(M, stage, P.q + cw2 * D, cl, D, nvalid, q);
+  if (CARRY && P.grad) store_row_wave(M, stage, P.grad + cw2 * D, cl, D, nvalid, g);
   uint32_t* rs2 = P.rng + ((size_t)c2 * kRngSlots + slot) * 4;
   if (live) {
     rs = rs2;
     rs[0] = rng.s0; rs[1] = rng.s1; rs[2] = rng.s2; rs[3] = rng.s3;
     if (slot == 0) {
+      if (CARRY && P.grad) P.logp[c2] = lp;
       P.adapt[c2 * 4 + 0] = kap[0]; P.adapt[c2 * 4 + 1] = es[0]; P.adapt[c2 * 4 + 2] = la_[0];
       P.adapt1[c2 * 4 + 0] = kap[1]; P.adapt1[c2 * 4 + 1] = es[1]; P.adapt1[c2 * 4 + 2] = la_[1];
       P.accept_count[c2] = nacc0; P.accept_count1[c2] = nacc1;

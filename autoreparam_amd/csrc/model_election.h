@@ -38,6 +38,7 @@ struct ElectionLane {
   ARP_DEV bool lvalid(int i) const { return i < NL - 1 ? true : last_ok; }
   bool last_ok;
   static constexpr bool HAS_MODES = false;
+  static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = true;    // kick_drift below
   static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
   using Args = ElectionArgs;
@@ -45,7 +46,7 @@ struct ElectionLane {
   float cn[NL][4], cy[NL][4], al[NL], be[NL], lat[NL];
   float si[4], cs[4];   // 1/s^b and s^(1-b) for mua, lsa, b1, b2
   float bbar; bool buni; // every state shares one b (always so for CP, NCP and the reference's tied cVIP/dVIP)
-  int nloc, slot, ndraw, S;
+  int slot, S;
 
   // flattened index of replicated global i (b1 -> 2+S, b2 -> 3+S: S is a run-time value)
   int gmap[NG];
@@ -54,10 +55,7 @@ struct ElectionLane {
   ARP_DEV void init(const Args& A, const float* av, const float* bv, int slot_) {
     slot = slot_;
     S = A.S;
-    nloc = (S - slot + K - 1) / K;       // latents: t < S
-    if (nloc < 0) nloc = 0;
     last_ok = slot + K * (NL - 1) < S;   // latent validity (t < S); the extra cell group t == S has no latent
-    ndraw = NG + (S + 1 + K - 1) / K;    // RNG layout counts the S+1 groups
     gmap[0] = 0; gmap[1] = 1; gmap[2] = 2 + S; gmap[3] = 3 + S;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {

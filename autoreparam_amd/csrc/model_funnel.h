@@ -18,12 +18,13 @@ struct FunnelLane {
   static constexpr int NG = 1, NL = NL_, ND = NG + NL, NGRP = NL_, DCAP = 2, LBASE = 1;
   static_assert(K_ == 1 && NL_ == 1, "the funnel runs one lane per chain");
   static constexpr bool HAS_MODES = false;
+  static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = false;
   static constexpr int MINW = 1;
   using Args = FunnelArgs;
 
   float s1i, c1, b2;   // 1/3^b1, 3^(1-b1), b of x2
-  int slot, ndraw;
+  int slot;
 
   static ARP_DEV int gg(int) { return 0; }
   ARP_DEV int lbase(int) const { return 1; }
@@ -33,7 +34,6 @@ struct FunnelLane {
 
   ARP_DEV void init(const Args&, const float* av, const float* bv, int slot_) {
     slot = slot_;
-    ndraw = ND;
     set_param(av, bv);
   }
   ARP_DEV void set_param(const float* /*av*/, const float* bv) {

@@ -40,6 +40,7 @@ struct GermanLane {
   static constexpr int DCAP = 1 + 2 * kGermanCols;   // upper bound of the flattened state dimension D
   static_assert(K_ * NLS_ == kGermanCols, "lanes x features per lane must cover the padded row");
   static constexpr bool HAS_MODES = false;
+  static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = false;
   static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
   using Args = GermanArgs;
@@ -47,7 +48,7 @@ struct GermanLane {
   float a[NLS], b[NLS];     // a of bls_d, b of beta_d (the only ones that matter)
   float s0i, c0;            // 1/10^b0, 10^(1-b0)
   const float* X; const float* y;
-  int N, F, slot, ndraw, nown;
+  int N, F, slot, nown;
 
   static ARP_DEV int gg(int) { return 0; }
   ARP_DEV int lbase(int i) const { return i < NLS ? 1 + slot * NLS : 1 + F + slot * NLS; }
@@ -60,7 +61,6 @@ struct GermanLane {
     X = A.X; y = A.y; N = A.N; F = A.F;
     nown = F - slot * NLS;
     nown = nown < 0 ? 0 : (nown > NLS ? NLS : nown);
-    ndraw = NG + 2 * NLS;
     set_param(av, bv);
   }
   ARP_DEV void set_param(const float* av, const float* bv) {

@@ -44,6 +44,7 @@ struct RadonLane {
   // VALU issue needs two resident waves per SIMD: cap the allocation at 256 VGPRs where the slice fits
   static constexpr int MINW = (NL_ <= 23) ? 2 : 1;
   static constexpr bool HAS_MODES = true;
+  static constexpr bool HAS_CARRY = true;   // carry<> below
   static constexpr bool HAS_FUSED = true;   // kick_drift below  // grad_m / to_centered_m / from_centered_m below
   using Args = RadonArgs;
 
@@ -54,8 +55,7 @@ struct RadonLane {
   static constexpr int NP = (NL + 1) / 2;
   v2f n2[NP], sx2[NP], sy2[NP], u2[NP], a2[NP];
   float sxy, sxx;
-  int nloc, slot;                // nloc: slices of this lane that map to a real county
-  int ndraw;                     // NG + ceil(J/K): normals every RNG slot draws per transition
+  int slot;
 
   // flattened index of replicated global i
   static ARP_DEV int gg(int i) { return i; }
@@ -63,9 +63,7 @@ struct RadonLane {
   ARP_DEV void init(const Args& A, const float* av, const float* bv, int slot_) {
     slot = slot_;
     const int J = A.J;
-    nloc = (J - slot + K - 1) / K;
     last_ok = slot + K * (NL - 1) < J;
-    ndraw = NG + (J + K - 1) / K;
     sxy = A.sxy;
     sxx = A.sxx;
 #pragma unroll
@@ -260,6 +258,28 @@ struct RadonLane {
     p[0] = fmaf(eps[0], g0, p[0]); q[0] = fmaf(eps[0], p[0], mua);
     p[1] = fmaf(eps[1], g1, p[1]); q[1] = fmaf(eps[1], p[1], b1);
     p[2] = fmaf(eps[2], g2, p[2]); q[2] = fmaf(eps[2], p[2], b2);
+  }
+
+  // Change of coordinates CP <-> NCP of a state AND its gradient (interleaved kernel).  The map
+  // m = mt + mu(mua, b1) is a shear with unit Jacobian: the log density is unchanged and
+  //   d/dmt_j = d/dm_j,   d/dmua (NCP) = d/dmua (CP) + sum_j d/dm_j,   d/db1 likewise with u_j.
+  // FROM == 1: CP -> NCP, FROM == 2: NCP -> CP.
+  template <int FROM>
+  ARP_DEV void carry(float (&q)[ND], float (&g)[ND]) const {
+    float s = 0.0f, su = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const float mu = fmaf(u2[i >> 1][i & 1], q[1], q[0]);
+      const float gj = g[NG + i];               // 0 in padding slots
+      s += gj;
+      su = fmaf(u2[i >> 1][i & 1], gj, su);
+      const float qn = (FROM == 1) ? q[NG + i] - mu : q[NG + i] + mu;
+      q[NG + i] = lvalid(i) ? qn : 0.0f;
+    }
+    s = group_sum<K>(s);
+    su = group_sum<K>(su);
+    g[0] += (FROM == 1) ? s : -s;
+    g[1] += (FROM == 1) ? su : -su;
   }
 
   template <int MODE>

@@ -30,12 +30,13 @@ struct RadonSdLane {
   static constexpr int NGRP = NLS_;   // groups owned by a lane (what the host matches against ceil(groups / K))
   static constexpr int DCAP = NG + 2 * K_ * NLS_;
   static constexpr bool HAS_MODES = false;
+  static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = false;
   static constexpr int MINW = 1;
   using Args = RadonSdArgs;
 
   float n[NLS], sx[NLS], sy[NLS], sxx[NLS], sxy[NLS], syy[NLS], u[NLS], a[NLS];
-  int J, slot, ndraw;
+  int J, slot;
   bool last_ok;
 
   static ARP_DEV int gg(int i) { return i; }
@@ -49,7 +50,6 @@ struct RadonSdLane {
     slot = slot_;
     J = A.J;
     last_ok = slot + K * (NLS - 1) < J;
-    ndraw = ND;
 #pragma unroll
     for (int i = 0; i < NLS; ++i) {
       int j = slot + K * i;

@@ -35,22 +35,20 @@ struct SchoolsLane {
   ARP_DEV bool lvalid(int i) const { return i < NL - 1 ? true : last_ok; }
   bool last_ok;
   static constexpr bool HAS_MODES = false;
+  static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = false;
   static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
   using Args = SchoolsArgs;
 
   float y[NL], is2[NL], a[NL], b[NL];
   float s0i, s1i, c0, c1;  // 1/5^b0, 1/5^b1, 5^(1-b0), 5^(1-b1)
-  int nloc, slot, ndraw;
+  int slot;
 
   static ARP_DEV int gg(int i) { return i; }
 
   ARP_DEV void init(const Args& A, const float* av, const float* bv, int slot_) {
     slot = slot_;
-    nloc = (8 - slot + K - 1) / K;
-    if (nloc < 0) nloc = 0;
     last_ok = slot + K * (NL - 1) < 8;
-    ndraw = NG + (8 + K - 1) / K;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       int k = slot + K * i;

@@ -157,6 +157,7 @@ class Engine(object):
         cfg.lanes_per_chain = int(lanes)
         io = _lib.InterleavedIO()
         io.k0.q = _ptr(state.q)
+        io.k0.grad, io.k0.logp = _ptr(state.grad), _ptr(state.logp)   # carried gradient / log density
         io.k0.adapt, io.k0.rng, io.k0.accept_count = _ptr(state.adapt), _ptr(state.rng), _ptr(state.accept_count)
         self._eps0 = self._dev(eps0_0)
         self._eps1 = self._dev(eps0_1)

@@ -137,7 +137,8 @@ int arp_hmc_run(arp_model* m, int which, const arp_hmc_config* cfg,
  * parameterisation 0 then 1 per step, each with its own leapfrog count, base
  * step sizes and adaptation state; `q` is kept in parameterisation-0 coordinates. */
 typedef struct arp_interleaved_io {
-  arp_hmc_io k0;             /* q/rng/trace live here; grad/logp unused (re-bootstrapped every step) */
+  arp_hmc_io k0;             /* q/rng/trace live here; grad/logp are optional: kernels that carry the gradient across the
+                                change of coordinates keep it there between calls (NULL: re-bootstrap at every call) */
   float* adapt1;             /* [C][4] adaptation state of kernel 1 */
   uint32_t* accept_count1;   /* [C] */
   const float* eps0_1;       /* [D] */
