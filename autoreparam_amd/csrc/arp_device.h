@@ -51,8 +51,10 @@ ARP_DEV float group_bcast0(float v, int slot) {
 }
 
 // ---------------------------------------------------------------------------
-// RNG.  Each (chain, slot) owns one xoshiro128++ stream (Blackman & Vigna,
-// public domain algorithm) whose 128-bit state is seeded once per run by
+// RNG.  Each (chain, slot) owns one xoshiro128+ stream (Blackman & Vigna, public
+// domain algorithm; the variant its authors recommend for 32-bit floating-point
+// generation, whose upper bits are what the conversions below consume) whose
+// 128-bit state is seeded once per run by
 // Philox4x32-10 (Salmon et al., SC'11) keyed on the user seed with counter
 // (global chain id, slot, lanes_per_chain).  The stream therefore depends on the
 // global chain id only, never on which GPU or workgroup runs the chain.
@@ -64,7 +66,7 @@ struct Rng {
 ARP_DEV uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
 
 ARP_DEV uint32_t rng_next(Rng& r) {
-  uint32_t result = rotl32(r.s0 + r.s3, 7) + r.s0;
+  uint32_t result = r.s0 + r.s3;
   uint32_t t = r.s1 << 9;
   r.s2 ^= r.s0;
   r.s3 ^= r.s1;
@@ -106,9 +108,11 @@ ARP_DEV float u01_open0(uint32_t w) { return (float)((w >> 8) + 1u) * 5.96046447
 
 // Two standard normals from two 32-bit words (Box-Muller on the hardware
 // transcendental units: v_log_f32 is log2, v_sin/v_cos take revolutions).
+// u = (float)w0 * 2^-32 + 2^-33 lies in (0, 1] after rounding, the angle (float)w1 * 2^-32 in [0, 1]
+// revolutions (1 == 0 for sin/cos): one conversion and one multiply-add each, no shifts.
 ARP_DEV void normal_pair(uint32_t w0, uint32_t w1, float& z0, float& z1) {
-  float u = u01_open0(w0);
-  float rev = (float)(w1 >> 8) * 5.9604644775390625e-08f;  // [0,1) revolutions
+  float u = fmaf((float)w0, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+  float rev = (float)w1 * 2.3283064365386963e-10f;
   // r = sqrt(-2 ln u) = sqrt(-2 ln2 * log2 u)
   float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));
   z0 = r * __builtin_amdgcn_cosf(rev);

@@ -51,14 +51,14 @@ typedef struct orc_hmc_cfg {
   int lanes;
 } orc_hmc_cfg;
 
-/* ---- RNG: xoshiro128++ streams seeded by Philox4x32-10 (DESIGN.md "Randomness") ---- */
+/* ---- RNG: xoshiro128+ streams seeded by Philox4x32-10 (DESIGN.md "Randomness") ---- */
 typedef struct { uint32_t s[4]; } orc_rng;
 
 static uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
 
 static uint32_t orc_rng_next(orc_rng* r) {
   uint32_t* s = r->s;
-  uint32_t result = rotl32(s[0] + s[3], 7) + s[0];
+  uint32_t result = s[0] + s[3];   /* xoshiro128+ */
   uint32_t t = s[1] << 9;
   s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
   s[2] ^= t;
@@ -87,10 +87,11 @@ static orc_rng orc_rng_seed(uint64_t seed, uint64_t chain, uint32_t slot, uint32
   return r;
 }
 
-/* Box-Muller: u in (0,1] from the top 24 bits of w0, angle from the top 24 bits of w1 */
+/* Box-Muller: u = (float)w0 2^-32 + 2^-33 in (0,1], angle (float)w1 2^-32 revolutions
+ * (uint32 -> float conversions round to nearest even, as v_cvt_f32_u32 does) */
 static void orc_normal_pair(uint32_t w0, uint32_t w1, float* z0, float* z1) {
-  float u = (float)((w0 >> 8) + 1u) * 5.9604644775390625e-08f;
-  float rev = (float)(w1 >> 8) * 5.9604644775390625e-08f;
+  float u = fmaf((float)w0, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+  float rev = (float)w1 * 2.3283064365386963e-10f;
   float r = sqrtf(-1.3862943611198906f * log2f(u));
   float ang = 6.283185307179586f * rev;
   *z0 = r * cosf(ang);

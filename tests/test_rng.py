@@ -1,5 +1,5 @@
 """CPU: known-answer and distribution tests of the sampler's RNG specification
-(Philox4x32-10 seeding, xoshiro128++ streams, Box-Muller normals)."""
+(Philox4x32-10 seeding, xoshiro128+ streams, Box-Muller normals)."""
 import ctypes as C
 
 import numpy as np
@@ -19,14 +19,14 @@ def test_philox_known_answers(oracle_lib):
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
-def _xoshiro128pp(state, n):
-    """Independent restatement (python ints) of Blackman & Vigna's xoshiro128++."""
+def _xoshiro128p(state, n):
+    """Independent restatement (python ints) of Blackman & Vigna's xoshiro128+."""
     s = list(state)
     M = 0xffffffff
     rotl = lambda x, k: ((x << k) | (x >> (32 - k))) & M
     out = []
     for _ in range(n):
-        out.append((rotl((s[0] + s[3]) & M, 7) + s[0]) & M)
+        out.append((s[0] + s[3]) & M)
         t = (s[1] << 9) & M
         s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]
         s[2] ^= t
@@ -40,7 +40,7 @@ def test_stream_is_philox_seeded_xoshiro(oracle_lib):
     oracle_lib.lib().orc_stream(C.c_uint64(seed), C.c_uint64(chain), C.c_uint32(slot), C.c_uint32(lanes), 64,
                                 out.ctypes.data_as(C.c_void_p))
     st = _philox(oracle_lib, [chain & 0xffffffff, chain >> 32, slot, lanes], [seed & 0xffffffff, seed >> 32])
-    assert [int(v) for v in out] == _xoshiro128pp(st, 64)
+    assert [int(v) for v in out] == _xoshiro128p(st, 64)
 
 
 def test_streams_differ_by_chain_slot_and_seed(oracle_lib):
@@ -67,4 +67,4 @@ def test_normals_moments(oracle_lib):
     # the two outputs of a pair are uncorrelated, and so are successive pairs
     assert abs(np.corrcoef(z[0::2], z[1::2])[0, 1]) < 4 / np.sqrt(n_pairs)
     assert abs(np.corrcoef(z[:-2:2], z[2::2])[0, 1]) < 4 / np.sqrt(n_pairs)
-    assert np.abs(z).max() < 6.0  # 24-bit uniform: |z| <= sqrt(2*24*ln2) = 5.77
+    assert np.abs(z).max() < 6.8  # u >= 2^-33: |z| <= sqrt(2*33*ln2) = 6.76
