@@ -296,7 +296,7 @@ ARP_DEV void adapt_update(const HmcParams& P, long long n, float la,
 template <class Lane, int MODE = kModeVIP>
 __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
     typename Lane::Args A, const float* __restrict__ av, const float* __restrict__ bv, HmcParams P) {
-  constexpr int K = Lane::K, ND = Lane::ND, NG = Lane::NG;
+  constexpr int K = Lane::K, ND = Lane::ND;
   long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
   const int slot = (int)(t % K);
   long long c = t / K;

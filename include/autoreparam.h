@@ -99,7 +99,7 @@ typedef struct arp_hmc_io {
   const float* eps0;         /* [D] base step size per element (VI posterior std / (L/4)^2, inference.py:212-216) */
   float* trace;              /* [S][C][D] or NULL */
   uint8_t* trace_accept;     /* [S][C] is_accepted of recorded transitions, or NULL */
-  float* moments;            /* [C][2][D] running sum / sum of squares of centred post-burn-in states, or NULL */
+  float* moments;            /* reserved, must be NULL (streaming moments are accumulated by the host from trace chunks) */
 } arp_hmc_io;
 
 int arp_version(void);
