@@ -10,7 +10,7 @@ for d in ("a","b"):
     for f in glob.glob("$OUT/%s/*/*counter_collection.csv"%d):
         acc=collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "interleaved_kernel" in r["Kernel_Name"] or "hmc_kernel" in r["Kernel_Name"]:
+            if ("interleaved_kernel" in r["Kernel_Name"] or "hmc_kernel" in r["Kernel_Name"]) and int(r["Grid_Size"]) >= 262144:
                 acc[(r["Kernel_Name"][:60],r["Counter_Name"])].append(float(r["Counter_Value"]))
         for k,v in sorted(acc.items()): print(k[0][10:52],k[1],"%.4g"%(sum(v)/len(v)),"n=%d"%len(v))
 PY
