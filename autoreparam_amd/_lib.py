@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libautoreparam_hip.so")
 
 MODEL_EIGHT_SCHOOLS, MODEL_RADON, MODEL_GERMAN_CREDIT, MODEL_ELECTION, MODEL_RADON_STDDVS = 0, 1, 2, 3, 4
 MODEL_NEALS_FUNNEL = 5
+MODEL_ELECTRIC = 6
 ADAPT_NONE, ADAPT_DUAL, ADAPT_SIMPLE = 0, 1, 2
 RNG_SLOTS = 16  # rng buffer is [C][16][4] uint32
 
@@ -23,7 +24,7 @@ class Dataset(C.Structure):
     _fields_ = [("model", C.c_int32), ("n_obs", C.c_int32), ("n_groups", C.c_int32),
                 ("n_features", C.c_int32),
                 ("group_host", _i32p), ("u_host", _f32p), ("x_host", _f32p), ("x2_host", _f32p),
-                ("y_host", _f32p), ("X_host", _f32p)]
+                ("y_host", _f32p), ("X_host", _f32p), ("group2_host", _i32p), ("group3_host", _i32p)]
 
 
 class HmcConfig(C.Structure):

@@ -48,6 +48,7 @@ static const std::vector<LaneOps>* family(const arp_model* m) {
     case ARP_MODEL_GERMAN_CREDIT: return &german_ops();
     case ARP_MODEL_RADON_STDDVS: return &radon_sd_ops();
     case ARP_MODEL_NEALS_FUNNEL: return &funnel_ops();
+    case ARP_MODEL_ELECTRIC: return &electric_ops();
     default: return nullptr;
   }
 }
@@ -59,6 +60,7 @@ static const void* family_args(const arp_model* m) {
     case ARP_MODEL_GERMAN_CREDIT: return &m->german;
     case ARP_MODEL_RADON_STDDVS: return &m->radon_sd;
     case ARP_MODEL_NEALS_FUNNEL: return &m->funnel;
+    case ARP_MODEL_ELECTRIC: return &m->electric;
     default: return nullptr;
   }
 }
@@ -211,6 +213,65 @@ static int build_german(arp_model* m, const arp_dataset* d) {
   return 0;
 }
 
+// reference models.py:1011-1046: group = pair, group2 = grade, group3 = grade_pair (all 1-based, fed to
+// tf.one_hot as they are), x = treatment, y = scores.  Observations collapse to (pair, treatment) cells.
+static int build_electric(arp_model* m, const arp_dataset* d) {
+  const int P = d->n_groups, N = d->n_obs, G = d->n_features;
+  if (!d->group_host || !d->group2_host || !d->group3_host || !d->x_host || !d->y_host || P <= 0 || N <= 0) {
+    set_error("electric: group(pair)/group2(grade)/group3(grade_pair)/x(treatment)/y and n_groups/n_obs are required");
+    return 1;
+  }
+  if (G != kElG) { set_error("electric: n_features (n_grade = n_grade_pair) must be 4"); return 1; }
+  const int R = P + 1;   // group P: observations whose pair index falls on the all-zero one-hot row
+  std::vector<double> n(2 * (size_t)R, 0.0), sy(2 * (size_t)R, 0.0), syy(2 * (size_t)R, 0.0);
+  std::vector<int> grade(R, -1);
+  for (int i = 0; i < N; ++i) {
+    int j = d->group_host[i];
+    if (j < 0 || j >= P) j = P;
+    int g = d->group2_host[i];
+    if (g < 0 || g >= G) g = G;   // zero row: b = 0, scale exp(0)
+    const float t = d->x_host[i];
+    if (t != 0.0f && t != 1.0f) { set_error("electric: treatment must be a 0/1 indicator for the cell collapse"); return 1; }
+    if (grade[j] >= 0 && grade[j] != g) {
+      set_error("electric: the observations of one pair must share a grade for the cell collapse");
+      return 1;
+    }
+    grade[j] = g;
+    const size_t c = (size_t)(t != 0.0f) * R + j;
+    const double y = d->y_host[i];
+    n[c] += 1; sy[c] += y; syy[c] += y * y;
+  }
+  m->D = 3 * G + P; m->n_groups = R;
+  m->host_tables.assign(13 * (size_t)R, 0.0f);
+  float* T = m->host_tables.data();
+  for (int j = 0; j < R; ++j) {
+    if (j < P) {
+      const int k = d->group3_host[j];
+      if (k >= 0 && k < G) T[(size_t)k * R + j] = 100.0f;
+    }
+    if (grade[j] >= 0 && grade[j] < G) T[(size_t)(4 + grade[j]) * R + j] = 1.0f;
+    double ss = 0;
+    for (int t = 0; t < 2; ++t) {
+      const size_t c = (size_t)t * R + j;
+      const double mean = n[c] > 0 ? sy[c] / n[c] : 0.0;
+      T[(size_t)(8 + 2 * t) * R + j] = (float)n[c];
+      T[(size_t)(9 + 2 * t) * R + j] = (float)mean;
+      ss += syy[c] - n[c] * mean * mean;
+    }
+    T[(size_t)12 * R + j] = (float)(ss > 0 ? ss : 0.0);
+  }
+  if (upload_tables(m)) return 1;
+  float* t = m->dev_tables;
+  m->electric.wm = t; m->electric.og = t + 4 * (size_t)R;
+  m->electric.n0 = t + 8 * (size_t)R; m->electric.y0 = t + 9 * (size_t)R;
+  m->electric.n1 = t + 10 * (size_t)R; m->electric.y1 = t + 11 * (size_t)R;
+  m->electric.ss = t + 12 * (size_t)R;
+  m->electric.P = P;
+  m->const_base = -(double)(m->D + N) * kHalfLog2Pi;
+  for (int k = 0; k < G; ++k) m->top_scale.push_back({2 * G + P + k, log(100.0)});
+  return 0;
+}
+
 }  // namespace arp
 
 using namespace arp;
@@ -232,6 +293,7 @@ int arp_model_create(const arp_dataset* data, arp_model** out) {
     case ARP_MODEL_ELECTION: rc = build_election(m.get(), data); break;
     case ARP_MODEL_GERMAN_CREDIT: rc = build_german(m.get(), data); break;
     case ARP_MODEL_RADON_STDDVS: rc = build_radon_sd(m.get(), data); break;
+    case ARP_MODEL_ELECTRIC: rc = build_electric(m.get(), data); break;
     case ARP_MODEL_NEALS_FUNNEL:   // models.py:671-696: no data
       m->D = 2; m->n_groups = 1; m->const_base = -2.0 * kHalfLog2Pi; m->top_scale = {{0, log(3.0)}};
       rc = 0; break;

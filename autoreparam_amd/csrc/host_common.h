@@ -14,6 +14,7 @@
 #include "model_german.h"
 #include "model_radon_stddvs.h"
 #include "model_funnel.h"
+#include "model_electric.h"
 
 namespace arp {
 
@@ -101,6 +102,7 @@ const std::vector<LaneOps>& election_ops();
 const std::vector<LaneOps>& german_ops();
 const std::vector<LaneOps>& radon_sd_ops();
 const std::vector<LaneOps>& funnel_ops();
+const std::vector<LaneOps>& electric_ops();
 
 }  // namespace arp
 
@@ -120,6 +122,7 @@ struct arp_model {
   arp::GermanArgs german{};
   arp::RadonSdArgs radon_sd{};
   arp::FunnelArgs funnel{};
+  arp::ElectricArgs electric{};
   std::vector<float> host_tables;
   double const_base = 0.0;                       // parameterisation independent part of the dropped constant
   std::vector<std::pair<int, double>> top_scale; // (flattened index, log prior scale) of top-level latents

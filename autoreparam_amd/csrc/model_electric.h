@@ -1,0 +1,186 @@
+// Electric company (reference models.py:1011-1066) under the general VIP
+// parameterisation.  Parts in trace order: mua[4], sigma_y[4], a[P], b[4].
+//
+//   mua_k ~ N(0,1), sigma_y_k ~ N(0,1)     unit scale: every (a,b) is the identity
+//   a_j ~ N(mu_j, 1), mu_j = 100 mua[grade_pair_j]:   at_j ~ N(al_j mu_j, 1), a_j = at_j + (1 - al_j) mu_j
+//   b_k ~ N(0,100)                          top level: bt_k ~ N(0, 100^be_k), b_k = 100^(1-be_k) bt_k
+//   y_i ~ N(a[pair_i] + b[grade_i] treatment_i, exp(sigma_y[grade_i]))
+//
+// pair, grade and grade_pair are 1-based in the data and the reference feeds them to
+// tf.one_hot unchanged, so index n falls on an all-zero row: pair P has no pair effect
+// (group P below: observations only, no latent), grade 4 has b = 0 and scale exp(0) = 1,
+// grade_pair 4 gives mu_j = 0, and a[0], mua[0], sigma_y[0], b[0] see the prior only.
+//
+// The observations of one pair share a grade g (checked by the host) and treatment is a
+// 0/1 indicator, so a group collapses to two cells (control, treated) with count n_t,
+// mean ybar_t and the pooled within-cell sum of squares SS:
+//   sum_i (y_i - a - b t_i)^2 = n_0 (ybar_0 - a)^2 + n_1 (ybar_1 - a - b)^2 + SS =: Q
+//   loglik_j = -(n_0 + n_1) s_g - w Q / 2,  w = exp(-2 s_g)
+//   d/da = w (n_0 r_0 + n_1 r_1),  d/db_g = w n_1 r_1,  d/ds_g = w Q - (n_0 + n_1)
+// The grade look-ups and scatters are one-hot FMAs against the replicated grade scalars.
+#pragma once
+#include "arp_device.h"
+
+namespace arp {
+
+constexpr int kElG = 4;   // grades (n_grade = n_grade_pair = 4 in the reference's data)
+
+struct ElectricArgs {
+  // all tables are [P+1] (group P = observations without a pair effect), wm/og are [4][P+1]
+  const float* wm;    // 100 * one_hot(grade_pair_j): location weights of a_j on mua
+  const float* og;    // one_hot(grade of the group's observations)
+  const float* n0; const float* y0; const float* n1; const float* y1; const float* ss;
+  int P;
+};
+
+template <int K_, int NL_>
+struct ElectricLane {
+  static constexpr int K = K_;
+  static constexpr int NG = 3 * kElG;  // mua[4], sigma_y[4], b[4]
+  static constexpr int NL = NL_;       // groups owned by this lane: j = slot + K*i, j <= P
+  static constexpr int ND = NG + NL;
+  static constexpr int NGRP = NL_;
+  static constexpr int DCAP = NG + K_ * NL_;
+  static constexpr int LBASE = 2 * kElG;
+  ARP_DEV int lbase(int) const { return LBASE + slot; }
+  static constexpr ARP_DEV int loff(int i) { return K * i; }
+  ARP_DEV int lidx(int i) const { return LBASE + slot + K * i; }
+  // only the last slice can be padding: NL == ceil(groups / K) is enforced by the host
+  ARP_DEV bool lvalid(int i) const { return i < NL - 1 ? true : last_ok; }
+  bool last_ok;
+  static constexpr bool HAS_MODES = false;
+  static constexpr bool HAS_CARRY = false;
+  static constexpr bool HAS_FUSED = false;
+  static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
+  using Args = ElectricArgs;
+
+  float wm[NL][kElG], og[NL][kElG], n0[NL], y0[NL], n1[NL], y1[NL], ss[NL], al[NL], lat[NL];
+  float si[kElG], cs[kElG];   // 1/100^b and 100^(1-b) of b_k
+  int slot, P;
+
+  // flattened index of replicated scalar i: mua, sigma_y in front of a[P], b behind it
+  ARP_DEV int gg(int i) const { return i < 2 * kElG ? i : i + P; }
+
+  ARP_DEV void init(const Args& A, const float* av, const float* bv, int slot_) {
+    slot = slot_;
+    P = A.P;
+    last_ok = slot + K * (NL - 1) < P;   // latent validity (j < P); group j == P has no latent
+    const int stride = P + 1;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int j = slot + K * i;
+      const bool has = j <= P;
+#pragma unroll
+      for (int k = 0; k < kElG; ++k) {
+        wm[i][k] = has ? A.wm[k * stride + j] : 0.0f;
+        og[i][k] = has ? A.og[k * stride + j] : 0.0f;
+      }
+      n0[i] = has ? A.n0[j] : 0.0f; y0[i] = has ? A.y0[j] : 0.0f;
+      n1[i] = has ? A.n1[j] : 0.0f; y1[i] = has ? A.y1[j] : 0.0f;
+      ss[i] = has ? A.ss[j] : 0.0f;
+      lat[i] = j < P ? 1.0f : 0.0f;
+    }
+    set_param(av, bv);
+  }
+  ARP_DEV void set_param(const float* av, const float* bv) {
+    const float l100 = 6.643856189774724f;  // log2(100)
+#pragma unroll
+    for (int k = 0; k < kElG; ++k) {
+      si[k] = __builtin_amdgcn_exp2f(-bv[LBASE + P + k] * l100);
+      cs[k] = 100.0f * si[k];
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) al[i] = lvalid(i) ? av[LBASE + slot + K * i] : 0.0f;
+  }
+
+  template <bool LOGP>
+  ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const {
+    float bb[kElG], dM[kElG], dS[kElG], dB[kElG];
+#pragma unroll
+    for (int k = 0; k < kElG; ++k) { bb[k] = cs[k] * q[2 * kElG + k]; dM[k] = 0.0f; dS[k] = 0.0f; dB[k] = 0.0f; }
+    float lp = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float mu = 0.0f, sg = 0.0f, bg = 0.0f;
+#pragma unroll
+      for (int k = 0; k < kElG; ++k) {
+        mu = fmaf(wm[i][k], q[k], mu);
+        sg = fmaf(og[i][k], q[kElG + k], sg);
+        bg = fmaf(og[i][k], bb[k], bg);
+      }
+      const float r = fmaf(-al[i], mu, q[NG + i]);   // group P / padding: q = 0, al = 0, wm = 0 -> r = 0
+      const float aj = r + mu;
+      const float w = fast_exp(-2.0f * sg);
+      const float r0 = y0[i] - aj, r1 = (y1[i] - aj) - bg;
+      const float e0 = n0[i] * r0, e1 = n1[i] * r1;
+      const float dA = w * (e0 + e1);
+      const float Q = fmaf(e0, r0, fmaf(e1, r1, ss[i]));
+      const float nn = n0[i] + n1[i];
+      const float dSv = fmaf(w, Q, -nn);
+      const float dBv = w * e1;
+      const float ga = lat[i] * (dA - r);
+      g[NG + i] = ga;
+      const float hm = fmaf(-al[i], ga, dA);   // d / d mu_j
+#pragma unroll
+      for (int k = 0; k < kElG; ++k) {
+        dM[k] = fmaf(wm[i][k], hm, dM[k]);
+        dS[k] = fmaf(og[i][k], dSv, dS[k]);
+        dB[k] = fmaf(og[i][k], dBv, dB[k]);
+      }
+      if (LOGP) lp += fmaf(-0.5f * r, r, fmaf(-0.5f * w, Q, -nn * sg));
+    }
+    float pri = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kElG; ++k) {
+      const float u = q[2 * kElG + k] * si[k];
+      g[k] = group_sum<K>(dM[k]) - q[k];
+      g[kElG + k] = group_sum<K>(dS[k]) - q[kElG + k];
+      g[2 * kElG + k] = fmaf(cs[k], group_sum<K>(dB[k]), -u * si[k]);
+      if (LOGP) pri += fmaf(q[k], q[k], fmaf(q[kElG + k], q[kElG + k], u * u));
+    }
+    if (LOGP) lp = group_sum<K>(lp) - 0.5f * pri;
+    return lp;
+  }
+
+  // d logp / d a, d logp / d b from the state gradient (see model_radon.h): only a_j has a
+  // location parent and only b_k a non-unit scale
+  ARP_DEV void dparam(const float (&q)[ND], const float (&g)[ND], float (&da)[ND], float (&db)[ND]) const {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) { da[i] = 0.0f; db[i] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < kElG; ++k)
+      db[2 * kElG + k] = -4.605170185988092f * fmaf(q[2 * kElG + k], g[2 * kElG + k], 1.0f);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float mu = 0.0f;
+#pragma unroll
+      for (int k = 0; k < kElG; ++k) mu = fmaf(wm[i][k], q[k], mu);
+      da[NG + i] = lvalid(i) ? -mu * g[NG + i] : 0.0f;
+    }
+  }
+
+  ARP_DEV void to_centered(const float (&q)[ND], float (&x)[ND]) const {
+#pragma unroll
+    for (int k = 0; k < kElG; ++k) { x[k] = q[k]; x[kElG + k] = q[kElG + k]; x[2 * kElG + k] = cs[k] * q[2 * kElG + k]; }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float mu = 0.0f;
+#pragma unroll
+      for (int k = 0; k < kElG; ++k) mu = fmaf(wm[i][k], q[k], mu);
+      x[NG + i] = fmaf(1.0f - al[i], mu, q[NG + i]);
+    }
+  }
+  ARP_DEV void from_centered(const float (&x)[ND], float (&q)[ND]) const {
+#pragma unroll
+    for (int k = 0; k < kElG; ++k) { q[k] = x[k]; q[kElG + k] = x[kElG + k]; q[2 * kElG + k] = x[2 * kElG + k] / cs[k]; }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float mu = 0.0f;
+#pragma unroll
+      for (int k = 0; k < kElG; ++k) mu = fmaf(wm[i][k], x[k], mu);
+      q[NG + i] = lvalid(i) ? fmaf(-(1.0f - al[i]), mu, x[NG + i]) : 0.0f;
+    }
+  }
+};
+
+}  // namespace arp

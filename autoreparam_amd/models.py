@@ -105,6 +105,12 @@ class ModelSpec(object):
             d.y_host = f32(r["y"])
         elif self.model_id == _lib.MODEL_NEALS_FUNNEL:
             pass
+        elif self.model_id == _lib.MODEL_ELECTRIC:
+            if int(r["n_grade"]) != int(r["n_grade_pair"]):
+                raise ValueError("electric: n_grade and n_grade_pair must agree")
+            d.n_obs = len(r["y"]); d.n_groups = int(r["n_pair"]); d.n_features = int(r["n_grade"])
+            d.group_host = i32(r["pair"]); d.group2_host = i32(r["grade"]); d.group3_host = i32(r["grade_pair"])
+            d.x_host = f32(r["treatment"]); d.y_host = f32(r["y"])
         elif self.model_id == _lib.MODEL_GERMAN_CREDIT:
             d.n_obs = r["X"].shape[0]; d.n_features = r["X"].shape[1]
             d.X_host = f32(r["X"]); d.y_host = f32(r["y"])
@@ -146,6 +152,14 @@ def _spec_funnel():
     return ModelSpec("neals_funnel", _lib.MODEL_NEALS_FUNNEL, ["x1", "x2"], [(), ()], {}, {})
 
 
+def _spec_electric():
+    """electric company (reference models.py:1011-1066); `a` keeps the reference's [n_pair, 1] shape."""
+    r = _load("electric.npz")
+    P, G = int(r["n_pair"]), int(r["n_grade"])
+    return ModelSpec("electric", _lib.MODEL_ELECTRIC, ["mua", "sigma_y", "a", "b"],
+                     [(int(r["n_grade_pair"]),), (G,), (P, 1), (G,)], r, {"y": r["y"]})
+
+
 def _spec_german():
     r = _load("german_credit.npz")
     F = r["X"].shape[1]
@@ -171,13 +185,15 @@ def get_model_by_name(model_name, dataset=None):
         spec = _spec_funnel()
     elif model_name == "radon_stddvs":
         spec = _spec_radon_stddvs(dataset if dataset else "MN")
+    elif model_name == "electric":
+        spec = _spec_electric()
     elif model_name == "german_credit_lognormalcentered":
         spec = _spec_german()
     elif model_name in ("election", "election88"):
         spec = _spec_election()
     else:
-        raise Exception("unknown model {} (this build covers 8schools, radon, "
-                        "radon_stddvs, neals_funnel, german_credit_lognormalcentered, election)".format(model_name))
+        raise Exception("unknown model {} (this build covers 8schools, radon, radon_stddvs, "
+                        "neals_funnel, electric, german_credit_lognormalcentered, election)".format(model_name))
     from . import engine  # deferred: converters run on the device
 
     varnames = spec.part_names

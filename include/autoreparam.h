@@ -38,7 +38,8 @@ enum {
   ARP_MODEL_GERMAN_CREDIT = 2, /* german_credit_lognormalcentered */
   ARP_MODEL_ELECTION = 3,
   ARP_MODEL_NEALS_FUNNEL = 5, /* models.py:671-696; no dataset fields are read */
-  ARP_MODEL_RADON_STDDVS = 4  /* radon with per-county observation scales, models.py:763-806 */
+  ARP_MODEL_RADON_STDDVS = 4, /* radon with per-county observation scales, models.py:763-806 */
+  ARP_MODEL_ELECTRIC = 6      /* electric company, models.py:1011-1066 */
 };
 
 /* Step-size adaptation wrapped around the HMC transition. */
@@ -53,14 +54,16 @@ enum {
 typedef struct arp_dataset {
   int32_t model;        /* ARP_MODEL_* */
   int32_t n_obs;        /* N */
-  int32_t n_groups;     /* radon: J counties; election: n_state; schools: 8 */
-  int32_t n_features;   /* german: 62 */
-  const int32_t* group_host;   /* [N] radon county (0-based) / election state (1-based, as the reference feeds tf.one_hot) */
+  int32_t n_groups;     /* radon: J counties; election: n_state; schools: 8; electric: n_pair */
+  int32_t n_features;   /* german: 62; electric: n_grade (= n_grade_pair, at most 4) */
+  const int32_t* group_host;   /* [N] radon county (0-based) / election state / electric pair (both 1-based, as the reference feeds tf.one_hot) */
   const float* u_host;         /* radon: [J] log uranium; schools: [8] treatment stddevs */
-  const float* x_host;         /* radon: [N] floor; election: [N] female */
+  const float* x_host;         /* radon: [N] floor; election: [N] female; electric: [N] treatment (0/1) */
   const float* x2_host;        /* election: [N] black */
   const float* y_host;         /* [N] observations (Bernoulli outcomes as 0/1 floats); schools: [8] effects */
   const float* X_host;         /* german: [N][n_features] row-major design matrix */
+  const int32_t* group2_host;  /* electric: [N] grade (1-based, as fed to tf.one_hot) */
+  const int32_t* group3_host;  /* electric: [n_groups] grade_pair (1-based) */
 } arp_dataset;
 
 typedef struct arp_model arp_model; /* opaque: frozen data + sufficient statistics, on one device */

@@ -10,7 +10,7 @@ here).
 
 Restated from (behaviour, not code):
   models.py:139-147 (schools), 826-837 (radon), 888-904 (german credit),
-  969-982 (election);
+  969-982 (election), 1013-1035 (electric);
   program_transformations.py:110-139 (log joint = sum of rv.log_prob over all
   RVs and elements), 262-279 (ncp: every Normal not named y*), 486-533 + 555-600
   (VIP: xt ~ N(a mu, sigma^b), x = mu + sigma/sigma^b (xt - a mu); missing `_b`
@@ -154,7 +154,25 @@ def election_program(r, raw):
     r.bernoulli("y", y_hat)
 
 
-PROGRAMS = {"8schools": schools_program, "radon": radon_program, "radon_stddvs": radon_stddvs_program, "neals_funnel": funnel_program,
+def electric_program(r, raw):
+    # models.py:1013-1035: pair, grade and grade_pair are all fed 1-based to tf.one_hot
+    n_pair, n_grade, n_gp = int(raw["n_pair"]), int(raw["n_grade"]), int(raw["n_grade_pair"])
+    C_pair = one_hot(raw["pair"], n_pair)
+    C_grade = one_hot(raw["grade"], n_grade)
+    C_gp = one_hot(raw["grade_pair"], n_gp)
+    mua = r.normal("mua", 0.0, torch.ones(n_gp, dtype=F64))
+    mua_hat = 100.0 * (C_gp @ mua.unsqueeze(1))                     # [n_pair, 1]
+    sigma_y = r.normal("sigma_y", 0.0, torch.ones(n_grade, dtype=F64))
+    sigma_y_hat = C_grade @ sigma_y.unsqueeze(1)                    # [N, 1]
+    a = r.normal("a", mua_hat, 1.0)                                 # [n_pair, 1]
+    b = r.normal("b", 0.0, 100.0 * torch.ones(n_grade, dtype=F64))
+    y_hat_a = (C_pair @ a).reshape(-1)
+    y_hat_b = (C_grade @ b.unsqueeze(1)).reshape(-1)
+    y_hat = y_hat_a + y_hat_b * _t(raw["treatment"])
+    r.normal("y", y_hat, torch.exp(sigma_y_hat.reshape(-1)))
+
+
+PROGRAMS = {"electric": electric_program, "8schools": schools_program, "radon": radon_program, "radon_stddvs": radon_stddvs_program, "neals_funnel": funnel_program,
             "german_credit_lognormalcentered": german_program, "election": election_program}
 
 

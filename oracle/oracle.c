@@ -8,7 +8,7 @@
  * bench.py's cpu_baseline leg; the product path (autoreparam_amd/) never links
  * or calls it.  PARITY UNPINNED (see oracle_impl.h).
  *
- * Reference files restated: models.py:131-166, 809-857, 884-923, 967-1008
+ * Reference files restated: models.py:131-166, 671-696, 763-857, 884-923, 967-1066
  * (densities), program_transformations.py:262-279, 555-600 (NCP / VIP algebra),
  * inference.py:198-242 (HMC wiring, step scaling, thinning),
  * interleaved.py:113-155 (interleaving order).  TFP internals (leapfrog,
@@ -27,7 +27,7 @@ typedef struct orc_model {
   int n_groups;    /* sliced axis length (RNG stream layout) */
   int n_local_parts; /* latent parts sliced along that axis (german: beta_log_scales and beta) */
   int contig;      /* 1: slot s owns consecutive elements s*per_lane + i (german); 0: s + lanes*i */
-  int glob_idx[8]; /* flattened index of each top-level scalar */
+  int glob_idx[16]; /* flattened index of each top-level scalar */
   int* group_idx;  /* [n_local_parts][n_groups] flattened index of element j, -1 if it has no latent */
   /* radon sufficient statistics */
   int J;
@@ -38,6 +38,11 @@ typedef struct orc_model {
    * election: cell tables [(S+1)][4] indexed (state, female + 2*black). */
   int S, F, N;
   float *y, *X, *cell_n, *cell_y;
+  /* electric: raw observations; pair / grade / grade_pair are the reference's 1-based values, used
+   * as 0-based one-hot columns (out of range = all-zero row).  P = n_pair, G = n_grade. */
+  int P, G;
+  int *pair, *grade, *grade_pair;
+  float* treat;
   double logp_const;   /* value dropped from logp under CP (tests add the (a,b)-dependent part) */
 } orc_model;
 
@@ -215,6 +220,28 @@ orc_model* orc_election_create(int N, int S, const int32_t* state, const float* 
   return M;
 }
 
+/* reference models.py:1011-1046.  Parts: mua[G], sigma_y[G], a[P], b[G]. */
+orc_model* orc_electric_create(int N, int P, int G, const int32_t* pair, const int32_t* grade,
+                               const int32_t* grade_pair, const float* treatment, const float* y) {
+  if (G > 4) return NULL;
+  orc_model* M = (orc_model*)calloc(1, sizeof(orc_model));
+  M->model = 6; M->N = N; M->P = P; M->G = G; M->D = 3 * G + P;
+  /* RNG stream layout: the 3G grade-level scalars are replicated, `a` is sliced; the extra group P
+   * stands for the observations whose pair index falls outside the one-hot (no latent) */
+  M->n_glob = 3 * G; M->n_groups = P + 1; M->n_local_parts = 1;
+  for (int k = 0; k < G; ++k) { M->glob_idx[k] = k; M->glob_idx[G + k] = G + k; M->glob_idx[2 * G + k] = 2 * G + P + k; }
+  M->group_idx = (int*)malloc(sizeof(int) * (P + 1));
+  for (int j = 0; j < P; ++j) M->group_idx[j] = 2 * G + j;
+  M->group_idx[P] = -1;
+  M->pair = (int*)malloc(sizeof(int) * N); M->grade = (int*)malloc(sizeof(int) * N);
+  M->grade_pair = (int*)malloc(sizeof(int) * P);
+  M->treat = (float*)malloc(sizeof(float) * N); M->y = (float*)malloc(sizeof(float) * N);
+  for (int i = 0; i < N; ++i) { M->pair[i] = pair[i]; M->grade[i] = grade[i]; M->treat[i] = treatment[i]; M->y[i] = y[i]; }
+  for (int j = 0; j < P; ++j) M->grade_pair[j] = grade_pair[j];
+  M->logp_const = -(double)(M->D + N) * HALF_LOG_2PI - G * log(100.0);
+  return M;
+}
+
 orc_model* orc_german_create(int N, int F, const float* X, const float* y) {
   orc_model* M = (orc_model*)calloc(1, sizeof(orc_model));
   M->model = 2; M->N = N; M->F = F; M->D = 1 + 2 * F;
@@ -234,6 +261,7 @@ void orc_model_destroy(orc_model* M) {
   free(M->group_idx); free(M->n); free(M->sx); free(M->sy); free(M->u);
   free(M->y); free(M->X); free(M->cell_n); free(M->cell_y);
   free(M->sxx_j); free(M->sxy_j); free(M->syy_j);
+  free(M->pair); free(M->grade); free(M->grade_pair); free(M->treat);
   free(M);
 }
 int orc_model_dim(const orc_model* M) { return M->D; }

@@ -320,6 +320,75 @@ static void FN(funnel_convert)(const orc_model* M, const float* a, const float* 
   else { out[0] = x[0] / c1; out[1] = x[1] * (REAL)exp(-0.5 * (1.0 - (double)b[1]) * (double)x[0]); }
 }
 
+/* electric company, reference models.py:1013-1035.  Parts: mua[G], sigma_y[G], a[P], b[G].
+ *   mua_k ~ N(0,1), sigma_y_k ~ N(0,1)   (unit scale: every (a,b) is the identity)
+ *   a_j ~ N(mu_j, 1), mu_j = 100 mua[grade_pair_j]:  at_j ~ N(al_j mu_j, 1), a_j = at_j + (1 - al_j) mu_j
+ *   b_k ~ N(0,100):  bt_k ~ N(0, 100^be_k), b_k = 100^(1-be_k) bt_k
+ *   y_i ~ N(a[pair_i] + b[grade_i] treatment_i, exp(sigma_y[grade_i]))
+ * All three index vectors are 1-based in the data and used as 0-based one-hot columns, so index
+ * n hits an all-zero row: pair 96 has no pair effect, grade 4 has b = 0 and scale exp(0) = 1,
+ * grade_pair 4 gives mu_j = 0; a[0], mua[0], sigma_y[0] and b[0] are informed by the prior only. */
+static REAL FN(electric_logp_grad)(const orc_model* M, const float* a, const float* b,
+                                   const REAL* x, REAL* g) {
+  const int P = M->P, G = M->G, N = M->N;
+  const int iS = G, iA = 2 * G, iB = 2 * G + P;
+  REAL mu[P], dA[P], bb[4], cb[4], sb[4], dB[4] = {0, 0, 0, 0}, dS[4] = {0, 0, 0, 0}, dM[4] = {0, 0, 0, 0};
+  REAL lp = 0;
+  for (int k = 0; k < G; ++k) {
+    sb[k] = (REAL)pow(100.0, (double)b[iB + k]);
+    cb[k] = 100 / sb[k];
+    bb[k] = cb[k] * x[iB + k];
+    lp += -(REAL)0.5 * (x[k] * x[k] + x[iS + k] * x[iS + k] + (x[iB + k] / sb[k]) * (x[iB + k] / sb[k]));
+  }
+  for (int j = 0; j < P; ++j) {
+    const int k = M->grade_pair[j];
+    mu[j] = (k >= 0 && k < G) ? 100 * x[k] : 0;
+    dA[j] = 0;
+  }
+  for (int i = 0; i < N; ++i) {
+    const int j = M->pair[i], k = M->grade[i];
+    const int hasj = j >= 0 && j < P, hask = k >= 0 && k < G;
+    const REAL aj = hasj ? mu[j] + x[iA + j] - (REAL)a[iA + j] * mu[j] : 0;
+    const REAL bk = hask ? bb[k] : 0, sk = hask ? x[iS + k] : 0;
+    const REAL t = M->treat[i];
+    const REAL w = (REAL)exp(-2.0 * (double)sk);
+    const REAL r = (REAL)M->y[i] - aj - bk * t;
+    lp += -sk - (REAL)0.5 * w * r * r;
+    if (hasj) dA[j] += w * r;
+    if (hask) { dB[k] += t * w * r; dS[k] += w * r * r - 1; }
+  }
+  for (int j = 0; j < P; ++j) {
+    const REAL al = a[iA + j];
+    const REAL r = x[iA + j] - al * mu[j];
+    lp += -(REAL)0.5 * r * r;
+    const REAL ga = dA[j] - r;
+    g[iA + j] = ga;
+    const int k = M->grade_pair[j];
+    if (k >= 0 && k < G) dM[k] += 100 * (dA[j] - al * ga);
+  }
+  for (int k = 0; k < G; ++k) {
+    g[k] = -x[k] + dM[k];
+    g[iS + k] = -x[iS + k] + dS[k];
+    g[iB + k] = -x[iB + k] / (sb[k] * sb[k]) + cb[k] * dB[k];
+  }
+  return lp;
+}
+static void FN(electric_convert)(const orc_model* M, const float* a, const float* b, const REAL* x,
+                                 REAL* out, int to_centered) {
+  const int P = M->P, G = M->G, iA = 2 * G, iB = 2 * G + P;
+  for (int k = 0; k < 2 * G; ++k) out[k] = x[k];
+  for (int k = 0; k < G; ++k) {
+    const REAL c = (REAL)pow(100.0, 1.0 - (double)b[iB + k]);
+    out[iB + k] = to_centered ? c * x[iB + k] : x[iB + k] / c;
+  }
+  for (int j = 0; j < P; ++j) {
+    const int k = M->grade_pair[j];
+    const REAL mu = (k >= 0 && k < G) ? 100 * x[k] : 0;
+    const REAL sh = (1 - (REAL)a[iA + j]) * mu;
+    out[iA + j] = to_centered ? x[iA + j] + sh : x[iA + j] - sh;
+  }
+}
+
 /* dispatch */
 static REAL FN(logp_grad)(const orc_model* M, const float* a, const float* b, const REAL* x, REAL* g) {
   switch (M->model) {
@@ -329,6 +398,7 @@ static REAL FN(logp_grad)(const orc_model* M, const float* a, const float* b, co
     case 3: return FN(election_logp_grad)(M, a, b, x, g);
     case 4: return FN(radon_sd_logp_grad)(M, a, b, x, g);
     case 5: return FN(funnel_logp_grad)(M, a, b, x, g);
+    case 6: return FN(electric_logp_grad)(M, a, b, x, g);
     default: return (REAL)NAN;
   }
 }
@@ -340,6 +410,7 @@ static void FN(to_centered)(const orc_model* M, const float* a, const float* b, 
     case 3: FN(election_convert)(M, a, b, x, o, 1); break;
     case 4: FN(radon_sd_convert)(M, a, b, x, o, 1); break;
     case 5: FN(funnel_convert)(M, a, b, x, o, 1); break;
+    case 6: FN(electric_convert)(M, a, b, x, o, 1); break;
     default: break;
   }
 }
@@ -351,6 +422,7 @@ static void FN(from_centered)(const orc_model* M, const float* a, const float* b
     case 3: FN(election_convert)(M, a, b, x, o, 0); break;
     case 4: FN(radon_sd_convert)(M, a, b, x, o, 0); break;
     case 5: FN(funnel_convert)(M, a, b, x, o, 0); break;
+    case 6: FN(electric_convert)(M, a, b, x, o, 0); break;
     default: break;
   }
 }
@@ -636,6 +708,13 @@ static void FN(dparam)(const orc_model* M, const float* a, const float* b, const
     case 3: ls[0] = (REAL)log(100.0); ls[1] = (REAL)log(10.0);
       ls[2 + M->S] = ls[3 + M->S] = (REAL)log(100.0);
       for (int t = 0; t < M->S; ++t) { mu[2 + t] = xc[0]; ls[2 + t] = xc[1]; } break;
+    case 6:
+      for (int k = 0; k < M->G; ++k) ls[2 * M->G + M->P + k] = (REAL)log(100.0);
+      for (int j = 0; j < M->P; ++j) {
+        const int k = M->grade_pair[j];
+        mu[2 * M->G + j] = (k >= 0 && k < M->G) ? 100 * xc[k] : 0;
+      }
+      break;
     default: break;
   }
   for (int d = 0; d < D; ++d) {

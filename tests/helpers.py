@@ -11,6 +11,7 @@ MODEL_SPECS = {
     "radon_sd_MN": lambda: models._spec_radon_stddvs("MN"),
     "funnel": lambda: models._spec_funnel(),
     "election": lambda: models._spec_election(),
+    "electric": lambda: models._spec_electric(),
 }
 _cache = {}
 

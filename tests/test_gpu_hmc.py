@@ -8,7 +8,7 @@ import torch
 import helpers
 
 pytestmark = pytest.mark.gpu
-LANES = {"8schools": [1, 8], "radon_MN": [4, 8, 16], "radon_PA": [4, 8, 16], "election": [4, 8, 16], "german": [4, 8, 16], "radon_sd_MN": [8, 16], "funnel": [1]}
+LANES = {"8schools": [1, 8], "radon_MN": [4, 8, 16], "radon_PA": [4, 8, 16], "election": [4, 8, 16], "german": [4, 8, 16], "radon_sd_MN": [8, 16], "funnel": [1], "electric": [16]}
 
 
 def _eng(mname, gpu):
@@ -55,7 +55,7 @@ def _compare(oracle_lib, gpu, mname, kind, lanes, adapt_kind, frac, L, n, n_adap
     return err, terr, st, so, ta.cpu().numpy(), tao
 
 
-@pytest.mark.parametrize("mname", ["8schools", "radon_MN", "radon_PA", "election", "german", "radon_sd_MN", "funnel"])
+@pytest.mark.parametrize("mname", ["8schools", "radon_MN", "radon_PA", "election", "german", "radon_sd_MN", "funnel", "electric"])
 @pytest.mark.parametrize("kind", ["CP", "NCP", "VIP"])
 def test_trajectories_match_oracle_fixed_step(oracle_lib, gpu, mname, kind):
     """Fixed step (the parity configuration of north_star): per-chain trajectories
@@ -176,7 +176,7 @@ def test_full_size_headline_invariants(gpu):
     np.testing.assert_allclose(m[:3], (1.3389, -0.0480, -0.1026), atol=0.01)
 
 
-@pytest.mark.parametrize("mname", ["8schools", "radon_PA", "election", "german", "radon_sd_MN", "funnel"])
+@pytest.mark.parametrize("mname", ["8schools", "radon_PA", "election", "german", "radon_sd_MN", "funnel", "electric"])
 def test_interleaved_matches_oracle(oracle_lib, gpu, mname):
     """Interleaved CP/NCP kernel (interleaved.py:113-155) against the float32 oracle:
     fixed small step sizes during the compared stretch, simple adaptation on."""

@@ -14,6 +14,8 @@ What is restated (behaviour, not code) and where it comes from:
                   blocks per categorical column, in column order).
   * election88 -- reference models.py:984-989 reading data/election88.py.
   * 8schools   -- constants at reference models.py:134-137.
+  * electric   -- reference models.py:1038-1046 reading data/electric.py (pair, grade and
+                  grade_pair stay 1-based, exactly as they are fed to tf.one_hot).
 
 Pandas semantics are version sensitive, which is why
 the result is frozen rather than re-derived per run.
@@ -103,6 +105,22 @@ def election():
                 y=np.asarray(d["y"], dtype=np.int32))
 
 
+def electric():
+    spec = importlib.util.spec_from_file_location(
+        "_el", os.path.join(REF, "electric.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    d = mod.data
+    assert d["N"] == len(d["y"]) and d["n_pair"] == len(d["grade_pair"])
+    return dict(n_pair=np.int32(d["n_pair"]), n_grade=np.int32(d["n_grade"]),
+                n_grade_pair=np.int32(d["n_grade_pair"]),
+                pair=np.asarray(d["pair"], dtype=np.int32),              # 1-based, kept as is
+                grade=np.asarray(d["grade"], dtype=np.int32),            # 1-based
+                grade_pair=np.asarray(d["grade_pair"], dtype=np.int32),  # 1-based
+                treatment=np.asarray(d["treatment"], dtype=np.float32),
+                y=np.asarray(d["y"], dtype=np.float32))
+
+
 def schools():
     return dict(y=np.array([28, 8, -3, 7, -1, 1, 18, 12], dtype=np.float32),
                 sigma=np.array([15, 10, 16, 11, 9, 11, 10, 18], dtype=np.float32))
@@ -128,6 +146,9 @@ def main():
     print("election N", e["y"].shape[0])
     np.savez_compressed(os.path.join(args.out, "election88.npz"), **e)
     np.savez_compressed(os.path.join(args.out, "eight_schools.npz"), **schools())
+    el = electric()
+    print("electric N", el["y"].shape[0], "pairs", int(el["n_pair"]))
+    np.savez_compressed(os.path.join(args.out, "electric.npz"), **el)
 
 
 if __name__ == "__main__":
