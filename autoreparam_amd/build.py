@@ -11,6 +11,7 @@ OUT = os.path.join(HERE, "libautoreparam_hip.so")
 OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fno-slp-vectorize", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("ARP_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DNAME for a timing variant)
 
 
 def _sources():

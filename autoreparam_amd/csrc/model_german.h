@@ -42,7 +42,7 @@ struct GermanLane {
   static constexpr bool HAS_MODES = false;
   static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = false;
-  static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
+  static constexpr int MINW = K_ >= 8 ? 2 : 1;   // waves per SIMD the register allocator must leave room for
   using Args = GermanArgs;
 
   float a[NLS], b[NLS];     // a of bls_d, b of beta_d (the only ones that matter)
@@ -74,32 +74,47 @@ struct GermanLane {
     }
   }
 
-  template <bool LOGP>
-  ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const {
-    __shared__ float tile[kGermanTile * kGermanCols];
-    __shared__ float ytile[kGermanTile];
-    const float ols = c0 * q[0];
-    float beta[NLS], v[NLS], bls[NLS], r[NLS];
-#pragma unroll
-    for (int i = 0; i < NLS; ++i) {
-      r[i] = fmaf(-a[i], ols, q[NG + i]);
-      bls[i] = r[i] + ols;
-      beta[i] = fast_exp((1.0f - b[i]) * bls[i]) * q[NG + NLS + i];   // padding: q = 0 -> beta = 0
-      v[i] = 0.0f;
-    }
-    float lp = 0.0f;
+  // LDS row stride of the design-matrix tile.  The matrix-core path (K = 4) pads rows to 68 floats:
+  // both of its operand reads (16 consecutive rows x one float4, and 4 rows x 16 consecutive
+  // columns per lane group) then fall on distinct banks.
+  static constexpr int kStride = K_ == 4 ? kGermanCols + 4 : kGermanCols;
+  static constexpr int kXchWaves = 8;                 // waves per workgroup the exchange area covers (VI: 512 threads)
+  static constexpr int kXch = 16 * kStride + 64;      // per wave: [16 chains][row] + 64 log-density partials
+  static constexpr int kTileFloats = kGermanTile * kStride + kGermanTile + (K_ == 4 ? kXchWaves * kXch : 0);
+  // The [rows x 64] design-matrix tile and its outcomes, shared by the workgroup (one copy per
+  // kernel: both instantiations of grad<> go through this function).
+  static ARP_DEV float* tile_mem() {
+    __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
+    return tile;
+  }
+
+  // Cooperative, coalesced float4 copy of tile `n0`; rows past N are zero filled (x = 0 adds
+  // nothing to the gradient; the log density masks them).
+  ARP_DEV void fill_tile(float* tile, int n0) const {
+    const int rows = min(kGermanTile, N - n0);
+    const float4* src = reinterpret_cast<const float4*>(X + (size_t)n0 * kGermanCols);
+    float4* dst = reinterpret_cast<float4*>(tile);
     const int nthreads = blockDim.x;
+    for (int t = threadIdx.x; t < kGermanTile * (kGermanCols / 4); t += nthreads)
+      dst[(t >> 4) * (kStride / 4) + (t & 15)] = t < rows * (kGermanCols / 4) ? src[t] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float* ytile = tile + kGermanTile * kStride;
+    if ((int)threadIdx.x < kGermanTile) ytile[threadIdx.x] = (int)threadIdx.x < rows ? y[n0 + threadIdx.x] : 0.0f;
+  }
+
+  // Likelihood pass, any K: every lane forms its partial logit of one observation, the K partials
+  // are summed with a DPP butterfly and all K lanes evaluate the same sigmoid.
+  template <bool LOGP>
+  ARP_DEV float likelihood_generic(const float (&beta)[NLS], float (&v)[NLS]) const {
+    float* tile = tile_mem();
+    const float* ytile = tile + kGermanTile * kStride;
+    float lp = 0.0f;
     for (int n0 = 0; n0 < N; n0 += kGermanTile) {
       __syncthreads();   // previous tile fully consumed
-      const int rows = min(kGermanTile, N - n0);
-      // cooperative, coalesced float4 copy of `rows` x 64 floats
-      const float4* src = reinterpret_cast<const float4*>(X + (size_t)n0 * kGermanCols);
-      float4* dst = reinterpret_cast<float4*>(tile);
-      for (int t = threadIdx.x; t < rows * (kGermanCols / 4); t += nthreads) dst[t] = src[t];
-      if ((int)threadIdx.x < rows) ytile[threadIdx.x] = y[n0 + threadIdx.x];
+      fill_tile(tile, n0);
       __syncthreads();
+      const int rows = min(kGermanTile, N - n0);
       for (int n = 0; n < rows; ++n) {
-        const float* xr = tile + n * kGermanCols + slot * NLS;
+        const float* xr = tile + n * kStride + slot * NLS;
         float x[NLS];
 #pragma unroll
         for (int i = 0; i < NLS; ++i) x[i] = xr[i];
@@ -117,7 +132,293 @@ struct GermanLane {
         if (LOGP) lp += fmaf(yn, eta, -(fmaxf(eta, 0.0f) + fast_log(1.0f + ex)));
       }
     }
-    // every lane of the chain accumulated the same likelihood value
+    return lp;   // every lane of the chain accumulated the same value
+  }
+
+  // Likelihood pass for K = 8 (8 features per lane), four observations at a time.  The two quads
+  // of a chain split the four rows: a lane calls the two rows its quad finishes `a` and the other
+  // two `b`.  It forms partial logits of all four (packed FMAs), hands the `b` partials to its
+  // mirror lane in the other quad (which calls those rows `a`), sums the `a` partials over its quad,
+  // evaluates two sigmoids instead of four, and fetches the other two residuals from the mirror
+  // lane again: 6 DPP adds + 2 DPP moves + 2 sigmoids per 4 observations instead of 12 + 4.
+  // The rows of the next block are fetched from LDS while the current one is processed.
+  // (The LDS reads are issued as inline asm so that they stay where they are written -- a whole
+  // block ahead of their use; left to the scheduler they sink next to the first use to save
+  // registers and every block then waits out the LDS latency.  lgkmcnt returns in order for LDS,
+  // so waiting until at most the newest block's 9 reads are outstanding completes the older block.)
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  struct Rows4 {
+    v4f a[2][2], b[2][2];   // rows `a` / `b`, features [0,4) and [4,8) of this lane's slice
+    v2f y;                  // outcomes of the two `a` rows
+  };
+  static ARP_DEV uint32_t lds_offset(const float* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+  }
+  ARP_DEV void load_rows(uint32_t tile_off, int nb, int half, Rows4& R) const {
+    const uint32_t pa = tile_off + (uint32_t)((nb + 2 * half) * kGermanCols + slot * NLS) * 4u;
+    const uint32_t pb = tile_off + (uint32_t)((nb + 2 * (1 - half)) * kGermanCols + slot * NLS) * 4u;
+    const uint32_t py = tile_off + (uint32_t)(kGermanTile * kGermanCols + nb + 2 * half) * 4u;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(R.a[0][0]) : "v"(pa));
+    asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(R.a[0][1]) : "v"(pa));
+    asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(R.a[1][0]) : "v"(pa));
+    asm volatile("ds_read_b128 %0, %1 offset:272" : "=v"(R.a[1][1]) : "v"(pa));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(R.b[0][0]) : "v"(pb));
+    asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(R.b[0][1]) : "v"(pb));
+    asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(R.b[1][0]) : "v"(pb));
+    asm volatile("ds_read_b128 %0, %1 offset:272" : "=v"(R.b[1][1]) : "v"(pb));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(R.y) : "v"(py));
+  }
+  // all reads of R have landed once at most `newer` younger LDS reads are outstanding
+  template <int NEWER>
+  static ARP_DEV void wait_rows(Rows4& R) {
+    static_assert(NEWER == 0 || NEWER == 9, "one block = 9 LDS reads");
+    if (NEWER == 9)
+      asm volatile("s_waitcnt lgkmcnt(9)"
+                   : "+v"(R.a[0][0]), "+v"(R.a[0][1]), "+v"(R.a[1][0]), "+v"(R.a[1][1]), "+v"(R.b[0][0]),
+                     "+v"(R.b[0][1]), "+v"(R.b[1][0]), "+v"(R.b[1][1]), "+v"(R.y));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(R.a[0][0]), "+v"(R.a[0][1]), "+v"(R.a[1][0]), "+v"(R.a[1][1]), "+v"(R.b[0][0]),
+                     "+v"(R.b[0][1]), "+v"(R.b[1][0]), "+v"(R.b[1][1]), "+v"(R.y));
+  }
+  template <bool LOGP>
+  ARP_DEV void use_rows(const Rows4& R, const v2f (&b2)[4], v2f (&v2)[4], float& lp, int ra, int rows) const {
+    float wa[2], wb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const v2f xa[4] = {R.a[j][0].xy, R.a[j][0].zw, R.a[j][1].xy, R.a[j][1].zw};
+      const v2f xb[4] = {R.b[j][0].xy, R.b[j][0].zw, R.b[j][1].xy, R.b[j][1].zw};
+      v2f sa = xa[0] * b2[0], sb = xb[0] * b2[0];
+#pragma unroll
+      for (int i = 1; i < 4; ++i) { sa = vfma(xa[i], b2[i], sa); sb = vfma(xb[i], b2[i], sb); }
+      float eta = (sa.x + sa.y) + dpp_mov<0x141>(sb.x + sb.y);   // row_half_mirror: lane 7-s, the other quad
+      eta += dpp_mov<0xB1>(eta);
+      eta += dpp_mov<0x4E>(eta);
+      const float ex = fast_exp(-fabsf(eta));
+      const float rc = __builtin_amdgcn_rcpf(1.0f + ex);
+      const float sg = eta >= 0.0f ? rc : ex * rc;
+      const float yj = j ? R.y.y : R.y.x;
+      wa[j] = yj - sg;
+      if (LOGP) {
+        const float t = fmaf(yj, eta, -(fmaxf(eta, 0.0f) + fast_log(1.0f + ex)));
+        lp += ra + j < rows ? t : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wb[j] = dpp_mov<0x141>(wa[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const v2f xa[4] = {R.a[j][0].xy, R.a[j][0].zw, R.a[j][1].xy, R.a[j][1].zw};
+      const v2f xb[4] = {R.b[j][0].xy, R.b[j][0].zw, R.b[j][1].xy, R.b[j][1].zw};
+      const v2f wa2 = v2f{wa[j], wa[j]}, wb2 = v2f{wb[j], wb[j]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v2[i] = vfma(xa[i], wa2, v2[i]); v2[i] = vfma(xb[i], wb2, v2[i]); }
+    }
+  }
+  template <bool LOGP>
+  ARP_DEV float likelihood_k8(const float (&beta)[NLS], float (&v)[NLS]) const {
+    static_assert(NLS == 8, "K = 8 owns 8 features per lane");
+    float* tile = tile_mem();
+    const uint32_t tile_off = lds_offset(tile);
+    const int half = (slot >> 2) & 1;
+    v2f b2[4], v2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { b2[i] = v2f{beta[2 * i], beta[2 * i + 1]}; v2[i] = v2f{0.0f, 0.0f}; }
+    float lp = 0.0f;
+    for (int n0 = 0; n0 < N; n0 += kGermanTile) {
+      __syncthreads();   // previous tile fully consumed
+      fill_tile(tile, n0);
+      __syncthreads();
+      const int rows = min(kGermanTile, N - n0);
+      Rows4 A, B;
+      load_rows(tile_off, 0, half, A);
+      for (int nb = 0; nb < rows; nb += 8) {   // the tile is zero filled up to its 64 rows
+        load_rows(tile_off, nb + 4, half, B);
+        wait_rows<9>(A);
+        use_rows<LOGP>(A, b2, v2, lp, nb + 2 * half, rows);
+        load_rows(tile_off, (nb + 8) & (kGermanTile - 1), half, A);
+        wait_rows<9>(B);
+        use_rows<LOGP>(B, b2, v2, lp, nb + 4 + 2 * half, rows);
+      }
+      wait_rows<0>(A);   // drain the look-ahead read before the tile is overwritten
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = v2[i].x; v[2 * i + 1] = v2[i].y; }
+    // the four lanes of a quad accumulated the same two rows per block: add the two quads
+    if (LOGP) lp += dpp_mov<0x141>(lp);
+    return lp;
+  }
+
+  // Likelihood pass for K = 4 on the matrix cores.  A wave holds 16 chains; logits = X beta is
+  // a [obs x 64] x [64 x 16 chains] product and v = X^T (y - sigmoid(logits)) a
+  // [64 x obs] x [obs x 16 chains] one, both with f32 inputs and f32 accumulation
+  // (v_mfma_f32_16x16x4_f32: exact f32 FMAs at the vector FMA rate, but X is read from LDS once
+  // per 16 chains instead of once per chain, every (observation, chain) sigmoid is evaluated
+  // exactly once, and the VALU is left to the sigmoids).
+  //   state layout : lane 4c+t   holds beta[16t .. 16t+15] of chain c
+  //   MFMA layout  : lane 16g+j  supplies B[k = g][col = chain j]; a 16 x 16 result has
+  //                  col = chain j on the lane and rows 4g .. 4g+3 in its 4 registers
+  // beta moves to the MFMA layout (and v back) through a per-wave LDS area, once per gradient.
+  // Forward, per 16 rows: 16 steps of k = 4, step s taking column 16g+s from lane group g (the
+  // order of a sum is free as long as A and B agree).  The residuals come out with rows 4g+r in
+  // register r, which is exactly the B operand of the backward product if its step s takes
+  // row 4g+s from lane group g: no movement between the two products.
+  // one tile in flight between global memory and LDS (at most 4 float4 per thread at 256 threads)
+  struct TileRegs {
+    float4 x[4];
+    float y;
+  };
+  ARP_DEV void fetch_tile(int n0, TileRegs& T) const {
+    const int rows = min(kGermanTile, N - n0);
+    const float4* src = reinterpret_cast<const float4*>(X + (size_t)n0 * kGermanCols);
+    const int nthreads = blockDim.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = threadIdx.x + k * nthreads;
+      T.x[k] = t < rows * (kGermanCols / 4) ? src[t] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    T.y = (int)threadIdx.x < rows ? y[n0 + threadIdx.x] : 0.0f;
+  }
+  ARP_DEV void store_tile(float* tile, const TileRegs& T) const {
+    float4* dst = reinterpret_cast<float4*>(tile);
+    const int nthreads = blockDim.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = threadIdx.x + k * nthreads;
+      if (t < kGermanTile * (kGermanCols / 4)) dst[(t >> 4) * (kStride / 4) + (t & 15)] = T.x[k];
+    }
+    if ((int)threadIdx.x < kGermanTile) tile[kGermanTile * kStride + threadIdx.x] = T.y;
+  }
+  // A operand of the forward product for rows r0 .. r0+15: lane (g, j) takes row r0+j, columns 16g .. 16g+15
+  static ARP_DEV void load_a(const float* tile, int r0, int gk, int j, float (&xa)[16]) {
+    const float4* pa = reinterpret_cast<const float4*>(tile + (r0 + j) * kStride + 16 * gk);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 f = pa[i];
+      xa[4 * i] = f.x; xa[4 * i + 1] = f.y; xa[4 * i + 2] = f.z; xa[4 * i + 3] = f.w;
+    }
+  }
+  // logits of 16 rows x 16 chains; two accumulation chains (a dependent MFMA waits 40 cycles,
+  // independent ones issue every 32)
+  static ARP_DEV v4f forward16(const float (&xa)[16], const float (&bB)[16]) {
+    v4f e0 = v4f{0.0f, 0.0f, 0.0f, 0.0f}, e1 = e0;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; s_ += 2) {
+      e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s_], bB[s_], e0, 0, 0, 0);
+      e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s_ + 1], bB[s_ + 1], e1, 0, 0, 0);
+    }
+    return e0 + e1;
+  }
+
+  template <bool LOGP>
+  ARP_DEV float likelihood_mfma(const float (&beta)[NLS], float (&v)[NLS]) const {
+    static_assert(NLS == 16, "K = 4 owns 16 features per lane");
+    float* tile = tile_mem();
+    const float* ytile = tile + kGermanTile * kStride;
+    const int lane = threadIdx.x & 63;
+    float* xch = tile + kGermanTile * kStride + kGermanTile + (threadIdx.x >> 6) * kXch;
+    float* lpx = xch + 16 * kStride;
+    const int c = lane >> 2, t = lane & 3;    // state layout (t == slot)
+    const int gk = lane >> 4, j = lane & 15;  // MFMA layout
+    float4* own = reinterpret_cast<float4*>(xch + c * kStride + 16 * t);
+    const float4* mine = reinterpret_cast<const float4*>(xch + j * kStride + 16 * gk);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) own[i] = make_float4(beta[4 * i], beta[4 * i + 1], beta[4 * i + 2], beta[4 * i + 3]);
+    __builtin_amdgcn_wave_barrier();
+    float bB[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 f = mine[i];
+      bB[4 * i] = f.x; bB[4 * i + 1] = f.y; bB[4 * i + 2] = f.z; bB[4 * i + 3] = f.w;
+    }
+    __builtin_amdgcn_wave_barrier();
+    v4f acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    float lp = 0.0f;
+    // one wave per SIMD here: nothing else hides the global-memory latency of a tile, so the
+    // next tile travels through registers while the current one is multiplied
+    TileRegs T;
+    fetch_tile(0, T);
+    for (int n0 = 0; n0 < N; n0 += kGermanTile) {
+      __syncthreads();   // previous tile fully consumed
+      store_tile(tile, T);
+      if (n0 + kGermanTile < N) fetch_tile(n0 + kGermanTile, T);
+      __syncthreads();
+      const int rows = min(kGermanTile, N - n0);
+      // The tile is zero filled up to its 64 rows: always four blocks of 16 rows, software
+      // pipelined so that the sigmoids of block i issue between the forward MFMAs of block i+1.
+      float xa[2][16];
+      v4f eta4[2];
+      load_a(tile, 0, gk, j, xa[0]);
+      load_a(tile, 16, gk, j, xa[1]);
+      eta4[0] = forward16(xa[0], bB);
+#pragma unroll
+      for (int i = 0; i < kGermanTile / 16; ++i) {
+        const int r0 = 16 * i;
+        const float* pb = tile + (r0 + 4 * gk) * kStride + j;
+        float xb[16];
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xb[4 * s_ + k] = pb[s_ * kStride + 16 * k];
+        const float4 y4 = *reinterpret_cast<const float4*>(ytile + r0 + 4 * gk);
+        const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+        if (i + 1 < kGermanTile / 16) eta4[(i + 1) & 1] = forward16(xa[(i + 1) & 1], bB);
+        if (i + 2 < kGermanTile / 16) load_a(tile, r0 + 32, gk, j, xa[i & 1]);
+        float w[4];
+#pragma unroll
+        for (int r_ = 0; r_ < 4; ++r_) {
+          const float eta = eta4[i & 1][r_];
+          if (LOGP) {
+            const float ex = fast_exp(-fabsf(eta));
+            const float rc = __builtin_amdgcn_rcpf(1.0f + ex);
+            w[r_] = yv[r_] - (eta >= 0.0f ? rc : ex * rc);
+            const float tt = fmaf(yv[r_], eta, -(fmaxf(eta, 0.0f) + fast_log(1.0f + ex)));
+            lp += r0 + 4 * gk + r_ < rows ? tt : 0.0f;
+          } else {
+            // 1 / (1 + e^-eta): e^-eta = inf gives 0, no NaN
+            w[r_] = yv[r_] - __builtin_amdgcn_rcpf(1.0f + fast_exp(-eta));
+          }
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[4 * s_ + k], w[s_], acc[k], 0, 0, 0);
+      }
+    }
+    // v back to the state layout: lane (g, j) holds v[16k + 4g + r] of chain j in acc[k][r]
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      *reinterpret_cast<float4*>(xch + j * kStride + 16 * k + 4 * gk) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+    if (LOGP) lpx[lane] = lp;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 f = own[i];
+      v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+    }
+    if (LOGP) lp = (lpx[c] + lpx[16 + c]) + (lpx[32 + c] + lpx[48 + c]);
+    __builtin_amdgcn_wave_barrier();
+    return lp;
+  }
+
+  template <bool LOGP>
+  ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const {
+    const float ols = c0 * q[0];
+    float beta[NLS], v[NLS], bls[NLS], r[NLS];
+#pragma unroll
+    for (int i = 0; i < NLS; ++i) {
+      r[i] = fmaf(-a[i], ols, q[NG + i]);
+      bls[i] = r[i] + ols;
+      beta[i] = fast_exp((1.0f - b[i]) * bls[i]) * q[NG + NLS + i];   // padding: q = 0 -> beta = 0
+      v[i] = 0.0f;
+    }
+    float lp;
+    if constexpr (K == 8) lp = likelihood_k8<LOGP>(beta, v);
+    else if constexpr (K == 4) lp = likelihood_mfma<LOGP>(beta, v);
+    else lp = likelihood_generic<LOGP>(beta, v);
     float lq = 0.0f, g_ols = 0.0f;
 #pragma unroll
     for (int i = 0; i < NLS; ++i) {

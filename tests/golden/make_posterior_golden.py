@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Long float64 CPU runs of the oracle's HMC for the two models without a closed-form
-posterior (election, german credit): posterior means / sds of every coordinate with
-Monte-Carlo standard errors.  Written to posterior_golden.npz and used
-by the GPU tests as the known answer for the sampled posterior."""
+"""Long float64 CPU runs of the oracle's HMC for the models without a closed-form
+posterior (election, german credit, electric): posterior means / sds of every coordinate
+with Monte-Carlo standard errors.  Written to posterior_golden.npz and
+used by the GPU tests as the known answer for the sampled posterior.
+
+`make_posterior_golden.py [model ...]` regenerates only the named models and keeps the
+other entries of the existing file."""
 import os
 import sys
 import time
@@ -37,8 +40,17 @@ def find_mode(orc, sp, a, b, iters=6000, lr=0.02):
     return x, hess_scale(orc, sp, a, b, x)
 
 
+PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "posterior_golden.npz")
+RUNS = (("election", "CP", 8, 256, 1500, 1500), ("german", "NCP", 8, 192, 1500, 1200),
+        ("electric", "NCP", 8, 256, 1500, 1500))
+only = sys.argv[1:]
 out = {}
-for mname, kind, L, C, burn, S in (("election", "CP", 8, 256, 1500, 1500), ("german", "NCP", 8, 192, 1500, 1200)):
+if only and os.path.exists(PATH):
+    with np.load(PATH) as z:
+        out = {k: z[k] for k in z.files}
+for mname, kind, L, C, burn, S in RUNS:
+    if only and mname not in only:
+        continue
     sp = helpers.spec(mname)
     orc = oracle.OracleModel(sp)
     a, b = helpers.params(sp, kind)
@@ -63,4 +75,4 @@ for mname, kind, L, C, burn, S in (("election", "CP", 8, 256, 1500, 1500), ("ger
     h1, h2 = trace[: S // 2].mean(axis=(0, 1)), trace[S // 2:].mean(axis=(0, 1))
     print("   max |first half - second half| / sd = %.3f" % np.abs((h1 - h2) / sd).max())
     assert np.abs((h1 - h2) / sd).max() < 0.25
-np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "posterior_golden.npz"), **out)
+np.savez_compressed(PATH, **out)

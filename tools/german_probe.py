@@ -1,0 +1,13 @@
+"""German credit HMC throughput vs chain count / leapfrog count (lanes = 8)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import model_sweep as ms
+from autoreparam_amd import models
+sp = models._spec_german()
+if len(sys.argv) > 1 and sys.argv[1] == "one":
+    ms.run("german", sp, 16384, 4, 8, "NCP", T=4, eps=0.005)
+    sys.exit(0)
+for C in (8192, 16384, 32768, 65536):
+    ms.run("german", sp, C, 4, 8, "NCP", T=4, eps=0.005)
+ms.run("german", sp, 16384, 16, 8, "NCP", T=2, eps=0.002)

@@ -28,13 +28,30 @@ def run(name, spec, C, L, lanes, reparam="CP", T=16, eps=0.01):
         name, reparam, C, L, lanes, ms, T, C * T * L / (ms * 1e-3), C * T * BT / (ms * 1e-3) / 1e12,
         st.accept_count.float().mean().item() / st.step), flush=True)
 
-for lanes in (1, 2, 4, 8):
-    run("8schools", models._spec_eight_schools(), 65536, 4, lanes, "NCP", eps=0.1)
-for lanes in (4, 8, 16):
-    run("radon_MN", models._spec_radon("MN"), 4096, 4, lanes, eps=0.05)
-for lanes in (4, 8, 16):
-    run("radon_MN", models._spec_radon("MN"), 65536, 4, lanes, eps=0.05)
-for lanes in (4, 8, 16):
-    run("election", models._spec_election(), 131072, 8, lanes, "NCP", eps=0.005)
-for lanes in (4, 8, 16):
-    run("german", models._spec_german(), 16384, 4, lanes, "NCP", T=4, eps=0.005)
+def main():
+    only = sys.argv[1:]
+    if only:   # e.g. `model_sweep.py electric radon_stddvs`
+        if "electric" in only:
+            run("electric", models._spec_electric(), 65536, 8, 16, "NCP", eps=0.01)
+            run("electric", models._spec_electric(), 16384, 8, 16, "NCP", eps=0.01)
+        if "german" in only:
+            for lanes in (4, 8, 16):
+                run("german", models._spec_german(), 16384, 4, lanes, "NCP", T=4, eps=0.005)
+        if "radon_stddvs" in only:
+            for lanes in (8, 16):
+                run("radon_sd", models._spec_radon_stddvs("MN"), 65536, 8, lanes, "NCP", eps=0.01)
+        return
+    for lanes in (1, 2, 4, 8):
+        run("8schools", models._spec_eight_schools(), 65536, 4, lanes, "NCP", eps=0.1)
+    for lanes in (4, 8, 16):
+        run("radon_MN", models._spec_radon("MN"), 4096, 4, lanes, eps=0.05)
+    for lanes in (4, 8, 16):
+        run("radon_MN", models._spec_radon("MN"), 65536, 4, lanes, eps=0.05)
+    for lanes in (4, 8, 16):
+        run("election", models._spec_election(), 131072, 8, lanes, "NCP", eps=0.005)
+    for lanes in (4, 8, 16):
+        run("german", models._spec_german(), 16384, 4, lanes, "NCP", T=4, eps=0.005)
+
+
+if __name__ == "__main__":
+    main()
