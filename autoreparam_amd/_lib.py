@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libautoreparam_hip.so")
+# ARP_LIB_PATH: timing experiments only (a variant built with ARP_HIPCC_FLAGS / ARP_BUILD_TAG)
+LIB_PATH = os.environ.get("ARP_LIB_PATH") or os.path.join(_HERE, "libautoreparam_hip.so")
 
 MODEL_EIGHT_SCHOOLS, MODEL_RADON, MODEL_GERMAN_CREDIT, MODEL_ELECTION, MODEL_RADON_STDDVS = 0, 1, 2, 3, 4
 MODEL_NEALS_FUNNEL = 5

@@ -7,8 +7,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libautoreparam_hip.so")
-OBJ = os.path.join(HERE, "build")
+TAG = os.environ.get("ARP_BUILD_TAG", "")   # experiments only: separate objects and library name
+OUT = os.path.join(HERE, "libautoreparam_hip%s.so" % TAG)
+OBJ = os.path.join(HERE, "build" + TAG)
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fno-slp-vectorize", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("ARP_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DNAME for a timing variant)

@@ -348,6 +348,9 @@ static const LaneOps* select_ops(arp_model* m, int K_req, int C) {
     set_error("lanes_per_chain must be 0,1,2,4,8 or 16");
     return nullptr;
   }
+  // german credit: the 4-lane instantiation runs its likelihood on the matrix cores and beats the
+  // wider ones at every chain count (per workgroup 4x the 8-lane and 17x the 16-lane rate)
+  if (K_req == 0 && m->model == ARP_MODEL_GERMAN_CREDIT) K_req = 4;
   const LaneOps* o = pick(*fam, m->n_groups, K_req, C, m->model != ARP_MODEL_GERMAN_CREDIT);
   if (!o) set_error("no kernel instantiation for this (lanes_per_chain, group count): add <Model>Lane<K, ceil(groups/K)> to the model's inst_*.hip");
   return o;
@@ -471,7 +474,7 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   int Kmax = 0;
   for (const auto& o : *fam) Kmax = std::max(Kmax, o.K);
   const LaneOps* o = pick(*fam, m->n_groups, Kmax, 1 << 30, m->model != ARP_MODEL_GERMAN_CREDIT);
-  if (!o) { set_error("no kernel instantiation covers this group count"); return 1; }
+  if (!o || !o->vi) { set_error("no VI kernel instantiation covers this group count"); return 1; }
   ViParams P;
   P.n_steps = cfg->n_steps; P.n_mc = cfg->n_mc; P.learn_a = cfg->learn_a; P.tied_b = cfg->tied_b; P.D = m->D;
   P.seed = cfg->seed;

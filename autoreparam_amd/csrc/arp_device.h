@@ -8,6 +8,8 @@
 
 namespace arp {
 
+constexpr int kBlock = 256;      // 4 waves per workgroup
+
 // register pair for the packed f32 VALU forms (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32)
 typedef float v2f __attribute__((ext_vector_type(2)));
 ARP_DEV v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }

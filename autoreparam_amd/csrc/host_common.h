@@ -71,8 +71,9 @@ struct Launch {
                        *(const typename Lane::Args*)args, a0, b0, a1, b1, P);
   }
   static void vi(const void* args, const float* a, const float* b, const ViParams& P, int n_lr, hipStream_t s) {
-    hipLaunchKernelGGL(vi_kernel<Lane>, dim3(n_lr), dim3(kViBlock), 0, s,
-                       *(const typename Lane::Args*)args, a, b, P);
+    if constexpr (Lane::HAS_VI)
+      hipLaunchKernelGGL(vi_kernel<Lane>, dim3(n_lr), dim3(kViBlock), 0, s,
+                         *(const typename Lane::Args*)args, a, b, P);
   }
   template <int MODE>
   static void hmc_m(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s) {
@@ -85,7 +86,8 @@ struct Launch {
                        *(const typename Lane::Args*)args, a0, b0, a1, b1, P);
   }
   static LaneOps ops() {
-    LaneOps o{Lane::K, Lane::NGRP, &logp_grad, &transform, &hmc, &interleaved, &vi, nullptr, nullptr, nullptr};
+    LaneOps o{Lane::K, Lane::NGRP, &logp_grad, &transform, &hmc, &interleaved, nullptr, nullptr, nullptr, nullptr};
+    if constexpr (Lane::HAS_VI) o.vi = &vi;
     if constexpr (Lane::HAS_MODES) {
       o.hmc_cp = &hmc_m<kModeCP>;
       o.hmc_ncp = &hmc_m<kModeNCP>;

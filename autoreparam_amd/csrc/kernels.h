@@ -9,7 +9,6 @@
 
 namespace arp {
 
-constexpr int kBlock = 256;      // 4 waves per workgroup
 constexpr int kRngSlots = 16;    // rng buffer stride per chain (max lanes per chain)
 constexpr int kMaxD = 256;       // largest state dimension the chain kernels stage in LDS
 

@@ -40,6 +40,7 @@ struct ElectionLane {
   static constexpr bool HAS_MODES = false;
   static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = true;    // kick_drift below
+  static constexpr bool HAS_VI = true;
   static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
   using Args = ElectionArgs;
 

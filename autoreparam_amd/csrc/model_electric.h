@@ -51,6 +51,7 @@ struct ElectricLane {
   static constexpr bool HAS_MODES = false;
   static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = false;
+  static constexpr bool HAS_VI = true;
   static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
   using Args = ElectricArgs;
 

@@ -20,6 +20,7 @@ struct FunnelLane {
   static constexpr bool HAS_MODES = false;
   static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = false;
+  static constexpr bool HAS_VI = true;
   static constexpr int MINW = 1;
   using Args = FunnelArgs;
 

@@ -21,7 +21,6 @@
 namespace arp {
 
 constexpr int kGermanCols = 64;   // padded row length of the device design matrix
-constexpr int kGermanTile = 64;   // rows per LDS tile
 
 struct GermanArgs {
   const float* X;   // [N][64] row-major, columns >= F are zero
@@ -78,9 +77,13 @@ struct GermanLane {
   // both of its operand reads (16 consecutive rows x one float4, and 4 rows x 16 consecutive
   // columns per lane group) then fall on distinct banks.
   static constexpr int kStride = K_ == 4 ? kGermanCols + 4 : kGermanCols;
-  static constexpr int kXchWaves = 8;                 // waves per workgroup the exchange area covers (VI: 512 threads)
+  // rows per LDS tile: the matrix-core path amortises its two workgroup barriers and the tile hand-over
+  // over 128 rows; the others keep 64 so that two workgroups fit a CU
+  static constexpr int kRows = K_ == 4 ? 128 : 64;
+  static constexpr int kXchWaves = kBlock / 64;       // waves per workgroup the exchange area covers (chain kernels only)
+  static constexpr bool HAS_VI = K_ != 4;   // the VI kernel (512 threads, always run at the widest K) is not built for K = 4
   static constexpr int kXch = 16 * kStride + 64;      // per wave: [16 chains][row] + 64 log-density partials
-  static constexpr int kTileFloats = kGermanTile * kStride + kGermanTile + (K_ == 4 ? kXchWaves * kXch : 0);
+  static constexpr int kTileFloats = kRows * kStride + kRows + (K_ == 4 ? kXchWaves * kXch : 0);
   // The [rows x 64] design-matrix tile and its outcomes, shared by the workgroup (one copy per
   // kernel: both instantiations of grad<> go through this function).
   static ARP_DEV float* tile_mem() {
@@ -91,14 +94,14 @@ struct GermanLane {
   // Cooperative, coalesced float4 copy of tile `n0`; rows past N are zero filled (x = 0 adds
   // nothing to the gradient; the log density masks them).
   ARP_DEV void fill_tile(float* tile, int n0) const {
-    const int rows = min(kGermanTile, N - n0);
+    const int rows = min(kRows, N - n0);
     const float4* src = reinterpret_cast<const float4*>(X + (size_t)n0 * kGermanCols);
     float4* dst = reinterpret_cast<float4*>(tile);
     const int nthreads = blockDim.x;
-    for (int t = threadIdx.x; t < kGermanTile * (kGermanCols / 4); t += nthreads)
+    for (int t = threadIdx.x; t < kRows * (kGermanCols / 4); t += nthreads)
       dst[(t >> 4) * (kStride / 4) + (t & 15)] = t < rows * (kGermanCols / 4) ? src[t] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float* ytile = tile + kGermanTile * kStride;
-    if ((int)threadIdx.x < kGermanTile) ytile[threadIdx.x] = (int)threadIdx.x < rows ? y[n0 + threadIdx.x] : 0.0f;
+    float* ytile = tile + kRows * kStride;
+    if ((int)threadIdx.x < kRows) ytile[threadIdx.x] = (int)threadIdx.x < rows ? y[n0 + threadIdx.x] : 0.0f;
   }
 
   // Likelihood pass, any K: every lane forms its partial logit of one observation, the K partials
@@ -106,13 +109,13 @@ struct GermanLane {
   template <bool LOGP>
   ARP_DEV float likelihood_generic(const float (&beta)[NLS], float (&v)[NLS]) const {
     float* tile = tile_mem();
-    const float* ytile = tile + kGermanTile * kStride;
+    const float* ytile = tile + kRows * kStride;
     float lp = 0.0f;
-    for (int n0 = 0; n0 < N; n0 += kGermanTile) {
+    for (int n0 = 0; n0 < N; n0 += kRows) {
       __syncthreads();   // previous tile fully consumed
       fill_tile(tile, n0);
       __syncthreads();
-      const int rows = min(kGermanTile, N - n0);
+      const int rows = min(kRows, N - n0);
       for (int n = 0; n < rows; ++n) {
         const float* xr = tile + n * kStride + slot * NLS;
         float x[NLS];
@@ -157,7 +160,7 @@ struct GermanLane {
   ARP_DEV void load_rows(uint32_t tile_off, int nb, int half, Rows4& R) const {
     const uint32_t pa = tile_off + (uint32_t)((nb + 2 * half) * kGermanCols + slot * NLS) * 4u;
     const uint32_t pb = tile_off + (uint32_t)((nb + 2 * (1 - half)) * kGermanCols + slot * NLS) * 4u;
-    const uint32_t py = tile_off + (uint32_t)(kGermanTile * kGermanCols + nb + 2 * half) * 4u;
+    const uint32_t py = tile_off + (uint32_t)(kRows * kGermanCols + nb + 2 * half) * 4u;
     asm volatile("ds_read_b128 %0, %1" : "=v"(R.a[0][0]) : "v"(pa));
     asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(R.a[0][1]) : "v"(pa));
     asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(R.a[1][0]) : "v"(pa));
@@ -225,18 +228,18 @@ struct GermanLane {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { b2[i] = v2f{beta[2 * i], beta[2 * i + 1]}; v2[i] = v2f{0.0f, 0.0f}; }
     float lp = 0.0f;
-    for (int n0 = 0; n0 < N; n0 += kGermanTile) {
+    for (int n0 = 0; n0 < N; n0 += kRows) {
       __syncthreads();   // previous tile fully consumed
       fill_tile(tile, n0);
       __syncthreads();
-      const int rows = min(kGermanTile, N - n0);
+      const int rows = min(kRows, N - n0);
       Rows4 A, B;
       load_rows(tile_off, 0, half, A);
       for (int nb = 0; nb < rows; nb += 8) {   // the tile is zero filled up to its 64 rows
         load_rows(tile_off, nb + 4, half, B);
         wait_rows<9>(A);
         use_rows<LOGP>(A, b2, v2, lp, nb + 2 * half, rows);
-        load_rows(tile_off, (nb + 8) & (kGermanTile - 1), half, A);
+        load_rows(tile_off, (nb + 8) & (kRows - 1), half, A);
         wait_rows<9>(B);
         use_rows<LOGP>(B, b2, v2, lp, nb + 4 + 2 * half, rows);
       }
@@ -263,17 +266,18 @@ struct GermanLane {
   // order of a sum is free as long as A and B agree).  The residuals come out with rows 4g+r in
   // register r, which is exactly the B operand of the backward product if its step s takes
   // row 4g+s from lane group g: no movement between the two products.
-  // one tile in flight between global memory and LDS (at most 4 float4 per thread at 256 threads)
+  // one tile in flight between global memory and LDS (kTileF4 float4 per thread at 256 threads)
+  static constexpr int kTileF4 = kRows * (kGermanCols / 4) / kBlock;
   struct TileRegs {
-    float4 x[4];
+    float4 x[kTileF4];
     float y;
   };
   ARP_DEV void fetch_tile(int n0, TileRegs& T) const {
-    const int rows = min(kGermanTile, N - n0);
+    const int rows = min(kRows, N - n0);
     const float4* src = reinterpret_cast<const float4*>(X + (size_t)n0 * kGermanCols);
     const int nthreads = blockDim.x;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kTileF4; ++k) {
       const int t = threadIdx.x + k * nthreads;
       T.x[k] = t < rows * (kGermanCols / 4) ? src[t] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
@@ -283,43 +287,145 @@ struct GermanLane {
     float4* dst = reinterpret_cast<float4*>(tile);
     const int nthreads = blockDim.x;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kTileF4; ++k) {
       const int t = threadIdx.x + k * nthreads;
-      if (t < kGermanTile * (kGermanCols / 4)) dst[(t >> 4) * (kStride / 4) + (t & 15)] = T.x[k];
+      if (t < kRows * (kGermanCols / 4)) dst[(t >> 4) * (kStride / 4) + (t & 15)] = T.x[k];
     }
-    if ((int)threadIdx.x < kGermanTile) tile[kGermanTile * kStride + threadIdx.x] = T.y;
+    if ((int)threadIdx.x < kRows) tile[kRows * kStride + threadIdx.x] = T.y;
   }
-  // A operand of the forward product for rows r0 .. r0+15: lane (g, j) takes row r0+j, columns 16g .. 16g+15
-  static ARP_DEV void load_a(const float* tile, int r0, int gk, int j, float (&xa)[16]) {
-    const float4* pa = reinterpret_cast<const float4*>(tile + (r0 + j) * kStride + 16 * gk);
+  // LDS reads of the matrix-core path, pinned with inline asm a block ahead of their use (see the
+  // note at Rows4: left to the scheduler they sink to the first use and the single wave per SIMD
+  // waits out every LDS round trip with the matrix pipe idle).
+  // A operand of the forward product for rows r0 .. r0+15: lane (g, j) takes row r0+j, columns 16g .. 16g+15.
+  static ARP_DEV void issue_a(uint32_t a_off, v4f (&xa)[4]) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(xa[0]) : "v"(a_off));
+    asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(xa[1]) : "v"(a_off));
+    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(xa[2]) : "v"(a_off));
+    asm volatile("ds_read_b128 %0, %1 offset:48" : "=v"(xa[3]) : "v"(a_off));
+  }
+  // A operand of the backward product for rows r0 .. r0+15: lane (g, j) takes rows r0+4g+s (s < 4),
+  // columns j+16k (k < 4): xb[2s + k/2][k%2]; plus the four outcomes of its rows.
+  static ARP_DEV void issue_y(uint32_t y_off, v4f& y4) { asm volatile("ds_read_b128 %0, %1" : "=v"(y4) : "v"(y_off)); }
+  static ARP_DEV void issue_b(uint32_t b_off, v2f (&xb)[8]) {
+    static_assert(3 * kStride + 48 <= 255, "ds_read2_b32 offsets are 8 bits of dwords");
+#define ARP_RD2(i, o0, o1) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(xb[i]) : "v"(b_off), "n"(o0), "n"(o1))
+    ARP_RD2(0, 0, 16); ARP_RD2(1, 32, 48);
+    ARP_RD2(2, kStride, kStride + 16); ARP_RD2(3, kStride + 32, kStride + 48);
+    ARP_RD2(4, 2 * kStride, 2 * kStride + 16); ARP_RD2(5, 2 * kStride + 32, 2 * kStride + 48);
+    ARP_RD2(6, 3 * kStride, 3 * kStride + 16); ARP_RD2(7, 3 * kStride + 32, 3 * kStride + 48);
+#undef ARP_RD2
+  }
+  // the reads of (y4, xa) / xb have landed once at most NEWER younger LDS reads are outstanding
+  // (LDS reads return in order; y4 is always issued before xa)
+  template <int NEWER>
+  static ARP_DEV void wait_a(v4f (&xa)[4], v4f& y4) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(y4) : "n"(NEWER));
+  }
+  template <int NEWER>
+  static ARP_DEV void wait_y(v4f& y4) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(y4) : "n"(NEWER)); }
+  template <int NEWER>
+  static ARP_DEV void wait_b(v2f (&xb)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]), "+v"(xb[4]), "+v"(xb[5]), "+v"(xb[6]),
+                   "+v"(xb[7])
+                 : "n"(NEWER));
+  }
+  // steps [S0, S1) of the 16 k-steps of a forward product, alternating two accumulation chains
+  // (a dependent MFMA waits 40 cycles, independent ones issue every 32)
+  template <int S0, int S1>
+  static ARP_DEV void forward_steps(const v4f (&xa)[4], const float (&bB)[16], v4f& e0, v4f& e1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 f = pa[i];
-      xa[4 * i] = f.x; xa[4 * i + 1] = f.y; xa[4 * i + 2] = f.z; xa[4 * i + 3] = f.w;
+    for (int s_ = S0; s_ < S1; s_ += 2) {
+      e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s_ >> 2][s_ & 3], bB[s_], e0, 0, 0, 0);
+      e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(s_ + 1) >> 2][(s_ + 1) & 3], bB[s_ + 1], e1, 0, 0, 0);
     }
   }
-  // logits of 16 rows x 16 chains; two accumulation chains (a dependent MFMA waits 40 cycles,
-  // independent ones issue every 32)
-  static ARP_DEV v4f forward16(const float (&xa)[16], const float (&bB)[16]) {
-    v4f e0 = v4f{0.0f, 0.0f, 0.0f, 0.0f}, e1 = e0;
-#pragma unroll
-    for (int s_ = 0; s_ < 16; s_ += 2) {
-      e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s_], bB[s_], e0, 0, 0, 0);
-      e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s_ + 1], bB[s_ + 1], e1, 0, 0, 0);
+  // y - sigmoid(eta) of one row (and its log density term)
+  template <bool LOGP>
+  static ARP_DEV float residual(float eta, float yv, bool valid, float& lp) {
+    if (LOGP) {
+      const float ex = fast_exp(-fabsf(eta));
+      const float rc = __builtin_amdgcn_rcpf(1.0f + ex);
+      const float tt = fmaf(yv, eta, -(fmaxf(eta, 0.0f) + fast_log(1.0f + ex)));
+      lp += valid ? tt : 0.0f;
+      return yv - (eta >= 0.0f ? rc : ex * rc);
     }
-    return e0 + e1;
+    // 1 / (1 + e^-eta): e^-eta = inf gives 0, no NaN
+    return yv - __builtin_amdgcn_rcpf(1.0f + fast_exp(-eta));
+  }
+  // step s of the backward product: four feature blocks, independent accumulators
+  static ARP_DEV void backward_step(const v2f (&xb)[8], int s_, float w, v4f (&acc)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[2 * s_ + (k >> 1)][k & 1], w, acc[k], 0, 0, 0);
+  }
+
+  // Block I (rows 16 I .. 16 I + 15) of a tile, see likelihood_mfma.  Program order:
+  //   issue  B(I) (backward operands), Y(I+1) (outcomes), A(I+2) (forward operands)
+  //   R1     forward MFMAs of block I+1 with the four residuals of block I spread between them
+  //          (one wave per SIMD: a VALU run longer than the ~24 spare issue cycles of an MFMA
+  //          leaves the matrix pipe idle, so the scheduler is told to alternate 1 MFMA : 2 VALU)
+  //   R2     backward MFMAs of block I
+  template <bool LOGP, int I>
+  static ARP_DEV void mfma_block(uint32_t a_off, uint32_t b_off, uint32_t y_off, int gk, int rows,
+                                 const float (&bB)[16], v4f (&xa)[2][4], v2f (&xb)[8], v4f (&y4)[2],
+                                 v4f (&e0)[2], v4f (&e1)[2], v4f (&acc)[4], float& lp) {
+    constexpr int r0 = 16 * I, cur = I & 1, nxt = (I + 1) & 1;
+    constexpr bool F1 = I + 1 < kRows / 16, F2 = I + 2 < kRows / 16;
+    const int row = r0 + 4 * gk;   // rows of a lane's four residuals: row + r
+    issue_b(b_off + r0 * kStride * 4, xb);
+    if (F1) issue_y(y_off + (r0 + 16) * 4, y4[nxt]);
+    if (F2) issue_a(a_off + (r0 + 32) * kStride * 4, xa[cur]);
+    if (F1) wait_a<8 + 1 + (F2 ? 4 : 0)>(xa[nxt], y4[cur]);
+    else wait_y<8>(y4[cur]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (F1) {
+      e0[nxt] = e1[nxt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      forward_steps<0, 16>(xa[nxt], bB, e0[nxt], e1[nxt]);
+    }
+    float w[4];
+#pragma unroll
+    for (int r_ = 0; r_ < 4; ++r_)
+      w[r_] = residual<LOGP>(e0[cur][r_] + e1[cur][r_], y4[cur][r_], row + r_ < rows, lp);
+    if (F1) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wait_b<(F1 ? 1 : 0) + (F2 ? 4 : 0)>(xb);
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) backward_step(xb, s_, w[s_], acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // blocks I, I+1, ... of a tile
+  template <bool LOGP, int I>
+  static ARP_DEV void mfma_blocks(uint32_t a_off, uint32_t b_off, uint32_t y_off, int gk, int rows,
+                                  const float (&bB)[16], v4f (&xa)[2][4], v2f (&xb)[8], v4f (&y4)[2],
+                                  v4f (&e0)[2], v4f (&e1)[2], v4f (&acc)[4], float& lp) {
+    if constexpr (I < kRows / 16) {
+      mfma_block<LOGP, I>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, e0, e1, acc, lp);
+      mfma_blocks<LOGP, I + 1>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, e0, e1, acc, lp);
+    }
   }
 
   template <bool LOGP>
   ARP_DEV float likelihood_mfma(const float (&beta)[NLS], float (&v)[NLS]) const {
     static_assert(NLS == 16, "K = 4 owns 16 features per lane");
     float* tile = tile_mem();
-    const float* ytile = tile + kGermanTile * kStride;
+    const float* ytile = tile + kRows * kStride;
     const int lane = threadIdx.x & 63;
-    float* xch = tile + kGermanTile * kStride + kGermanTile + (threadIdx.x >> 6) * kXch;
+    float* xch = tile + kRows * kStride + kRows + (threadIdx.x >> 6) * kXch;
     float* lpx = xch + 16 * kStride;
     const int c = lane >> 2, t = lane & 3;    // state layout (t == slot)
     const int gk = lane >> 4, j = lane & 15;  // MFMA layout
+    const uint32_t tile_off = lds_offset(tile);
+    const uint32_t a_off = tile_off + (uint32_t)(j * kStride + 16 * gk) * 4u;      // row j, columns 16g..
+    const uint32_t b_off = tile_off + (uint32_t)(4 * gk * kStride + j) * 4u;       // rows 4g.., column j
+    const uint32_t y_off = tile_off + (uint32_t)(kRows * kStride + 4 * gk) * 4u;
     float4* own = reinterpret_cast<float4*>(xch + c * kStride + 16 * t);
     const float4* mine = reinterpret_cast<const float4*>(xch + j * kStride + 16 * gk);
 #pragma unroll
@@ -340,53 +446,24 @@ struct GermanLane {
     // next tile travels through registers while the current one is multiplied
     TileRegs T;
     fetch_tile(0, T);
-    for (int n0 = 0; n0 < N; n0 += kGermanTile) {
+    for (int n0 = 0; n0 < N; n0 += kRows) {
       __syncthreads();   // previous tile fully consumed
       store_tile(tile, T);
-      if (n0 + kGermanTile < N) fetch_tile(n0 + kGermanTile, T);
+      if (n0 + kRows < N) fetch_tile(n0 + kRows, T);
       __syncthreads();
-      const int rows = min(kGermanTile, N - n0);
-      // The tile is zero filled up to its 64 rows: always four blocks of 16 rows, software
-      // pipelined so that the sigmoids of block i issue between the forward MFMAs of block i+1.
-      float xa[2][16];
-      v4f eta4[2];
-      load_a(tile, 0, gk, j, xa[0]);
-      load_a(tile, 16, gk, j, xa[1]);
-      eta4[0] = forward16(xa[0], bB);
-#pragma unroll
-      for (int i = 0; i < kGermanTile / 16; ++i) {
-        const int r0 = 16 * i;
-        const float* pb = tile + (r0 + 4 * gk) * kStride + j;
-        float xb[16];
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) xb[4 * s_ + k] = pb[s_ * kStride + 16 * k];
-        const float4 y4 = *reinterpret_cast<const float4*>(ytile + r0 + 4 * gk);
-        const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
-        if (i + 1 < kGermanTile / 16) eta4[(i + 1) & 1] = forward16(xa[(i + 1) & 1], bB);
-        if (i + 2 < kGermanTile / 16) load_a(tile, r0 + 32, gk, j, xa[i & 1]);
-        float w[4];
-#pragma unroll
-        for (int r_ = 0; r_ < 4; ++r_) {
-          const float eta = eta4[i & 1][r_];
-          if (LOGP) {
-            const float ex = fast_exp(-fabsf(eta));
-            const float rc = __builtin_amdgcn_rcpf(1.0f + ex);
-            w[r_] = yv[r_] - (eta >= 0.0f ? rc : ex * rc);
-            const float tt = fmaf(yv[r_], eta, -(fmaxf(eta, 0.0f) + fast_log(1.0f + ex)));
-            lp += r0 + 4 * gk + r_ < rows ? tt : 0.0f;
-          } else {
-            // 1 / (1 + e^-eta): e^-eta = inf gives 0, no NaN
-            w[r_] = yv[r_] - __builtin_amdgcn_rcpf(1.0f + fast_exp(-eta));
-          }
-        }
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[4 * s_ + k], w[s_], acc[k], 0, 0, 0);
-      }
+      const int rows = min(kRows, N - n0);
+      // The tile is zero filled up to its last row: always kRows / 16 blocks of 16 rows, software
+      // pipelined (mfma_block).
+      v4f xa[2][4], y4[2];
+      v2f xb[8];
+      v4f e0[2], e1[2];
+      issue_y(y_off, y4[0]);
+      issue_a(a_off, xa[0]);
+      issue_a(a_off + 16 * kStride * 4, xa[1]);
+      wait_a<4>(xa[0], y4[0]);
+      e0[0] = e1[0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+      forward_steps<0, 16>(xa[0], bB, e0[0], e1[0]);
+      mfma_blocks<LOGP, 0>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, e0, e1, acc, lp);
     }
     // v back to the state layout: lane (g, j) holds v[16k + 4g + r] of chain j in acc[k][r]
 #pragma unroll

@@ -46,6 +46,7 @@ struct RadonLane {
   static constexpr bool HAS_MODES = true;
   static constexpr bool HAS_CARRY = true;   // carry<> below
   static constexpr bool HAS_FUSED = true;   // kick_drift below  // grad_m / to_centered_m / from_centered_m below
+  static constexpr bool HAS_VI = true;
   using Args = RadonArgs;
 
   static constexpr int LBASE = 3; // flattened index of m_0 (parts: mua, b1, b2, m[J])

@@ -32,6 +32,7 @@ struct RadonSdLane {
   static constexpr bool HAS_MODES = false;
   static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = false;
+  static constexpr bool HAS_VI = true;
   static constexpr int MINW = 1;
   using Args = RadonSdArgs;
 

@@ -6,7 +6,7 @@ R="${GRAFT_REPO_ROOT:-$(pwd)}"; OUT="$R/gpurun_out/pmc_cmd"; rm -rf "$OUT"; mkdi
 S="$R/$1"; shift
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d "$OUT/a" -- python3 "$S" "$@" > "$OUT/a.log" 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d "$OUT/b" -- python3 "$S" "$@" > "$OUT/b.log" 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d "$OUT/b" -- python3 "$S" "$@" > "$OUT/b.log" 2>&1
 KERNEL="${KERNEL:-arp::}" python3 - <<PY
 import csv,glob,collections,os
 for d in ("a","b"):
