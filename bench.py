@@ -180,6 +180,34 @@ def main():
                  "achieved_GBps": C * T * algorithmic_bytes_per_transition(D) / (pms * 1e-3) / 1e9}
         st = st2
 
+    # secondary figure: the one compute-bound model (BASELINE configs[2], german credit, 16 384 chains).
+    # SURVEY.md 8d prices it against the f32 peak: algorithmic flops = 2 products x 2 flop x N x F per gradient.
+    german = None
+    if world == 1:
+        gspec = models._spec_german()
+        geng = engine.Engine(gspec, dev)
+        geng.set_param(0, "NCP")
+        Cg, Lg, Tg = 16384, 4, 4
+        rsg = np.random.RandomState(1)
+        stg = engine.ChainState(torch.as_tensor((0.1 * rsg.randn(Cg, gspec.D)).astype(np.float32), device=dev))
+        epsg = np.full(gspec.D, 0.005, np.float32)
+        kwg = dict(seed=5, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9)
+        geng.hmc_run(stg, epsg, Lg, Tg, **kwg)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            geng.hmc_run(stg, epsg, Lg, Tg, **kwg)
+        e1.record(); torch.cuda.synchronize()
+        gms = e0.elapsed_time(e1) / 3
+        Ng, Fg = gspec.raw["X"].shape
+        gflop = 4.0 * Ng * Fg
+        german = {"kernel": "hmc_kernel<GermanLane<4,16>> (v_mfma_f32_16x16x4_f32)", "chains": Cg, "num_leapfrog_steps": Lg,
+                  "kernel_ms": gms, "leapfrog_steps_per_s": Cg * Tg * Lg / (gms * 1e-3),
+                  "roofline": {"bound": "mfma", "achieved": Cg * Tg * Lg * gflop / (gms * 1e-3) / 1e12, "peak": 157.3,
+                               "unit": "TFLOP/s", "frac": Cg * Tg * Lg * gflop / (gms * 1e-3) / 1e12 / 157.3,
+                               "algorithmic_flop_per_gradient": gflop}}
+
     # ESS/sec (second half of the BASELINE metric): a separate short run with the same kernel,
     # S recorded samples at the reference's thinning, ESS by FFT on the device trace
     ess_info = None
@@ -239,7 +267,8 @@ def main():
                          "kernel": "interleaved_kernel<RadonLane,CP,NCP>" if inter else "hmc_kernel<RadonLane,CP>",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_step_per_chain": BT,
                          "algorithmic_bytes_per_launch": C * T * BT},
-            "accept_rate": accept_rate, "stats_allgather_s": t_coll, "plain_hmc": plain, "ess": ess_info,
+            "accept_rate": accept_rate, "stats_allgather_s": t_coll, "plain_hmc": plain, "german_credit": german,
+            "ess": ess_info,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
