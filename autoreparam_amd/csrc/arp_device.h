@@ -53,30 +53,27 @@ ARP_DEV float group_bcast0(float v, int slot) {
 }
 
 // ---------------------------------------------------------------------------
-// RNG.  Each (chain, slot) owns one xoshiro128+ stream (Blackman & Vigna, public
-// domain algorithm; the variant its authors recommend for 32-bit floating-point
-// generation, whose upper bits are what the conversions below consume) whose
-// 128-bit state is seeded once per run by
-// Philox4x32-10 (Salmon et al., SC'11) keyed on the user seed with counter
-// (global chain id, slot, lanes_per_chain).  The stream therefore depends on the
-// global chain id only, never on which GPU or workgroup runs the chain.
+// RNG.  Each (chain, slot) owns one MWC64X stream (a 32-bit multiply-with-carry generator,
+// x' = lo(A x + c), c' = hi(A x + c), output x ^ c of the state before the step; D. B. Thomas'
+// published parameters A = 4294883355, period ~2^63; passes BigCrush).  One step is a single
+// v_mad_u64_u32 plus an xor -- a third of the issue time of a 128-bit xorshift-family step, and
+// the momentum draw is the largest per-transition cost of the chain kernels -- and the state is
+// two registers.  The 64-bit state is seeded once per run by Philox4x32-10 (Salmon et al., SC'11)
+// keyed on the user seed with counter (global chain id, slot, lanes_per_chain), so a stream
+// depends on the global chain id only, never on which GPU or workgroup runs the chain.
 // ---------------------------------------------------------------------------
 struct Rng {
-  uint32_t s0, s1, s2, s3;
+  uint32_t x, c;
 };
 
-ARP_DEV uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+constexpr uint32_t kMwcA = 4294883355u;
 
 ARP_DEV uint32_t rng_next(Rng& r) {
-  uint32_t result = r.s0 + r.s3;
-  uint32_t t = r.s1 << 9;
-  r.s2 ^= r.s0;
-  r.s3 ^= r.s1;
-  r.s1 ^= r.s2;
-  r.s0 ^= r.s3;
-  r.s2 ^= t;
-  r.s3 = rotl32(r.s3, 11);
-  return result;
+  const uint32_t res = r.x ^ r.c;
+  const uint64_t t = (uint64_t)r.x * kMwcA + r.c;
+  r.x = (uint32_t)t;
+  r.c = (uint32_t)(t >> 32);
+  return res;
 }
 
 ARP_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -100,8 +97,8 @@ ARP_DEV Rng rng_seed(uint64_t seed, uint64_t chain, uint32_t slot, uint32_t lane
   uint32_t o[4];
   philox4x32_10((uint32_t)chain, (uint32_t)(chain >> 32), slot, lanes,
                 (uint32_t)seed, (uint32_t)(seed >> 32), o);
-  Rng r{o[0], o[1], o[2], o[3]};
-  if ((r.s0 | r.s1 | r.s2 | r.s3) == 0u) r.s0 = 1u;  // the all-zero state is absorbing
+  Rng r{o[0], o[1] >> 1};      // carry < 2^31 < A: a state on the generator's cycle
+  if ((r.x | r.c) == 0u) r.x = 1u;  // (0, 0) is a fixed point
   return r;
 }
 

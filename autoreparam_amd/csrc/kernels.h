@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
     rng = rng_seed(P.seed, (unsigned long long)(P.chain_offset + c), (uint32_t)slot, (uint32_t)K);
   } else {
     kappa = P.adapt[c * 4 + 0]; esum = P.adapt[c * 4 + 1]; logavg = P.adapt[c * 4 + 2];
-    rng = Rng{rs[0], rs[1], rs[2], rs[3]};
+    rng = Rng{rs[0], rs[1]};
   }
   uint32_t nacc = (P.step_base == 0) ? 0u : P.accept_count[c];
 
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
   uint32_t* rs2 = P.rng + ((size_t)c2 * kRngSlots + slot) * 4;
   if (live) {
     rs = rs2;
-    rs[0] = rng.s0; rs[1] = rng.s1; rs[2] = rng.s2; rs[3] = rng.s3;
+    rs[0] = rng.x; rs[1] = rng.c; rs[2] = 0u; rs[3] = 0u;
     if (slot == 0) {
       P.logp[c2] = lp;
       P.adapt[c2 * 4 + 0] = kappa; P.adapt[c2 * 4 + 1] = esum; P.adapt[c2 * 4 + 2] = logavg;
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
     kap[0] = P.adapt[c * 4 + 0]; es[0] = P.adapt[c * 4 + 1]; la_[0] = P.adapt[c * 4 + 2];
     kap[1] = P.adapt1[c * 4 + 0]; es[1] = P.adapt1[c * 4 + 1]; la_[1] = P.adapt1[c * 4 + 2];
     nacc0 = P.accept_count[c]; nacc1 = P.accept_count1[c];
-    rng = Rng{rs[0], rs[1], rs[2], rs[3]};
+    rng = Rng{rs[0], rs[1]};
   }
 
   // The reference re-bootstraps logp/grad after every change of coordinates
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
   uint32_t* rs2 = P.rng + ((size_t)c2 * kRngSlots + slot) * 4;
   if (live) {
     rs = rs2;
-    rs[0] = rng.s0; rs[1] = rng.s1; rs[2] = rng.s2; rs[3] = rng.s3;
+    rs[0] = rng.x; rs[1] = rng.c; rs[2] = 0u; rs[3] = 0u;
     if (slot == 0) {
       if (CARRY && P.grad) P.logp[c2] = lp;
       P.adapt[c2 * 4 + 0] = kap[0]; P.adapt[c2 * 4 + 1] = es[0]; P.adapt[c2 * 4 + 2] = la_[0];

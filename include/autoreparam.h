@@ -97,7 +97,7 @@ typedef struct arp_hmc_io {
   float* grad;               /* [C][D] in/out cached gradient at q (ignored when step_base == 0) */
   float* logp;               /* [C]    in/out cached log-density at q (additive constants dropped) */
   float* adapt;              /* [C][4] in/out {step multiplier kappa, error sum, log-averaged multiplier, unused} */
-  uint32_t* rng;             /* [C][16][4] in/out xoshiro128+ states, one per RNG slot */
+  uint32_t* rng;             /* [C][16][4] in/out stream states, one 16-byte record per RNG slot (MWC64X: x, carry, 0, 0) */
   uint32_t* accept_count;    /* [C] in/out accepted transitions */
   const float* eps0;         /* [D] base step size per element (VI posterior std / (L/4)^2, inference.py:212-216) */
   float* trace;              /* [S][C][D] or NULL */

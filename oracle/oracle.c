@@ -56,18 +56,15 @@ typedef struct orc_hmc_cfg {
   int lanes;
 } orc_hmc_cfg;
 
-/* ---- RNG: xoshiro128+ streams seeded by Philox4x32-10 (DESIGN.md "Randomness") ---- */
+/* ---- RNG: MWC64X streams seeded by Philox4x32-10 (DESIGN.md "Randomness").  The stream record
+ * keeps the 16-byte layout of the state buffers: s[0] = x, s[1] = carry, s[2] = s[3] = 0. ---- */
 typedef struct { uint32_t s[4]; } orc_rng;
-
-static uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
 
 static uint32_t orc_rng_next(orc_rng* r) {
   uint32_t* s = r->s;
-  uint32_t result = s[0] + s[3];   /* xoshiro128+ */
-  uint32_t t = s[1] << 9;
-  s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
-  s[2] ^= t;
-  s[3] = rotl32(s[3], 11);
+  uint32_t result = s[0] ^ s[1];
+  uint64_t t = (uint64_t)s[0] * 4294883355u + s[1];   /* x' = lo(A x + c), c' = hi(A x + c) */
+  s[0] = (uint32_t)t; s[1] = (uint32_t)(t >> 32);
   return result;
 }
 
@@ -87,8 +84,8 @@ static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 static orc_rng orc_rng_seed(uint64_t seed, uint64_t chain, uint32_t slot, uint32_t lanes) {
   uint32_t c[4] = {(uint32_t)chain, (uint32_t)(chain >> 32), slot, lanes};
   philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-  orc_rng r = {{c[0], c[1], c[2], c[3]}};
-  if ((c[0] | c[1] | c[2] | c[3]) == 0u) r.s[0] = 1u;
+  orc_rng r = {{c[0], c[1] >> 1, 0u, 0u}};
+  if ((r.s[0] | r.s[1]) == 0u) r.s[0] = 1u;
   return r;
 }
 

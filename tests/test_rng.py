@@ -1,5 +1,5 @@
 """CPU: known-answer and distribution tests of the sampler's RNG specification
-(Philox4x32-10 seeding, xoshiro128+ streams, Box-Muller normals)."""
+(Philox4x32-10 seeding, MWC64X streams, Box-Muller normals)."""
 import ctypes as C
 
 import numpy as np
@@ -19,28 +19,51 @@ def test_philox_known_answers(oracle_lib):
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
-def _xoshiro128p(state, n):
-    """Independent restatement (python ints) of Blackman & Vigna's xoshiro128+."""
-    s = list(state)
-    M = 0xffffffff
-    rotl = lambda x, k: ((x << k) | (x >> (32 - k))) & M
+def _mwc64x(x, c, n):
+    """Independent restatement (python ints) of D. B. Thomas' MWC64X: output x ^ c, then
+    (x, c) <- (lo, hi) of A x + c with A = 4294883355."""
     out = []
     for _ in range(n):
-        out.append((s[0] + s[3]) & M)
-        t = (s[1] << 9) & M
-        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]
-        s[2] ^= t
-        s[3] = rotl(s[3], 11)
+        out.append(x ^ c)
+        t = x * 4294883355 + c
+        x, c = t & 0xffffffff, t >> 32
     return out
 
 
-def test_stream_is_philox_seeded_xoshiro(oracle_lib):
+def test_mwc64x_known_answer():
+    # first outputs from state (x, c) = (1, 0): 1, then A, then (A*A mod 2^32) ^ (A*A >> 32), ...
+    A = 4294883355
+    o = _mwc64x(1, 0, 3)
+    assert o[0] == 1 and o[1] == A and o[2] == ((A * A) & 0xffffffff) ^ ((A * A) >> 32)
+    # (0, 0) and (2^32 - 1, A - 1) are the generator's fixed points
+    assert _mwc64x(0, 0, 2) == [0, 0]
+    assert _mwc64x(0xffffffff, A - 1, 2)[0] == _mwc64x(0xffffffff, A - 1, 2)[1]
+
+
+def test_stream_is_philox_seeded_mwc64x(oracle_lib):
     seed, chain, slot, lanes = 0x123456789abcdef, 4242, 3, 8
     out = np.zeros(64, np.uint32)
     oracle_lib.lib().orc_stream(C.c_uint64(seed), C.c_uint64(chain), C.c_uint32(slot), C.c_uint32(lanes), 64,
                                 out.ctypes.data_as(C.c_void_p))
     st = _philox(oracle_lib, [chain & 0xffffffff, chain >> 32, slot, lanes], [seed & 0xffffffff, seed >> 32])
-    assert [int(v) for v in out] == _xoshiro128p(st, 64)
+    assert [int(v) for v in out] == _mwc64x(st[0], st[1] >> 1, 64)
+
+
+def test_word_stream_is_equidistributed(oracle_lib):
+    """Bit frequencies and byte chi-square of one stream (the normals consume the high bits)."""
+    n = 1 << 18
+    out = np.zeros(n, np.uint32)
+    oracle_lib.lib().orc_stream(C.c_uint64(99), C.c_uint64(7), C.c_uint32(1), C.c_uint32(4), n,
+                                out.ctypes.data_as(C.c_void_p))
+    bits = ((out[:, None] >> np.arange(32, dtype=np.uint32)) & 1).mean(axis=0)
+    assert np.abs(bits - 0.5).max() < 5 * 0.5 / np.sqrt(n)
+    for shift in (0, 8, 16, 24):
+        cnt = np.bincount((out >> shift) & 0xff, minlength=256)
+        chi2 = ((cnt - n / 256.0) ** 2 / (n / 256.0)).sum()
+        assert chi2 < 255 + 5 * np.sqrt(2 * 255)
+    # serial correlation of successive words
+    u = out.astype(np.float64) / 2 ** 32
+    assert abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 5 / np.sqrt(n)
 
 
 def test_streams_differ_by_chain_slot_and_seed(oracle_lib):
