@@ -64,3 +64,14 @@ def test_product_path_does_not_import_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), (dirpath, f)
                 assert "liboracle" not in txt, (dirpath, f)
+
+
+def test_enum_values_match_header(built):
+    src = open(os.path.join(ROOT, "include", "autoreparam.h")).read()
+    enums = {k: int(v) for k, v in re.findall(r"\b(ARP_[A-Z_0-9]+)\s*=\s*(\d+)", src)}
+    assert len([k for k in enums if k.startswith("ARP_MODEL_")]) == 7
+    for k, v in enums.items():
+        if k.startswith("ARP_MODEL_"):
+            assert getattr(built, k[4:]) == v, k          # _lib.MODEL_*
+        elif k.startswith("ARP_ADAPT_"):
+            assert getattr(built, k[4:]) == v, k          # _lib.ADAPT_*

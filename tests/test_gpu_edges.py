@@ -37,7 +37,7 @@ def test_bad_arguments_raise(gpu):
     assert st.step == 0 and torch.equal(st.q, torch.zeros_like(st.q))
 
 
-@pytest.mark.parametrize("mname", ["8schools", "radon_PA", "election", "german"])
+@pytest.mark.parametrize("mname", ["8schools", "radon_PA", "election", "german", "electric"])
 def test_single_chain_and_ragged_tail(oracle_lib, gpu, mname):
     """C = 1 and C = 67 (neither a multiple of the chains per wave) run and agree with the oracle."""
     from autoreparam_amd import engine
@@ -47,18 +47,18 @@ def test_single_chain_and_ragged_tail(oracle_lib, gpu, mname):
     a, b = helpers.params(sp, "NCP")
     eng.set_param(0, (a, b))
     eps = np.full(sp.D, 1e-3, np.float32)
-    lanes = {"8schools": 8, "radon_PA": 8, "election": 16, "german": 16}[mname]
-    for Cn in (1, 67):
-        q0 = helpers.states(sp, Cn, seed=Cn, scale=0.05)
-        st = engine.ChainState(torch.as_tensor(q0, device=gpu))
-        tr = torch.full((2, Cn, sp.D), 7.0, device=gpu)
-        eng.hmc_run(st, eps, 2, 3, seed=3, n_burnin=0, thin=2, trace=tr, lanes=lanes)
-        so = oracle_lib.new_state(q0, np.float32)
-        tro = np.zeros((2, Cn, sp.D), np.float32)
-        orc.hmc_run(so, a, b, eps, 2, 3, seed=3, n_burnin=0, thin=2, trace=tro, lanes=lanes)
-        scale = np.abs(so["q"]).max() + 1
-        assert np.abs(st.q.cpu().numpy() - so["q"]).max() <= 1e-4 * scale
-        assert np.abs(tr.cpu().numpy() - tro).max() <= 1e-4 * scale      # every row written, nothing else
+    for lanes in {"8schools": [8], "radon_PA": [8], "election": [16], "german": [4, 8, 16], "electric": [16]}[mname]:
+        for Cn in (1, 67):
+            q0 = helpers.states(sp, Cn, seed=Cn, scale=0.05)
+            st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+            tr = torch.full((2, Cn, sp.D), 7.0, device=gpu)
+            eng.hmc_run(st, eps, 2, 3, seed=3, n_burnin=0, thin=2, trace=tr, lanes=lanes)
+            so = oracle_lib.new_state(q0, np.float32)
+            tro = np.zeros((2, Cn, sp.D), np.float32)
+            orc.hmc_run(so, a, b, eps, 2, 3, seed=3, n_burnin=0, thin=2, trace=tro, lanes=lanes)
+            scale = np.abs(so["q"]).max() + 1
+            assert np.abs(st.q.cpu().numpy() - so["q"]).max() <= 1e-4 * scale
+            assert np.abs(tr.cpu().numpy() - tro).max() <= 1e-4 * scale      # every row written, nothing else
 
 
 def test_non_finite_proposals_are_rejected(gpu):
@@ -91,3 +91,21 @@ def test_election_at_config5_size(gpu):
     assert torch.isfinite(st.q).all()
     acc = st.accept_count.double().mean().item() / st.step
     assert 0.4 < acc < 0.98
+
+
+def test_electric_rejects_data_its_cell_collapse_cannot_hold(gpu):
+    """The electric lane collapses each pair to (control, treated) cells: pairs must not mix grades and
+    treatment must be a 0/1 indicator; anything else fails loudly at model creation."""
+    import copy
+    from autoreparam_amd import engine
+    sp = helpers.spec("electric")
+    bad = copy.copy(sp); bad.raw = dict(sp.raw)
+    g = sp.raw["grade"].copy(); g[0] = g[0] % 4 + 1        # first observation's pair now mixes two grades
+    bad.raw["grade"] = g
+    with pytest.raises(RuntimeError, match="share a grade"):
+        engine.Engine(bad, gpu)
+    bad = copy.copy(sp); bad.raw = dict(sp.raw)
+    t = sp.raw["treatment"].copy(); t[3] = 0.5
+    bad.raw["treatment"] = t
+    with pytest.raises(RuntimeError, match="0/1"):
+        engine.Engine(bad, gpu)
