@@ -144,6 +144,15 @@ ARP_DEV void lane_from_centered(const Lane& M, const float (&x)[Lane::ND], float
   else M.from_centered(x, q);
 }
 
+// Make `M` evaluate the parameterisation the interleaved kernel switches to: the general form
+// reloads (a, b); a compile-time mode has nothing to reload unless the lane model derives
+// run-time state from (a, b) (election's top-level prior scales), which set_mode<> rebuilds.
+template <int MODE, class Lane>
+ARP_DEV void switch_param(Lane& M, const float* av, const float* bv) {
+  if constexpr (MODE == kModeVIP || !Lane::HAS_MODES) M.set_param(av, bv);
+  else if constexpr (Lane::HAS_MODE_STATE) M.template set_mode<MODE>();
+}
+
 // ---------------------------------------------------------------------------
 // logp + grad for a batch of states (test hook and bootstrap of the cached
 // gradient; reference: vectorized target + tf.gradients, inference.py:172-195)
@@ -480,7 +489,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
       M.template carry<kModeCP>(q, g);
     } else {
       lane_to_centered<M0>(M, q, x);
-      if (M1 == kModeVIP || !Lane::HAS_MODES) M.set_param(av1, bv1);
+      switch_param<M1>(M, av1, bv1);
       lane_from_centered<M1>(M, x, q);
       lp = lane_grad<M1, true>(M, q, g);
     }
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
       M.template carry<kModeNCP>(q, g);
     } else {
       lane_to_centered<M1>(M, q, x);
-      if (M0 == kModeVIP || !Lane::HAS_MODES) M.set_param(av0, bv0);
+      switch_param<M0>(M, av0, bv0);
       lane_from_centered<M0>(M, x, q);
     }
 

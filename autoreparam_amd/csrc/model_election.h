@@ -37,14 +37,28 @@ struct ElectionLane {
   // only the last slice can be padding: NL == ceil(groups / K) is enforced by the host
   ARP_DEV bool lvalid(int i) const { return i < NL - 1 ? true : last_ok; }
   bool last_ok;
-  static constexpr bool HAS_MODES = false;
+  static constexpr bool HAS_MODES = true;    // CP / NCP: (a, b) are compile-time constants, no al / be registers
   static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = true;    // kick_drift below
   static constexpr bool HAS_VI = true;
-  static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
+  static constexpr bool HAS_MODE_STATE = true;    // si / cs of the top-level scalars follow b (set_mode)
+  static constexpr int MINW = K_ == 4 ? 2 : 1;   // waves per SIMD the register allocator must leave room for
   using Args = ElectionArgs;
 
-  float cn[NL][4], cy[NL][4], al[NL], be[NL], lat[NL];
+  float cn[NL][4], cy[NL][4], al[NL], be[NL];
+  float lat_last;   // 1 if the lane's last slice is a state effect, 0 if it is the cell-only group S or padding
+  // (only the last slice can be anything but a latent, see lvalid)
+  ARP_DEV float lat(int i) const { return i < NL - 1 ? 1.0f : lat_last; }
+  // (a, b) of slice i under the compile-time parameterisations
+  // (a non-latent slice has a = b = 0 in every mode: its prior terms vanish and q stays 0)
+  template <int MODE> ARP_DEV float A(int i) const { return MODE == 1 ? lat(i) : (MODE == 2 ? 0.0f : al[i]); }
+  template <int MODE> ARP_DEV float B(int i) const { return MODE == 1 ? lat(i) : (MODE == 2 ? 0.0f : be[i]); }
+  // exp(-b_i ls): shared by all slices when b is uniform (always so for CP, NCP and the reference's tied cVIP/dVIP)
+  template <int MODE> ARP_DEV float E(int i, float ls, float eu) const {
+    if (MODE == 2) return 1.0f;
+    if (MODE == 1) return i < NL - 1 ? eu : (lat_last != 0.0f ? eu : 1.0f);
+    return buni ? eu : fast_exp(-be[i] * ls);
+  }
   float si[4], cs[4];   // 1/s^b and s^(1-b) for mua, lsa, b1, b2
   float bbar; bool buni; // every state shares one b (always so for CP, NCP and the reference's tied cVIP/dVIP)
   int slot, S;
@@ -67,9 +81,19 @@ struct ElectionLane {
         cn[i][c] = cell ? A.cell_n[t * 4 + c] : 0.0f;
         cy[i][c] = cell ? A.cell_y[t * 4 + c] : 0.0f;
       }
-      lat[i] = t < S ? 1.0f : 0.0f;
     }
+    lat_last = slot + K * (NL - 1) < S ? 1.0f : 0.0f;
     set_param(av, bv);
+  }
+  // si, cs under CP (b = 1: xt = x) and NCP (b = 0: xt = x / s)
+  template <int MODE>
+  ARP_DEV void set_mode() {
+    const float sc[4] = {100.0f, 10.0f, 100.0f, 100.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      si[i] = MODE == 1 ? 1.0f / sc[i] : 1.0f;
+      cs[i] = MODE == 1 ? 1.0f : sc[i];
+    }
   }
   ARP_DEV void set_param(const float* av, const float* bv) {
     const float l100 = 6.643856189774724f, l10 = 3.321928094887362f;  // log2
@@ -103,14 +127,15 @@ struct ElectionLane {
     const float mua = cs[0] * q[0], ls = cs[1] * q[1], b1 = cs[2] * q[2], b2 = cs[3] * q[3];
     const float sig = fast_exp(ls);
     const float E1 = fast_exp(-b1), E2 = fast_exp(-b2), E12 = E1 * E2;
-    const float eu = fast_exp(-bbar * ls);
+    const float eu = MODE == 2 ? 1.0f : fast_exp(-(MODE == 1 ? 1.0f : bbar) * ls);
     float g_mua = 0.0f, g_ls = 0.0f, g_b1 = 0.0f, g_b2 = 0.0f;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const float qt = q[NG + i];
-      const float e = buni ? eu : fast_exp(-be[i] * ls);
-      const float z = (qt - al[i] * mua) * e;
-      const float as = lat[i] * fmaf(sig, z, mua);
+      const float ai = A<MODE>(i), bi = B<MODE>(i), li = lat(i);
+      const float e = E<MODE>(i, ls, eu);
+      const float z = (qt - ai * mua) * e;
+      const float as = li * fmaf(sig, z, mua);
       const float t = fast_exp(-as);
       const float w0 = fmaf(-cn[i][0], __builtin_amdgcn_rcpf(1.0f + t), cy[i][0]);
       const float w1 = fmaf(-cn[i][1], __builtin_amdgcn_rcpf(fmaf(t, E2, 1.0f)), cy[i][1]);
@@ -119,9 +144,9 @@ struct ElectionLane {
       const float W = (w0 + w1) + (w2 + w3);
       g_b2 += w1 + w3;
       g_b1 += w2 + w3;
-      const float gt = lat[i] * e * fmaf(sig, W, -z);
-      g_mua += lat[i] * fmaf(-al[i], gt, W);
-      g_ls += fmaf(be[i], fmaf(z, z, -1.0f), lat[i] * W * sig * z * (1.0f - be[i]));
+      const float gt = li * e * fmaf(sig, W, -z);
+      g_mua += li * fmaf(-ai, gt, W);
+      g_ls += fmaf(bi, fmaf(z, z, -1.0f), li * W * sig * z * (1.0f - bi));
       const float pn = fmaf(eps[NG + i], gt, p[NG + i]);
       p[NG + i] = pn;
       q[NG + i] = fmaf(eps[NG + i], pn, qt);
@@ -140,15 +165,20 @@ struct ElectionLane {
   }
 
   template <bool LOGP>
-  ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const {
+  ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const { return grad_m<LOGP, 0>(q, g); }
+
+  template <bool LOGP, int MODE>
+  ARP_DEV float grad_m(const float (&q)[ND], float (&g)[ND]) const {
     const float mua = cs[0] * q[0], ls = cs[1] * q[1], b1 = cs[2] * q[2], b2 = cs[3] * q[3];
     const float sig = fast_exp(ls);
+    const float eu = MODE == 2 ? 1.0f : fast_exp(-(MODE == 1 ? 1.0f : bbar) * ls);
     float g_mua = 0.0f, g_ls = 0.0f, g_b1 = 0.0f, g_b2 = 0.0f, lp = 0.0f;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      float e = fast_exp(-be[i] * ls);
-      float z = (q[NG + i] - al[i] * mua) * e;      // group S / padding: q = 0, al = 0 -> z = 0
-      float as = lat[i] * fmaf(sig, z, mua);
+      const float ai = A<MODE>(i), bi = B<MODE>(i), li = lat(i);
+      const float e = MODE == 0 ? fast_exp(-be[i] * ls) : E<MODE>(i, ls, eu);
+      float z = (q[NG + i] - ai * mua) * e;      // group S / padding: q = 0, a = 0 -> z = 0
+      float as = li * fmaf(sig, z, mua);
       const float eta[4] = {as, as + b2, as + b1, as + b1 + b2};
       float w[4];
 #pragma unroll
@@ -166,11 +196,11 @@ struct ElectionLane {
       float W = (w[0] + w[1]) + (w[2] + w[3]);
       g_b2 += w[1] + w[3];
       g_b1 += w[2] + w[3];
-      float gt = lat[i] * e * fmaf(sig, W, -z);
+      float gt = li * e * fmaf(sig, W, -z);
       g[NG + i] = gt;
-      g_mua += lat[i] * fmaf(-al[i], gt, W);
-      g_ls += fmaf(be[i], fmaf(z, z, -1.0f), lat[i] * W * sig * z * (1.0f - be[i]));
-      if (LOGP) lp += fmaf(-0.5f * z, z, -be[i] * ls);
+      g_mua += li * fmaf(-ai, gt, W);
+      g_ls += fmaf(bi, fmaf(z, z, -1.0f), li * W * sig * z * (1.0f - bi));
+      if (LOGP) lp += fmaf(-0.5f * z, z, -bi * ls);
     }
     g_mua = group_sum<K>(g_mua);
     g_ls = group_sum<K>(g_ls);
@@ -204,19 +234,31 @@ struct ElectionLane {
     }
   }
 
-  ARP_DEV void to_centered(const float (&q)[ND], float (&x)[ND]) const {
+  ARP_DEV void to_centered(const float (&q)[ND], float (&x)[ND]) const { to_centered_m<0>(q, x); }
+  ARP_DEV void from_centered(const float (&x)[ND], float (&q)[ND]) const { from_centered_m<0>(x, q); }
+  template <int MODE>
+  ARP_DEV void to_centered_m(const float (&q)[ND], float (&x)[ND]) const {
     const float mua = cs[0] * q[0], ls = cs[1] * q[1];
     x[0] = mua; x[1] = ls; x[2] = cs[2] * q[2]; x[3] = cs[3] * q[3];
+    const float sig = MODE == 2 ? fast_exp(ls) : 1.0f;
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
-      x[NG + i] = fmaf(fast_exp((1.0f - be[i]) * ls), q[NG + i] - al[i] * mua, mua);
+    for (int i = 0; i < NL; ++i) {
+      if (MODE == 1) x[NG + i] = q[NG + i];                             // a = b = 1: identity
+      else if (MODE == 2) x[NG + i] = lat(i) * fmaf(sig, q[NG + i], mua);   // a = b = 0: mua + sigma q
+      else x[NG + i] = fmaf(fast_exp((1.0f - be[i]) * ls), q[NG + i] - al[i] * mua, mua);
+    }
   }
-  ARP_DEV void from_centered(const float (&x)[ND], float (&q)[ND]) const {
+  template <int MODE>
+  ARP_DEV void from_centered_m(const float (&x)[ND], float (&q)[ND]) const {
     const float mua = x[0], ls = x[1];
     q[0] = mua / cs[0]; q[1] = ls / cs[1]; q[2] = x[2] / cs[2]; q[3] = x[3] / cs[3];
+    const float isig = MODE == 2 ? fast_exp(-ls) : 1.0f;
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
-      q[NG + i] = lvalid(i) ? fmaf(x[NG + i] - mua, fast_exp(-(1.0f - be[i]) * ls), al[i] * mua) : 0.0f;
+    for (int i = 0; i < NL; ++i) {
+      if (MODE == 1) q[NG + i] = lvalid(i) ? x[NG + i] : 0.0f;
+      else if (MODE == 2) q[NG + i] = lvalid(i) ? (x[NG + i] - mua) * isig : 0.0f;
+      else q[NG + i] = lvalid(i) ? fmaf(x[NG + i] - mua, fast_exp(-(1.0f - be[i]) * ls), al[i] * mua) : 0.0f;
+    }
   }
 };
 

@@ -47,6 +47,7 @@ struct RadonLane {
   static constexpr bool HAS_CARRY = true;   // carry<> below
   static constexpr bool HAS_FUSED = true;   // kick_drift below  // grad_m / to_centered_m / from_centered_m below
   static constexpr bool HAS_VI = true;
+  static constexpr bool HAS_MODE_STATE = false;   // nothing but (a, b) depends on the parameterisation
   using Args = RadonArgs;
 
   static constexpr int LBASE = 3; // flattened index of m_0 (parts: mua, b1, b2, m[J])

@@ -34,6 +34,10 @@ def main():
         if "electric" in only:
             run("electric", models._spec_electric(), 65536, 8, 16, "NCP", eps=0.01)
             run("electric", models._spec_electric(), 16384, 8, 16, "NCP", eps=0.01)
+        if "election" in only:
+            for rep in ("NCP", "CP", "VIP"):
+                for lanes in (4, 8, 16):
+                    run("election", models._spec_election(), 131072, 8, lanes, rep if rep != "VIP" else {k + "_a": 0.5 for k in ("mua", "log_sigma_a", "a", "b1", "b2")}, eps=0.005)
         if "german" in only:
             for lanes in (4, 8, 16):
                 run("german", models._spec_german(), 16384, 4, lanes, "NCP", T=4, eps=0.005)
