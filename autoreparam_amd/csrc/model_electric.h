@@ -17,7 +17,10 @@
 //   sum_i (y_i - a - b t_i)^2 = n_0 (ybar_0 - a)^2 + n_1 (ybar_1 - a - b)^2 + SS =: Q
 //   loglik_j = -(n_0 + n_1) s_g - w Q / 2,  w = exp(-2 s_g)
 //   d/da = w (n_0 r_0 + n_1 r_1),  d/db_g = w n_1 r_1,  d/ds_g = w Q - (n_0 + n_1)
-// The grade look-ups and scatters are one-hot FMAs against the replicated grade scalars.
+// The grade look-ups and scatters are one-hot FMAs against the replicated grade scalars.  The
+// one-hot weights depend on (slot, slice) only, not on the chain, so they live in a 3.5 KB LDS
+// table shared by the workgroup (two ds_read_b128 per pair and gradient) instead of 56 registers
+// per lane: that is what lets two waves share a SIMD.
 #pragma once
 #include "arp_device.h"
 
@@ -52,12 +55,26 @@ struct ElectricLane {
   static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = false;
   static constexpr bool HAS_VI = true;
-  static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
+  static constexpr int MINW = 2;   // waves per SIMD the register allocator must leave room for
   using Args = ElectricArgs;
 
-  float wm[NL][kElG], og[NL][kElG], n0[NL], y0[NL], n1[NL], y1[NL], ss[NL], al[NL], lat[NL];
+  float n0[NL], y0[NL], n1[NL], y1[NL], ss[NL], al[NL];
+  float lat_last;   // 1 if the lane's last slice is a pair effect, 0 if it is the observation-only group P or padding
+  ARP_DEV float lat(int i) const { return i < NL - 1 ? 1.0f : lat_last; }
   float si[kElG], cs[kElG];   // 1/100^b and 100^(1-b) of b_k
   int slot, P;
+
+  // one-hot weights of (slice i, slot): [wm0..3][og0..3], 32 bytes per entry
+  static ARP_DEV float* onehot_table() {
+    __shared__ __attribute__((aligned(16))) float tab[NL * K * 8];
+    return tab;
+  }
+  ARP_DEV void onehot(int i, float (&wm)[kElG], float (&og)[kElG]) const {
+    const float4* t = reinterpret_cast<const float4*>(onehot_table() + (i * K + slot) * 8);
+    const float4 a = t[0], b = t[1];
+    wm[0] = a.x; wm[1] = a.y; wm[2] = a.z; wm[3] = a.w;
+    og[0] = b.x; og[1] = b.y; og[2] = b.z; og[3] = b.w;
+  }
 
   // flattened index of replicated scalar i: mua, sigma_y in front of a[P], b behind it
   ARP_DEV int gg(int i) const { return i < 2 * kElG ? i : i + P; }
@@ -67,20 +84,25 @@ struct ElectricLane {
     P = A.P;
     last_ok = slot + K * (NL - 1) < P;   // latent validity (j < P); group j == P has no latent
     const int stride = P + 1;
+    float* tab = onehot_table();
+    __syncthreads();   // a previous user of the table (none inside one kernel) is done
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int j = slot + K * i;
       const bool has = j <= P;
+      if ((int)threadIdx.x < K) {   // the first chain of the workgroup fills the table for everybody
 #pragma unroll
-      for (int k = 0; k < kElG; ++k) {
-        wm[i][k] = has ? A.wm[k * stride + j] : 0.0f;
-        og[i][k] = has ? A.og[k * stride + j] : 0.0f;
+        for (int k = 0; k < kElG; ++k) {
+          tab[(i * K + slot) * 8 + k] = has ? A.wm[k * stride + j] : 0.0f;
+          tab[(i * K + slot) * 8 + 4 + k] = has ? A.og[k * stride + j] : 0.0f;
+        }
       }
       n0[i] = has ? A.n0[j] : 0.0f; y0[i] = has ? A.y0[j] : 0.0f;
       n1[i] = has ? A.n1[j] : 0.0f; y1[i] = has ? A.y1[j] : 0.0f;
       ss[i] = has ? A.ss[j] : 0.0f;
-      lat[i] = j < P ? 1.0f : 0.0f;
     }
+    lat_last = slot + K * (NL - 1) < P ? 1.0f : 0.0f;
+    __syncthreads();
     set_param(av, bv);
   }
   ARP_DEV void set_param(const float* av, const float* bv) {
@@ -102,12 +124,14 @@ struct ElectricLane {
     float lp = 0.0f;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
+      float wm[kElG], og[kElG];
+      onehot(i, wm, og);
       float mu = 0.0f, sg = 0.0f, bg = 0.0f;
 #pragma unroll
       for (int k = 0; k < kElG; ++k) {
-        mu = fmaf(wm[i][k], q[k], mu);
-        sg = fmaf(og[i][k], q[kElG + k], sg);
-        bg = fmaf(og[i][k], bb[k], bg);
+        mu = fmaf(wm[k], q[k], mu);
+        sg = fmaf(og[k], q[kElG + k], sg);
+        bg = fmaf(og[k], bb[k], bg);
       }
       const float r = fmaf(-al[i], mu, q[NG + i]);   // group P / padding: q = 0, al = 0, wm = 0 -> r = 0
       const float aj = r + mu;
@@ -119,16 +143,19 @@ struct ElectricLane {
       const float nn = n0[i] + n1[i];
       const float dSv = fmaf(w, Q, -nn);
       const float dBv = w * e1;
-      const float ga = lat[i] * (dA - r);
+      const float ga = lat(i) * (dA - r);
       g[NG + i] = ga;
       const float hm = fmaf(-al[i], ga, dA);   // d / d mu_j
 #pragma unroll
       for (int k = 0; k < kElG; ++k) {
-        dM[k] = fmaf(wm[i][k], hm, dM[k]);
-        dS[k] = fmaf(og[i][k], dSv, dS[k]);
-        dB[k] = fmaf(og[i][k], dBv, dB[k]);
+        dM[k] = fmaf(wm[k], hm, dM[k]);
+        dS[k] = fmaf(og[k], dSv, dS[k]);
+        dB[k] = fmaf(og[k], dBv, dB[k]);
       }
       if (LOGP) lp += fmaf(-0.5f * r, r, fmaf(-0.5f * w, Q, -nn * sg));
+      // keep the table reads of the next pairs from being hoisted over this one (they would sit in
+      // registers for the whole pass -- the very registers the LDS table is there to save)
+      if (i & 1) __builtin_amdgcn_sched_barrier(0);
     }
     float pri = 0.0f;
 #pragma unroll
@@ -153,9 +180,11 @@ struct ElectricLane {
       db[2 * kElG + k] = -4.605170185988092f * fmaf(q[2 * kElG + k], g[2 * kElG + k], 1.0f);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
+      float wm[kElG], og[kElG];
+      onehot(i, wm, og);
       float mu = 0.0f;
 #pragma unroll
-      for (int k = 0; k < kElG; ++k) mu = fmaf(wm[i][k], q[k], mu);
+      for (int k = 0; k < kElG; ++k) mu = fmaf(wm[k], q[k], mu);
       da[NG + i] = lvalid(i) ? -mu * g[NG + i] : 0.0f;
     }
   }
@@ -165,9 +194,11 @@ struct ElectricLane {
     for (int k = 0; k < kElG; ++k) { x[k] = q[k]; x[kElG + k] = q[kElG + k]; x[2 * kElG + k] = cs[k] * q[2 * kElG + k]; }
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
+      float wm[kElG], og[kElG];
+      onehot(i, wm, og);
       float mu = 0.0f;
 #pragma unroll
-      for (int k = 0; k < kElG; ++k) mu = fmaf(wm[i][k], q[k], mu);
+      for (int k = 0; k < kElG; ++k) mu = fmaf(wm[k], q[k], mu);
       x[NG + i] = fmaf(1.0f - al[i], mu, q[NG + i]);
     }
   }
@@ -176,9 +207,11 @@ struct ElectricLane {
     for (int k = 0; k < kElG; ++k) { q[k] = x[k]; q[kElG + k] = x[kElG + k]; q[2 * kElG + k] = x[2 * kElG + k] / cs[k]; }
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
+      float wm[kElG], og[kElG];
+      onehot(i, wm, og);
       float mu = 0.0f;
 #pragma unroll
-      for (int k = 0; k < kElG; ++k) mu = fmaf(wm[i][k], x[k], mu);
+      for (int k = 0; k < kElG; ++k) mu = fmaf(wm[k], x[k], mu);
       q[NG + i] = lvalid(i) ? fmaf(-(1.0f - al[i]), mu, x[NG + i]) : 0.0f;
     }
   }
