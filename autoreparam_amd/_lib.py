@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("ARP_LIB_PATH") or os.path.join(_HERE, "libautoreparam
 MODEL_EIGHT_SCHOOLS, MODEL_RADON, MODEL_GERMAN_CREDIT, MODEL_ELECTION, MODEL_RADON_STDDVS = 0, 1, 2, 3, 4
 MODEL_NEALS_FUNNEL = 5
 MODEL_ELECTRIC = 6
+MODEL_TIME_SERIES = 7
 ADAPT_NONE, ADAPT_DUAL, ADAPT_SIMPLE = 0, 1, 2
 RNG_SLOTS = 16  # rng buffer is [C][16][4] uint32
 

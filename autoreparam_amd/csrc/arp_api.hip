@@ -49,6 +49,7 @@ static const std::vector<LaneOps>* family(const arp_model* m) {
     case ARP_MODEL_RADON_STDDVS: return &radon_sd_ops();
     case ARP_MODEL_NEALS_FUNNEL: return &funnel_ops();
     case ARP_MODEL_ELECTRIC: return &electric_ops();
+    case ARP_MODEL_TIME_SERIES: return &time_series_ops();
     default: return nullptr;
   }
 }
@@ -61,6 +62,7 @@ static const void* family_args(const arp_model* m) {
     case ARP_MODEL_RADON_STDDVS: return &m->radon_sd;
     case ARP_MODEL_NEALS_FUNNEL: return &m->funnel;
     case ARP_MODEL_ELECTRIC: return &m->electric;
+    case ARP_MODEL_TIME_SERIES: return &m->time_series;
     default: return nullptr;
   }
 }
@@ -272,6 +274,24 @@ static int build_electric(arp_model* m, const arp_dataset* d) {
   return 0;
 }
 
+// reference models.py:1069-1141: x = regressor (years), y = series, n_obs = T
+static int build_time_series(arp_model* m, const arp_dataset* d) {
+  const int T = d->n_obs;
+  if (!d->x_host || !d->y_host || T <= 0) { set_error("time_series: x, y and n_obs are required"); return 1; }
+  // the block scan splits the T steps evenly over the 4 lanes of a chain; the one instantiation
+  // (inst_time_series.hip) holds 15 steps per lane, the reference's T = 60
+  if (T != 60) { set_error("time_series: n_obs must be 60 (add TimeSeriesLane<4, T/2> to inst_time_series.hip for another length)"); return 1; }
+  m->D = 3 + 2 * T; m->n_groups = 2 * T;
+  m->host_tables.assign(d->x_host, d->x_host + T);
+  m->host_tables.insert(m->host_tables.end(), d->y_host, d->y_host + T);
+  if (upload_tables(m)) return 1;
+  m->time_series.x = m->dev_tables;
+  m->time_series.y = m->dev_tables + T;
+  m->time_series.T = T;
+  m->const_base = -(double)(m->D + T) * kHalfLog2Pi - T * log(0.12);
+  return 0;
+}
+
 }  // namespace arp
 
 using namespace arp;
@@ -294,6 +314,7 @@ int arp_model_create(const arp_dataset* data, arp_model** out) {
     case ARP_MODEL_GERMAN_CREDIT: rc = build_german(m.get(), data); break;
     case ARP_MODEL_RADON_STDDVS: rc = build_radon_sd(m.get(), data); break;
     case ARP_MODEL_ELECTRIC: rc = build_electric(m.get(), data); break;
+    case ARP_MODEL_TIME_SERIES: rc = build_time_series(m.get(), data); break;
     case ARP_MODEL_NEALS_FUNNEL:   // models.py:671-696: no data
       m->D = 2; m->n_groups = 1; m->const_base = -2.0 * kHalfLog2Pi; m->top_scale = {{0, log(3.0)}};
       rc = 0; break;

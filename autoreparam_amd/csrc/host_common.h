@@ -15,6 +15,7 @@
 #include "model_radon_stddvs.h"
 #include "model_funnel.h"
 #include "model_electric.h"
+#include "model_time_series.h"
 
 namespace arp {
 
@@ -105,6 +106,7 @@ const std::vector<LaneOps>& german_ops();
 const std::vector<LaneOps>& radon_sd_ops();
 const std::vector<LaneOps>& funnel_ops();
 const std::vector<LaneOps>& electric_ops();
+const std::vector<LaneOps>& time_series_ops();
 
 }  // namespace arp
 
@@ -125,6 +127,7 @@ struct arp_model {
   arp::RadonSdArgs radon_sd{};
   arp::FunnelArgs funnel{};
   arp::ElectricArgs electric{};
+  arp::TimeSeriesArgs time_series{};
   std::vector<float> host_tables;
   double const_base = 0.0;                       // parameterisation independent part of the dropped constant
   std::vector<std::pair<int, double>> top_scale; // (flattened index, log prior scale) of top-level latents

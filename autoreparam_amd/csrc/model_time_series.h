@@ -1,0 +1,239 @@
+// Local linear trend ("time_series", reference models.py:1069-1141) under the general VIP
+// parameterisation.  Every latent is its own scalar random variable; trace order:
+//   sigma_alpha, sigma_mu, alpha_0, mu_0, alpha_1, mu_1, ..., alpha_{T-1}, mu_{T-1}, beta.
+//
+//   sa, sm, beta ~ N(0,1);  Sa = softplus(sa), Sm = softplus(sm)
+//   alpha_t ~ N(m_t, Sa), m_t = alpha_{t-1} + mu_{t-1} (m_0 = 0):
+//       at_t ~ N(a m_t, Sa^b),  alpha_t = m_t + c (at_t - a m_t) = f m_t + c at_t,  c = Sa^(1-b), f = 1 - a c
+//   mu_t ~ N(mu_{t-1}, Sm) (mu_{-1} = 0):  mt_t likewise with (a', b', c', f')
+//   y_t ~ N(alpha_t + beta x_t, 0.12)
+//
+// The centred values form a chain in t, so the K = 4 lanes of a chain own consecutive blocks of
+// B = T/4 time steps and the two recurrences are block scans:
+//   forward   (alpha, mu)_t = [[f, f], [0, f']] (alpha, mu)_{t-1} + (c at_t, c' mt_t)
+//   backward  with e_t = d loglik / d alpha_t, z = (at - a m) / Sa^b and the messages
+//             G_t = d logp / d m_t, H_t = d logp / d mu_{t-1} (through mu_t's prior):
+//             Abar_t = e_t + G_{t+1},  Mbar_t = G_{t+1} + H_{t+1},
+//             G_t = f Abar_t + a z / Sa^b,  H_t = f' Mbar_t + a' z' / Sm^b'
+// Both are affine in the incoming pair, so a lane first runs its block with a zero input while
+// composing the block's 2x2 (triangular) map, the three block maps are chained across the quad
+// with DPP broadcasts, and the lane reruns its block with the right input.
+#pragma once
+#include "arp_device.h"
+
+namespace arp {
+
+struct TimeSeriesArgs {
+  const float* x;   // [T] regressor (years)
+  const float* y;   // [T] observations
+  int T;
+};
+
+template <int K_, int NL_>
+struct TimeSeriesLane {
+  static_assert(K_ == 4, "the block scan is written for the four lanes of a quad");
+  static constexpr int K = K_;
+  static constexpr int NG = 3;          // sigma_alpha, sigma_mu, beta
+  static constexpr int NL = NL_;        // trend latents owned by this lane: (alpha, mu) of B consecutive steps
+  static constexpr int B = NL_ / 2;
+  static constexpr int ND = NG + NL;
+  static constexpr int NGRP = NL_;
+  static constexpr int DCAP = NG + K_ * NL_;
+  static constexpr bool HAS_MODES = false;
+  static constexpr bool HAS_CARRY = false;
+  static constexpr bool HAS_FUSED = false;
+  static constexpr bool HAS_VI = true;
+  static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
+  using Args = TimeSeriesArgs;
+
+  float xt[B], yt[B], aA[B], bA[B], aM[B], bM[B];
+  int slot, T;
+
+  // flattened indices: the lane's latents are one consecutive run; beta sits behind all of them
+  ARP_DEV int gg(int i) const { return i < 2 ? i : 2 + 2 * T; }
+  ARP_DEV int lbase(int) const { return 2 + slot * NL; }
+  static constexpr ARP_DEV int loff(int i) { return i; }
+  ARP_DEV int lidx(int i) const { return 2 + slot * NL + i; }
+  ARP_DEV bool lvalid(int) const { return true; }   // the host only accepts T == K * B
+
+  ARP_DEV void init(const Args& A, const float* av, const float* bv, int slot_) {
+    slot = slot_;
+    T = A.T;
+#pragma unroll
+    for (int tl = 0; tl < B; ++tl) { xt[tl] = A.x[slot * B + tl]; yt[tl] = A.y[slot * B + tl]; }
+    set_param(av, bv);
+  }
+  ARP_DEV void set_param(const float* av, const float* bv) {
+#pragma unroll
+    for (int tl = 0; tl < B; ++tl) {
+      const int i = 2 + slot * NL + 2 * tl;
+      aA[tl] = av[i]; bA[tl] = bv[i]; aM[tl] = av[i + 1]; bM[tl] = bv[i + 1];
+    }
+  }
+
+  // value held by slot S of the chain's quad, in every lane
+  template <int S>
+  static ARP_DEV float from_slot(float v) { return dpp_mov<S | (S << 2) | (S << 4) | (S << 6)>(v); }
+  // value held by the previous slot (slot 0 receives its own; callers mask it)
+  static ARP_DEV float from_prev(float v) { return dpp_mov<0x90>(v); }   // quad_perm [0,0,1,2]
+
+  struct Scales { float Sa, Sm, lSa, lSm; };
+  ARP_DEV Scales scales(float sa, float sm) const {
+    Scales s;
+    s.Sa = softplusf_(sa); s.Sm = softplusf_(sm);
+    s.lSa = fast_log(s.Sa); s.lSm = fast_log(s.Sm);
+    return s;
+  }
+
+  // Forward block scan: centred (alpha_t, mu_t) of this lane's steps; eA/eM = Sa^-b, Sm^-b' per step.
+  ARP_DEV void forward(const float (&q)[ND], const Scales& S, float (&al)[B], float (&mu)[B], float (&eA)[B],
+                       float (&eM)[B]) const {
+    // pass 1: zero input, compose the block map (alpha, mu)_out = [[p11, p12], [0, p22]] in + (da, dm)
+    float p11 = 1.0f, p12 = 0.0f, p22 = 1.0f, da = 0.0f, dm = 0.0f;
+#pragma unroll
+    for (int tl = 0; tl < B; ++tl) {
+      eA[tl] = fast_exp(-bA[tl] * S.lSa);
+      eM[tl] = fast_exp(-bM[tl] * S.lSm);
+      const float cA = S.Sa * eA[tl], cM = S.Sm * eM[tl];
+      const float fA = fmaf(-aA[tl], cA, 1.0f), fM = fmaf(-aM[tl], cM, 1.0f);
+      p12 = fA * (p12 + p22); p11 = fA * p11; p22 = fM * p22;
+      da = fmaf(fA, da + dm, cA * q[NG + 2 * tl]);
+      dm = fmaf(fM, dm, cM * q[NG + 2 * tl + 1]);
+    }
+    // chain the maps of slots 0, 1, 2: the input of slot s is the output of slots 0 .. s-1 applied to (0, 0)
+    const float a1 = from_slot<0>(da), m1 = from_slot<0>(dm);
+    const float a2 = fmaf(from_slot<1>(p11), a1, fmaf(from_slot<1>(p12), m1, from_slot<1>(da)));
+    const float m2 = fmaf(from_slot<1>(p22), m1, from_slot<1>(dm));
+    const float a3 = fmaf(from_slot<2>(p11), a2, fmaf(from_slot<2>(p12), m2, from_slot<2>(da)));
+    const float m3 = fmaf(from_slot<2>(p22), m2, from_slot<2>(dm));
+    float ap = slot == 0 ? 0.0f : (slot == 1 ? a1 : (slot == 2 ? a2 : a3));
+    float mp = slot == 0 ? 0.0f : (slot == 1 ? m1 : (slot == 2 ? m2 : m3));
+    // pass 2: the block with its real input
+#pragma unroll
+    for (int tl = 0; tl < B; ++tl) {
+      const float cA = S.Sa * eA[tl], cM = S.Sm * eM[tl];
+      const float mA = ap + mp;
+      al[tl] = fmaf(cA, fmaf(-aA[tl], mA, q[NG + 2 * tl]), mA);
+      mu[tl] = fmaf(cM, fmaf(-aM[tl], mp, q[NG + 2 * tl + 1]), mp);
+      ap = al[tl]; mp = mu[tl];
+    }
+  }
+
+  // (alpha, mu) at the step before this lane's first (zero for slot 0)
+  ARP_DEV void incoming(const float (&al)[B], const float (&mu)[B], float& ap, float& mp) const {
+    ap = from_prev(al[B - 1]); mp = from_prev(mu[B - 1]);
+    ap = slot == 0 ? 0.0f : ap; mp = slot == 0 ? 0.0f : mp;
+  }
+
+  template <bool LOGP>
+  ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const {
+    const float s2i = 69.44444444444444f;   // 1 / 0.12^2
+    const float sa = q[0], sm = q[1], beta = q[2];
+    const Scales S = scales(sa, sm);
+    float al[B], mu[B], eA[B], eM[B];
+    forward(q, S, al, mu, eA, eM);
+    float ap, mp;
+    incoming(al, mu, ap, mp);
+    // residuals: e_t, z_t, z'_t (al / mu are overwritten by zA / zM)
+    float e[B], lp = 0.0f, g_beta = 0.0f;
+#pragma unroll
+    for (int tl = 0; tl < B; ++tl) {
+      const float mA = ap + mp, alpha = al[tl], mut = mu[tl];
+      const float res = (yt[tl] - alpha) - beta * xt[tl];
+      e[tl] = res * s2i;
+      g_beta = fmaf(e[tl], xt[tl], g_beta);
+      const float zA = fmaf(-aA[tl], mA, q[NG + 2 * tl]) * eA[tl];
+      const float zM = fmaf(-aM[tl], mp, q[NG + 2 * tl + 1]) * eM[tl];
+      if (LOGP) lp += fmaf(-0.5f * zA, zA, fmaf(-0.5f * zM, zM, fmaf(-0.5f * res, e[tl], -(bA[tl] * S.lSa + bM[tl] * S.lSm))));
+      al[tl] = zA; mu[tl] = zM;
+      ap = alpha; mp = mut;
+    }
+    // backward pass 1: zero input, compose (G, H)_out = [[r11, 0], [r21, r22]] in + (oG, oH)
+    float r11 = 1.0f, r21 = 0.0f, r22 = 1.0f, oG = 0.0f, oH = 0.0f;
+#pragma unroll
+    for (int tl = B - 1; tl >= 0; --tl) {
+      const float cA = S.Sa * eA[tl], cM = S.Sm * eM[tl];
+      const float fA = fmaf(-aA[tl], cA, 1.0f), fM = fmaf(-aM[tl], cM, 1.0f);
+      const float kA = aA[tl] * al[tl] * eA[tl], kM = aM[tl] * mu[tl] * eM[tl];
+      r21 = fM * (r11 + r21); r11 = fA * r11; r22 = fM * r22;
+      const float nH = fmaf(fM, oG + oH, kM);
+      oG = fmaf(fA, e[tl] + oG, kA);
+      oH = nH;
+    }
+    // chain from the last slot down: the input of slot s is the output of slots 3 .. s+1 applied to (0, 0)
+    const float G2 = from_slot<3>(oG), H2 = from_slot<3>(oH);
+    const float G1 = fmaf(from_slot<2>(r11), G2, from_slot<2>(oG));
+    const float H1 = fmaf(from_slot<2>(r21), G2, fmaf(from_slot<2>(r22), H2, from_slot<2>(oH)));
+    const float G0 = fmaf(from_slot<1>(r11), G1, from_slot<1>(oG));
+    const float H0 = fmaf(from_slot<1>(r21), G1, fmaf(from_slot<1>(r22), H1, from_slot<1>(oH)));
+    float G = slot == 3 ? 0.0f : (slot == 2 ? G2 : (slot == 1 ? G1 : G0));
+    float H = slot == 3 ? 0.0f : (slot == 2 ? H2 : (slot == 1 ? H1 : H0));
+    // backward pass 2: gradients
+    float g_lSa = 0.0f, g_lSm = 0.0f;
+#pragma unroll
+    for (int tl = B - 1; tl >= 0; --tl) {
+      const float cA = S.Sa * eA[tl], cM = S.Sm * eM[tl];
+      const float fA = fmaf(-aA[tl], cA, 1.0f), fM = fmaf(-aM[tl], cM, 1.0f);
+      const float zA = al[tl], zM = mu[tl];
+      const float Ab = e[tl] + G, Mb = G + H;
+      g[NG + 2 * tl] = fmaf(cA, Ab, -zA * eA[tl]);
+      g[NG + 2 * tl + 1] = fmaf(cM, Mb, -zM * eM[tl]);
+      g_lSa += fmaf(Ab * (1.0f - bA[tl]), zA * S.Sa, bA[tl] * fmaf(zA, zA, -1.0f));
+      g_lSm += fmaf(Mb * (1.0f - bM[tl]), zM * S.Sm, bM[tl] * fmaf(zM, zM, -1.0f));
+      G = fmaf(fA, Ab, aA[tl] * zA * eA[tl]);
+      H = fmaf(fM, Mb, aM[tl] * zM * eM[tl]);
+    }
+    g_lSa = group_sum<K>(g_lSa);
+    g_lSm = group_sum<K>(g_lSm);
+    g_beta = group_sum<K>(g_beta);
+    g[0] = fmaf(g_lSa, sigmoidf_(sa) * __builtin_amdgcn_rcpf(S.Sa), -sa);
+    g[1] = fmaf(g_lSm, sigmoidf_(sm) * __builtin_amdgcn_rcpf(S.Sm), -sm);
+    g[2] = g_beta - beta;
+    if (LOGP) lp = group_sum<K>(lp) - 0.5f * (sa * sa + sm * sm + beta * beta);
+    return lp;
+  }
+
+  // d logp / d a = -loc g, d logp / d b = -log(scale) (1 + (xt - a loc) g) (see model_radon.h)
+  ARP_DEV void dparam(const float (&q)[ND], const float (&g)[ND], float (&da)[ND], float (&db)[ND]) const {
+    const Scales S = scales(q[0], q[1]);
+    float al[B], mu[B], eA[B], eM[B];
+    forward(q, S, al, mu, eA, eM);
+    float ap, mp;
+    incoming(al, mu, ap, mp);
+    da[0] = da[1] = da[2] = 0.0f; db[0] = db[1] = db[2] = 0.0f;
+#pragma unroll
+    for (int tl = 0; tl < B; ++tl) {
+      const float mA = ap + mp;
+      da[NG + 2 * tl] = -mA * g[NG + 2 * tl];
+      da[NG + 2 * tl + 1] = -mp * g[NG + 2 * tl + 1];
+      db[NG + 2 * tl] = -S.lSa * fmaf(fmaf(-aA[tl], mA, q[NG + 2 * tl]), g[NG + 2 * tl], 1.0f);
+      db[NG + 2 * tl + 1] = -S.lSm * fmaf(fmaf(-aM[tl], mp, q[NG + 2 * tl + 1]), g[NG + 2 * tl + 1], 1.0f);
+      ap = al[tl]; mp = mu[tl];
+    }
+  }
+
+  ARP_DEV void to_centered(const float (&q)[ND], float (&x)[ND]) const {
+    const Scales S = scales(q[0], q[1]);
+    float al[B], mu[B], eA[B], eM[B];
+    forward(q, S, al, mu, eA, eM);
+    x[0] = q[0]; x[1] = q[1]; x[2] = q[2];
+#pragma unroll
+    for (int tl = 0; tl < B; ++tl) { x[NG + 2 * tl] = al[tl]; x[NG + 2 * tl + 1] = mu[tl]; }
+  }
+  ARP_DEV void from_centered(const float (&x)[ND], float (&q)[ND]) const {
+    const Scales S = scales(x[0], x[1]);
+    q[0] = x[0]; q[1] = x[1]; q[2] = x[2];
+    // every location is a centred value: only the step before the lane's first comes from the neighbour
+    float ap = from_prev(x[NG + NL - 2]), mp = from_prev(x[NG + NL - 1]);
+    ap = slot == 0 ? 0.0f : ap; mp = slot == 0 ? 0.0f : mp;
+#pragma unroll
+    for (int tl = 0; tl < B; ++tl) {
+      const float mA = ap + mp;
+      q[NG + 2 * tl] = fmaf(x[NG + 2 * tl] - mA, fast_exp(-(1.0f - bA[tl]) * S.lSa), aA[tl] * mA);
+      q[NG + 2 * tl + 1] = fmaf(x[NG + 2 * tl + 1] - mp, fast_exp(-(1.0f - bM[tl]) * S.lSm), aM[tl] * mp);
+      ap = x[NG + 2 * tl]; mp = x[NG + 2 * tl + 1];
+    }
+  }
+};
+
+}  // namespace arp

@@ -105,6 +105,8 @@ class ModelSpec(object):
             d.y_host = f32(r["y"])
         elif self.model_id == _lib.MODEL_NEALS_FUNNEL:
             pass
+        elif self.model_id == _lib.MODEL_TIME_SERIES:
+            d.n_obs = len(r["y"]); d.x_host = f32(r["x"]); d.y_host = f32(r["y"])
         elif self.model_id == _lib.MODEL_ELECTRIC:
             if int(r["n_grade"]) != int(r["n_grade_pair"]):
                 raise ValueError("electric: n_grade and n_grade_pair must agree")
@@ -160,6 +162,15 @@ def _spec_electric():
                      [(int(r["n_grade_pair"]),), (G,), (P, 1), (G,)], r, {"y": r["y"]})
 
 
+def _spec_time_series():
+    """local linear trend (reference models.py:1069-1141): every latent is its own scalar random variable, in
+    trace order sigma_alpha, sigma_mu, alpha0, mu0, alpha1, mu1, ..., beta."""
+    r = _load("time_series.npz")
+    T = len(r["y"])
+    names = ["sigma_alpha", "sigma_mu"] + [n for t in range(T) for n in ("alpha%d" % t, "mu%d" % t)] + ["beta"]
+    return ModelSpec("time_series", _lib.MODEL_TIME_SERIES, names, [()] * len(names), r, {"y": r["y"]})
+
+
 def _spec_german():
     r = _load("german_credit.npz")
     F = r["X"].shape[1]
@@ -187,13 +198,15 @@ def get_model_by_name(model_name, dataset=None):
         spec = _spec_radon_stddvs(dataset if dataset else "MN")
     elif model_name == "electric":
         spec = _spec_electric()
+    elif model_name == "time_series":
+        spec = _spec_time_series()
     elif model_name == "german_credit_lognormalcentered":
         spec = _spec_german()
     elif model_name in ("election", "election88"):
         spec = _spec_election()
     else:
         raise Exception("unknown model {} (this build covers 8schools, radon, radon_stddvs, "
-                        "neals_funnel, electric, german_credit_lognormalcentered, election)".format(model_name))
+                        "neals_funnel, electric, time_series, german_credit_lognormalcentered, election)".format(model_name))
     from . import engine  # deferred: converters run on the device
 
     varnames = spec.part_names

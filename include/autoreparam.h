@@ -39,7 +39,8 @@ enum {
   ARP_MODEL_ELECTION = 3,
   ARP_MODEL_NEALS_FUNNEL = 5, /* models.py:671-696; no dataset fields are read */
   ARP_MODEL_RADON_STDDVS = 4, /* radon with per-county observation scales, models.py:763-806 */
-  ARP_MODEL_ELECTRIC = 6      /* electric company, models.py:1011-1066 */
+  ARP_MODEL_ELECTRIC = 6,     /* electric company, models.py:1011-1066 */
+  ARP_MODEL_TIME_SERIES = 7   /* local linear trend, models.py:1069-1141: n_obs = T, x = years, y = series */
 };
 
 /* Step-size adaptation wrapped around the HMC transition. */

@@ -35,7 +35,7 @@ def lib():
             build()
         _lib = C.CDLL(LIB_PATH)
         for f in ("orc_radon_create", "orc_schools_create", "orc_election_create", "orc_german_create",
-                  "orc_radon_sd_create", "orc_funnel_create", "orc_electric_create"):
+                  "orc_radon_sd_create", "orc_funnel_create", "orc_electric_create", "orc_time_series_create"):
             getattr(_lib, f).restype = C.c_void_p
         _lib.orc_model_dim.argtypes = [C.c_void_p]
         _lib.orc_model_destroy.argtypes = [C.c_void_p]
@@ -64,6 +64,9 @@ class OracleModel(object):
             self._h = C.c_void_p(create(len(y), len(u), _p(county), _p(u), _p(x), _p(y)))
         elif spec.name == "neals_funnel":
             self._h = C.c_void_p(L.orc_funnel_create())
+        elif spec.name == "time_series":
+            x = np.ascontiguousarray(r["x"], np.float32); y = np.ascontiguousarray(r["y"], np.float32)
+            self._h = C.c_void_p(L.orc_time_series_create(len(y), _p(x), _p(y)))
         elif spec.name == "electric":
             i32 = lambda k: np.ascontiguousarray(r[k], np.int32)
             pr, gr, gp = i32("pair"), i32("grade"), i32("grade_pair")
@@ -101,7 +104,7 @@ class OracleModel(object):
         S = self.D - 4
         top = {"8schools": [(0, 5.0), (1, 5.0)], "radon": [], "radon_stddvs": [], "neals_funnel": [(0, 3.0)],
                "german_credit_lognormalcentered": [(0, 10.0)],
-               "electric": [(self.D - 4 + k, 100.0) for k in range(4)],
+               "electric": [(self.D - 4 + k, 100.0) for k in range(4)], "time_series": [],
                "election": [(0, 100.0), (1, 10.0), (2 + S, 100.0), (3 + S, 100.0)]}[self.spec.name]
         return c + sum((1.0 - float(b[i])) * np.log(s) for i, s in top)
 
@@ -166,7 +169,7 @@ OracleModel.interleaved_run = _interleaved
 
 _TOP = {"8schools": lambda D: [(0, 5.0), (1, 5.0)], "radon": lambda D: [], "radon_stddvs": lambda D: [], "neals_funnel": lambda D: [(0, 3.0)],
         "german_credit_lognormalcentered": lambda D: [(0, 10.0)],
-        "electric": lambda D: [(D - 4 + k, 100.0) for k in range(4)],
+        "electric": lambda D: [(D - 4 + k, 100.0) for k in range(4)], "time_series": lambda D: [],
         "election": lambda D: [(0, 100.0), (1, 10.0), (D - 2, 100.0), (D - 1, 100.0)]}
 
 

@@ -10,7 +10,7 @@ here).
 
 Restated from (behaviour, not code):
   models.py:139-147 (schools), 826-837 (radon), 888-904 (german credit),
-  969-982 (election), 1013-1035 (electric);
+  969-982 (election), 1013-1035 (electric), 1071-1094 (time_series);
   program_transformations.py:110-139 (log joint = sum of rv.log_prob over all
   RVs and elements), 262-279 (ncp: every Normal not named y*), 486-533 + 555-600
   (VIP: xt ~ N(a mu, sigma^b), x = mu + sigma/sigma^b (xt - a mu); missing `_b`
@@ -172,7 +172,22 @@ def electric_program(r, raw):
     r.normal("y", y_hat, torch.exp(sigma_y_hat.reshape(-1)))
 
 
-PROGRAMS = {"electric": electric_program, "8schools": schools_program, "radon": radon_program, "radon_stddvs": radon_stddvs_program, "neals_funnel": funnel_program,
+def time_series_program(r, raw):
+    # models.py:1071-1094: every latent is its own scalar RV; scales are softplus of the sigma latents
+    T = len(raw["y"])
+    sp = torch.nn.functional.softplus
+    sigma_alpha = r.normal("sigma_alpha", 0.0, 1.0)
+    sigma_mu = r.normal("sigma_mu", 0.0, 1.0)
+    alpha = [r.normal("alpha0", 0.0, sp(sigma_alpha))]
+    mu = [r.normal("mu0", 0.0, sp(sigma_mu))]
+    for t in range(1, T):
+        alpha.append(r.normal("alpha%d" % t, alpha[t - 1] + mu[t - 1], sp(sigma_alpha)))
+        mu.append(r.normal("mu%d" % t, mu[t - 1], sp(sigma_mu)))
+    beta = r.normal("beta", 0.0, 1.0)
+    r.normal("y", torch.stack(alpha) + beta * _t(raw["x"]), 0.12)
+
+
+PROGRAMS = {"time_series": time_series_program, "electric": electric_program, "8schools": schools_program, "radon": radon_program, "radon_stddvs": radon_stddvs_program, "neals_funnel": funnel_program,
             "german_credit_lognormalcentered": german_program, "election": election_program}
 
 

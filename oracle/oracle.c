@@ -8,7 +8,7 @@
  * bench.py's cpu_baseline leg; the product path (autoreparam_amd/) never links
  * or calls it.  PARITY UNPINNED (see oracle_impl.h).
  *
- * Reference files restated: models.py:131-166, 671-696, 763-857, 884-923, 967-1066
+ * Reference files restated: models.py:131-166, 671-696, 763-857, 884-923, 967-1141
  * (densities), program_transformations.py:262-279, 555-600 (NCP / VIP algebra),
  * inference.py:198-242 (HMC wiring, step scaling, thinning),
  * interleaved.py:113-155 (interleaving order).  TFP internals (leapfrog,
@@ -236,6 +236,22 @@ orc_model* orc_electric_create(int N, int P, int G, const int32_t* pair, const i
   for (int i = 0; i < N; ++i) { M->pair[i] = pair[i]; M->grade[i] = grade[i]; M->treat[i] = treatment[i]; M->y[i] = y[i]; }
   for (int j = 0; j < P; ++j) M->grade_pair[j] = grade_pair[j];
   M->logp_const = -(double)(M->D + N) * HALF_LOG_2PI - G * log(100.0);
+  return M;
+}
+
+/* reference models.py:1069-1141.  Parts: sigma_alpha, sigma_mu, alpha0, mu0, ..., alpha{T-1}, mu{T-1}, beta. */
+orc_model* orc_time_series_create(int T, const float* x, const float* y) {
+  orc_model* M = (orc_model*)calloc(1, sizeof(orc_model));
+  M->model = 7; M->N = T; M->D = 3 + 2 * T;
+  /* RNG stream layout: sigma_alpha, sigma_mu, beta are replicated; the 2T trend latents are one
+   * part sliced in consecutive runs (slot s owns elements s*per_lane .. (s+1)*per_lane-1) */
+  M->n_glob = 3; M->n_groups = 2 * T; M->n_local_parts = 1; M->contig = 1;
+  M->glob_idx[0] = 0; M->glob_idx[1] = 1; M->glob_idx[2] = 2 + 2 * T;
+  M->group_idx = (int*)malloc(sizeof(int) * 2 * T);
+  for (int j = 0; j < 2 * T; ++j) M->group_idx[j] = 2 + j;
+  M->u = (float*)malloc(sizeof(float) * T); M->y = (float*)malloc(sizeof(float) * T);
+  for (int t = 0; t < T; ++t) { M->u[t] = x[t]; M->y[t] = y[t]; }
+  M->logp_const = -(double)(M->D + T) * HALF_LOG_2PI - T * log(0.12);
   return M;
 }
 

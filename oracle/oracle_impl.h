@@ -389,6 +389,78 @@ static void FN(electric_convert)(const orc_model* M, const float* a, const float
   }
 }
 
+/* local linear trend ("time_series"), reference models.py:1071-1094.  x = [sa, sm, (at_t, mt_t) t < T, beta].
+ *   sa, sm, beta ~ N(0,1);  Sa = softplus(sa), Sm = softplus(sm)
+ *   alpha_t ~ N(m_t, Sa), m_t = alpha_{t-1} + mu_{t-1} (m_0 = 0):  at_t ~ N(a m_t, Sa^b), alpha_t = m_t + Sa^(1-b) (at_t - a m_t)
+ *   mu_t ~ N(mu_{t-1}, Sm) (mu_{-1} = 0):                          mt_t ~ N(a' mu_{t-1}, Sm^b'), likewise
+ *   y_t ~ N(alpha_t + beta x_t, 0.12)
+ * Forward recurrence in t, then the adjoint recurrence backwards: with e_t = d loglik / d alpha_t,
+ * z_t = (at_t - a m_t) / Sa^b and the messages G_t = d logp / d m_t, H_t = d logp / d mu_{t-1} (through mu_t's prior),
+ *   Abar_t = e_t + G_{t+1},  Mbar_t = G_{t+1} + H_{t+1},
+ *   G_t = (1 - a c) Abar_t + a z / Sa^b,  H_t = (1 - a' c') Mbar_t + a' z' / Sm^b',  c = Sa^(1-b), c' = Sm^(1-b'). */
+static REAL FN(time_series_run)(const orc_model* M, const float* a, const float* b, const REAL* x, REAL* g,
+                                REAL* centred, REAL* mloc) {
+  const int T = M->N, iB = 2 + 2 * T;
+  const REAL s2i = (REAL)(1.0 / (0.12 * 0.12));
+  const REAL sa = x[0], sm = x[1], beta = x[iB];
+  const REAL Sa = (REAL)log1p(exp((double)sa)), Sm = (REAL)log1p(exp((double)sm));
+  const REAL lSa = (REAL)log((double)Sa), lSm = (REAL)log((double)Sm);
+  REAL al[T], mu[T], zA[T], zM[T], e[T];
+  REAL lp = -(REAL)0.5 * (sa * sa + sm * sm + beta * beta);
+  REAL ap = 0, mp = 0;
+  for (int t = 0; t < T; ++t) {
+    const int iA = 2 + 2 * t, iM = 3 + 2 * t;
+    const REAL mA = ap + mp, mM = mp;                 /* locations (centred parents) */
+    const REAL cA = (REAL)exp((double)((1 - b[iA]) * lSa)), cM = (REAL)exp((double)((1 - b[iM]) * lSm));
+    const REAL rA = x[iA] - a[iA] * mA, rM = x[iM] - a[iM] * mM;
+    al[t] = mA + cA * rA; mu[t] = mM + cM * rM;
+    zA[t] = rA * (REAL)exp((double)(-b[iA] * lSa)); zM[t] = rM * (REAL)exp((double)(-b[iM] * lSm));
+    const REAL res = (REAL)M->y[t] - al[t] - beta * (REAL)M->u[t];
+    e[t] = res * s2i;
+    lp += -(REAL)0.5 * zA[t] * zA[t] - b[iA] * lSa - (REAL)0.5 * zM[t] * zM[t] - b[iM] * lSm - (REAL)0.5 * res * res * s2i;
+    if (centred) { centred[iA] = al[t]; centred[iM] = mu[t]; }
+    if (mloc) { mloc[iA] = mA; mloc[iM] = mM; }
+    ap = al[t]; mp = mu[t];
+  }
+  if (!g) return lp;
+  REAL G = 0, H = 0, g_lSa = 0, g_lSm = 0, g_beta = -beta;
+  for (int t = T - 1; t >= 0; --t) {
+    const int iA = 2 + 2 * t, iM = 3 + 2 * t;
+    const REAL cA = (REAL)exp((double)((1 - b[iA]) * lSa)), cM = (REAL)exp((double)((1 - b[iM]) * lSm));
+    const REAL eA = (REAL)exp((double)(-b[iA] * lSa)), eM = (REAL)exp((double)(-b[iM] * lSm));
+    const REAL Ab = e[t] + G, Mb = G + H;
+    g[iA] = cA * Ab - zA[t] * eA;
+    g[iM] = cM * Mb - zM[t] * eM;
+    g_lSa += Ab * (1 - b[iA]) * zA[t] * Sa + b[iA] * (zA[t] * zA[t] - 1);
+    g_lSm += Mb * (1 - b[iM]) * zM[t] * Sm + b[iM] * (zM[t] * zM[t] - 1);
+    g_beta += e[t] * (REAL)M->u[t];
+    G = (1 - a[iA] * cA) * Ab + a[iA] * zA[t] * eA;
+    H = (1 - a[iM] * cM) * Mb + a[iM] * zM[t] * eM;
+  }
+  g[0] = -sa + g_lSa * (REAL)(1.0 / (1.0 + exp(-(double)sa))) / Sa;
+  g[1] = -sm + g_lSm * (REAL)(1.0 / (1.0 + exp(-(double)sm))) / Sm;
+  g[iB] = g_beta;
+  return lp;
+}
+static REAL FN(time_series_logp_grad)(const orc_model* M, const float* a, const float* b, const REAL* x, REAL* g) {
+  return FN(time_series_run)(M, a, b, x, g, NULL, NULL);
+}
+static void FN(time_series_convert)(const orc_model* M, const float* a, const float* b, const REAL* x,
+                                    REAL* out, int to_centered) {
+  const int T = M->N, iB = 2 + 2 * T;
+  out[0] = x[0]; out[1] = x[1]; out[iB] = x[iB];
+  if (to_centered) { FN(time_series_run)(M, a, b, x, NULL, out, NULL); return; }
+  const REAL lSa = (REAL)log(log1p(exp((double)x[0]))), lSm = (REAL)log(log1p(exp((double)x[1])));
+  REAL ap = 0, mp = 0;
+  for (int t = 0; t < T; ++t) {   /* x holds centred values: every location is known */
+    const int iA = 2 + 2 * t, iM = 3 + 2 * t;
+    const REAL mA = ap + mp, mM = mp;
+    out[iA] = a[iA] * mA + (x[iA] - mA) * (REAL)exp((double)(-(1 - b[iA]) * lSa));
+    out[iM] = a[iM] * mM + (x[iM] - mM) * (REAL)exp((double)(-(1 - b[iM]) * lSm));
+    ap = x[iA]; mp = x[iM];
+  }
+}
+
 /* dispatch */
 static REAL FN(logp_grad)(const orc_model* M, const float* a, const float* b, const REAL* x, REAL* g) {
   switch (M->model) {
@@ -399,6 +471,7 @@ static REAL FN(logp_grad)(const orc_model* M, const float* a, const float* b, co
     case 4: return FN(radon_sd_logp_grad)(M, a, b, x, g);
     case 5: return FN(funnel_logp_grad)(M, a, b, x, g);
     case 6: return FN(electric_logp_grad)(M, a, b, x, g);
+    case 7: return FN(time_series_logp_grad)(M, a, b, x, g);
     default: return (REAL)NAN;
   }
 }
@@ -411,6 +484,7 @@ static void FN(to_centered)(const orc_model* M, const float* a, const float* b, 
     case 4: FN(radon_sd_convert)(M, a, b, x, o, 1); break;
     case 5: FN(funnel_convert)(M, a, b, x, o, 1); break;
     case 6: FN(electric_convert)(M, a, b, x, o, 1); break;
+    case 7: FN(time_series_convert)(M, a, b, x, o, 1); break;
     default: break;
   }
 }
@@ -423,6 +497,7 @@ static void FN(from_centered)(const orc_model* M, const float* a, const float* b
     case 4: FN(radon_sd_convert)(M, a, b, x, o, 0); break;
     case 5: FN(funnel_convert)(M, a, b, x, o, 0); break;
     case 6: FN(electric_convert)(M, a, b, x, o, 0); break;
+    case 7: FN(time_series_convert)(M, a, b, x, o, 0); break;
     default: break;
   }
 }
@@ -708,6 +783,12 @@ static void FN(dparam)(const orc_model* M, const float* a, const float* b, const
     case 3: ls[0] = (REAL)log(100.0); ls[1] = (REAL)log(10.0);
       ls[2 + M->S] = ls[3 + M->S] = (REAL)log(100.0);
       for (int t = 0; t < M->S; ++t) { mu[2 + t] = xc[0]; ls[2 + t] = xc[1]; } break;
+    case 7: {
+      FN(time_series_run)(M, a, b, x, NULL, NULL, mu);   /* locations of every trend latent */
+      const REAL lSa = (REAL)log(log1p(exp((double)x[0]))), lSm = (REAL)log(log1p(exp((double)x[1])));
+      for (int t = 0; t < M->N; ++t) { ls[2 + 2 * t] = lSa; ls[3 + 2 * t] = lSm; }
+      break;
+    }
     case 6:
       for (int k = 0; k < M->G; ++k) ls[2 * M->G + M->P + k] = (REAL)log(100.0);
       for (int j = 0; j < M->P; ++j) {

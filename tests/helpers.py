@@ -12,6 +12,7 @@ MODEL_SPECS = {
     "funnel": lambda: models._spec_funnel(),
     "election": lambda: models._spec_election(),
     "electric": lambda: models._spec_electric(),
+    "time_series": lambda: models._spec_time_series(),
 }
 _cache = {}
 

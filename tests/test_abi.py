@@ -69,7 +69,7 @@ def test_product_path_does_not_import_oracle():
 def test_enum_values_match_header(built):
     src = open(os.path.join(ROOT, "include", "autoreparam.h")).read()
     enums = {k: int(v) for k, v in re.findall(r"\b(ARP_[A-Z_0-9]+)\s*=\s*(\d+)", src)}
-    assert len([k for k in enums if k.startswith("ARP_MODEL_")]) == 7
+    assert len([k for k in enums if k.startswith("ARP_MODEL_")]) == 8
     for k, v in enums.items():
         if k.startswith("ARP_MODEL_"):
             assert getattr(built, k[4:]) == v, k          # _lib.MODEL_*

@@ -14,6 +14,8 @@ What is restated (behaviour, not code) and where it comes from:
                   blocks per categorical column, in column order).
   * election88 -- reference models.py:984-989 reading data/election88.py.
   * 8schools   -- constants at reference models.py:134-137.
+  * time_series -- the two constant lists at reference models.py:1096-1112 (years 1959-2018 and the
+                  annual series they index).
   * electric   -- reference models.py:1038-1046 reading data/electric.py (pair, grade and
                   grade_pair stay 1-based, exactly as they are fed to tf.one_hot).
 
@@ -121,6 +123,18 @@ def electric():
                 y=np.asarray(d["y"], dtype=np.float32))
 
 
+def time_series():
+    x = np.arange(1959, 2019, dtype=np.float32)
+    y = np.array([
+        315.97, 316.91, 317.64, 318.45, 318.99, 319.62, 320.04, 321.38, 322.16, 323.04, 324.62, 325.68, 326.32,
+        327.45, 329.68, 330.18, 331.11, 332.04, 333.83, 335.4, 336.84, 338.75, 340.11, 341.45, 343.05, 344.65,
+        346.12, 347.42, 349.19, 351.57, 353.12, 354.39, 355.61, 356.45, 357.1, 358.83, 360.82, 362.61, 363.73,
+        366.7, 368.38, 369.55, 371.14, 373.28, 375.8, 377.52, 379.8, 381.9, 383.79, 385.6, 387.43, 389.9, 391.65,
+        393.85, 396.52, 398.65, 400.83, 404.24, 406.55, 408.52], dtype=np.float32)
+    assert len(x) == len(y) == 60
+    return dict(x=x, y=y)
+
+
 def schools():
     return dict(y=np.array([28, 8, -3, 7, -1, 1, 18, 12], dtype=np.float32),
                 sigma=np.array([15, 10, 16, 11, 9, 11, 10, 18], dtype=np.float32))
@@ -146,6 +160,7 @@ def main():
     print("election N", e["y"].shape[0])
     np.savez_compressed(os.path.join(args.out, "election88.npz"), **e)
     np.savez_compressed(os.path.join(args.out, "eight_schools.npz"), **schools())
+    np.savez_compressed(os.path.join(args.out, "time_series.npz"), **time_series())
     el = electric()
     print("electric N", el["y"].shape[0], "pairs", int(el["n_pair"]))
     np.savez_compressed(os.path.join(args.out, "electric.npz"), **el)
