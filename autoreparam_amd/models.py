@@ -1,5 +1,6 @@
 """Model definitions for the hot path: the four hierarchical models named by
-BASELINE.json, as frozen data + a model id the HIP engine understands.
+BASELINE.json plus radon_stddvs, neals_funnel, electric and time_series, as frozen
+data + a model id the HIP engine understands.
 
 Mirrors the reference's ``models.get_model_by_name(name, dataset) -> ModelConfig``
 (models.py:51-54, 1144-1175).  In the reference ``ModelConfig.model`` is an
@@ -187,7 +188,8 @@ def _spec_election():
 
 
 def get_model_by_name(model_name, dataset=None):
-    """Reference: models.py:1144-1175 (only the four hot-path models are built)."""
+    """Reference: models.py:1144-1175 (the four BASELINE models and the scalar-Normal hierarchical models of
+    SURVEY 8f-3; the GP / MVN / Wishart models are out of scope)."""
     if model_name == "8schools":
         spec = _spec_eight_schools()
     elif model_name == "radon":
