@@ -491,9 +491,11 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   if (m->D > kViDmax) { set_error("arp_vi_run: model dimension exceeds the VI kernel's limit"); return 1; }
   const auto* fam = family(m);
   if (!fam) { set_error("model family has no kernels"); return 1; }
-  // the VI kernel wants the smallest per-lane slice: the widest lanes-per-chain instantiation
+  // the VI kernel wants the smallest per-lane slice: the widest lanes-per-chain instantiation that has one
+  // (german credit: its matrix-core instantiation)
   int Kmax = 0;
-  for (const auto& o : *fam) Kmax = std::max(Kmax, o.K);
+  for (const auto& o : *fam) if (o.vi) Kmax = std::max(Kmax, o.K);
+  if (m->model == ARP_MODEL_GERMAN_CREDIT) Kmax = 4;
   const LaneOps* o = pick(*fam, m->n_groups, Kmax, 1 << 30, m->model != ARP_MODEL_GERMAN_CREDIT);
   if (!o || !o->vi) { set_error("no VI kernel instantiation covers this group count"); return 1; }
   ViParams P;

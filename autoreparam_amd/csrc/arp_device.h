@@ -9,6 +9,7 @@
 namespace arp {
 
 constexpr int kBlock = 256;      // 4 waves per workgroup
+constexpr int kViBlock = 512;
 
 // register pair for the packed f32 VALU forms (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32)
 typedef float v2f __attribute__((ext_vector_type(2)));

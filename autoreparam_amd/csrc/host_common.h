@@ -86,6 +86,12 @@ struct Launch {
     hipLaunchKernelGGL((interleaved_kernel<Lane, kModeCP, kModeNCP>), dim3(blocks(P.C)), dim3(kBlock), 0, s,
                        *(const typename Lane::Args*)args, a0, b0, a1, b1, P);
   }
+  // only the VI launcher (a lane sized for the VI kernel's workgroup; nothing else is instantiated)
+  static LaneOps vi_only() {
+    LaneOps o{Lane::K, Lane::NGRP, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if constexpr (Lane::HAS_VI) o.vi = &vi;
+    return o;
+  }
   static LaneOps ops() {
     LaneOps o{Lane::K, Lane::NGRP, &logp_grad, &transform, &hmc, &interleaved, nullptr, nullptr, nullptr, nullptr};
     if constexpr (Lane::HAS_VI) o.vi = &vi;

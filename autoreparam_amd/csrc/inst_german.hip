@@ -3,9 +3,13 @@
 #include "host_common.h"
 
 namespace arp {
+// chain kernels from the lanes sized for 4 waves per workgroup, the VI kernel from the 4-lane
+// (matrix-core) instantiation sized for its 8 waves
+static LaneOps with_vi(LaneOps o, const LaneOps& vi) { o.vi = vi.vi; return o; }
 const std::vector<LaneOps>& german_ops() {
   static const std::vector<LaneOps> t = {
-      Launch<GermanLane<4, 16>>::ops(), Launch<GermanLane<8, 8>>::ops(), Launch<GermanLane<16, 4>>::ops(),
+      with_vi(Launch<GermanLane<4, 16>>::ops(), Launch<GermanLane<4, 16, kViBlock / 64>>::vi_only()),
+      Launch<GermanLane<8, 8>>::ops(), Launch<GermanLane<16, 4>>::ops(),
   };
   return t;
 }

@@ -553,7 +553,6 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
 // With learn_a the VIP parameter a = sigmoid(w) is optimised too (cVIP,
 // program_transformations.py:507-510).
 // ---------------------------------------------------------------------------
-constexpr int kViBlock = 512;
 constexpr int kViDmax = kMaxD;
 
 struct ViParams {

@@ -28,7 +28,9 @@ struct GermanArgs {
   int N, F;
 };
 
-template <int K_, int NLS_>
+// W_: waves per workgroup of the kernels the lane is used in (sizes the per-wave LDS areas of the
+// matrix-core path): kBlock / 64 for the chain kernels, kViBlock / 64 for the VI kernel.
+template <int K_, int NLS_, int W_ = kBlock / 64>
 struct GermanLane {
   static constexpr int K = K_;
   static constexpr int NG = 1;          // overall_log_scale
@@ -80,8 +82,8 @@ struct GermanLane {
   // rows per LDS tile: the matrix-core path amortises its two workgroup barriers and the tile hand-over
   // over 128 rows; the others keep 64 so that two workgroups fit a CU
   static constexpr int kRows = K_ == 4 ? 128 : 64;
-  static constexpr int kXchWaves = kBlock / 64;       // waves per workgroup the exchange area covers (chain kernels only)
-  static constexpr bool HAS_VI = K_ != 4;   // the VI kernel (512 threads, always run at the widest K) is not built for K = 4
+  static constexpr int kXchWaves = W_;                // waves per workgroup the exchange area covers
+  static constexpr bool HAS_VI = W_ == kViBlock / 64;   // the VI kernel is built from the lanes sized for its 8 waves
   static constexpr int kXch = 16 * kStride + 64;      // per wave: [16 chains][row] + 64 log-density partials
   static constexpr int kTileFloats = kRows * kStride + kRows + (K_ == 4 ? kXchWaves * kXch : 0);
   // The [rows x 64] design-matrix tile and its outcomes, shared by the workgroup (one copy per
@@ -266,8 +268,8 @@ struct GermanLane {
   // order of a sum is free as long as A and B agree).  The residuals come out with rows 4g+r in
   // register r, which is exactly the B operand of the backward product if its step s takes
   // row 4g+s from lane group g: no movement between the two products.
-  // one tile in flight between global memory and LDS (kTileF4 float4 per thread at 256 threads)
-  static constexpr int kTileF4 = kRows * (kGermanCols / 4) / kBlock;
+  // one tile in flight between global memory and LDS (kTileF4 float4 per thread)
+  static constexpr int kTileF4 = kRows * (kGermanCols / 4) / (64 * W_);
   struct TileRegs {
     float4 x[kTileF4];
     float y;
