@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long float64 CPU runs of the oracle's HMC for the models without a closed-form
-posterior (election, german credit, electric): posterior means / sds of every coordinate
+posterior (election, german credit, electric, radon_stddvs): posterior means / sds of every coordinate
 with Monte-Carlo standard errors.  Written to posterior_golden.npz and
 used by the GPU tests as the known answer for the sampled posterior.
 
@@ -42,7 +42,7 @@ def find_mode(orc, sp, a, b, iters=6000, lr=0.02):
 
 PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "posterior_golden.npz")
 RUNS = (("election", "CP", 8, 256, 1500, 1500), ("german", "NCP", 8, 192, 1500, 1200),
-        ("electric", "NCP", 8, 256, 1500, 1500))
+        ("electric", "NCP", 8, 256, 1500, 1500), ("radon_sd_MN", "CP", 8, 256, 1500, 1500))
 only = sys.argv[1:]
 out = {}
 if only and os.path.exists(PATH):

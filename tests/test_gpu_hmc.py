@@ -260,9 +260,10 @@ def test_eight_schools_posterior_against_quadrature(gpu):
     assert np.abs(m[2:] - e_th).max() < 0.25, (m[2:], e_th)
 
 
-@pytest.mark.parametrize("mname,kind,L,Cn", [("election", "CP", 8, 2048), ("german", "NCP", 8, 768), ("electric", "NCP", 8, 1024)])
+@pytest.mark.parametrize("mname,kind,L,Cn", [("election", "CP", 8, 2048), ("german", "NCP", 8, 768), ("electric", "NCP", 8, 1024),
+                                              ("radon_sd_MN", "CP", 8, 1024)])
 def test_posterior_moments_against_long_cpu_run(gpu, mname, kind, L, Cn):
-    """election / german credit / electric have no closed-form posterior: the known answer is a long float64
+    """election / german credit / electric / radon_stddvs have no closed-form posterior: the known answer is a long float64
     oracle run committed with Monte-Carlo error bars (tests/golden/posterior_golden.npz)."""
     import os
     from autoreparam_amd import engine, _lib
