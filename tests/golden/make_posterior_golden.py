@@ -43,6 +43,9 @@ def find_mode(orc, sp, a, b, iters=6000, lr=0.02):
 PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "posterior_golden.npz")
 RUNS = (("election", "CP", 8, 256, 1500, 1500), ("german", "NCP", 8, 192, 1500, 1200),
         ("electric", "NCP", 8, 256, 1500, 1500), ("radon_sd_MN", "CP", 8, 256, 1500, 1500))
+# (time_series is not here: with a diagonal step-size scale its chains agree between run halves only to 0.24 sd
+#  after 6 000 transitions -- too loose to serve as a known answer; its parity rests on the density, gradient,
+#  converter and trajectory tests)
 only = sys.argv[1:]
 out = {}
 if only and os.path.exists(PATH):
