@@ -92,7 +92,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        try:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL; binds the communicator to this rank's GPU
+        except TypeError:                                     # older torch: no device_id keyword
+            dist.init_process_group("nccl")
 
     from autoreparam_amd import models, engine, _lib
     spec = models._spec_radon(args.dataset)
