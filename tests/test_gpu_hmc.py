@@ -183,6 +183,44 @@ def test_full_size_headline_invariants(gpu):
     np.testing.assert_allclose(m[:3], (1.3389, -0.0480, -0.1026), atol=0.01)
 
 
+def test_full_size_interleaved_posterior(gpu, oracle_lib):
+    """The headline kernel itself (interleaved CP/NCP, radon PA, 65 536 chains, 4 + 4 leapfrog steps, simple
+    adaptation, gradient carried across the coordinate change): pooled posterior means and sds of all 71
+    coordinates against the closed-form Gaussian answer."""
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec("radon_PA")
+    eng = _eng("radon_PA", gpu)
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "CP")
+    eng.set_param(0, "CP"); eng.set_param(1, "NCP")
+    D = sp.D
+    _, g0 = orc.logp_grad(np.zeros((1, D)), a, b)
+    _, gI = orc.logp_grad(np.eye(D), a, b)
+    P = -(gI - g0)
+    mean = np.linalg.solve(P, g0[0]); sd = np.sqrt(np.diag(np.linalg.inv(P)))
+    Cn, S, burn = 65536, 8, 400
+    rs = np.random.RandomState(3)
+    q0 = (mean + 1.5 * sd * rs.randn(Cn, D)).astype(np.float32)
+    st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+    tr = torch.zeros(S, Cn, D, device=gpu)
+    e0 = (0.5 * sd).astype(np.float32)
+    # NCP scales: the county effects are unit-scale residuals there
+    x_ncp = orc.transform(mean[None], *helpers.params(sp, "NCP"), to_centered=False)[0]
+    e1 = e0.copy(); e1[3:] = 0.5
+    eng.interleaved_run(st, e0, e1, 4, 4, 1 + burn + 25 * (S - 1), seed=21, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=300,
+                        n_burnin=burn, thin=25, trace=tr)
+    assert torch.isfinite(st.q).all() and np.isfinite(x_ncp).all()
+    acc0 = st.accept_count.double().mean().item() / st.step
+    acc1 = st.accept_count1.double().mean().item() / st.step
+    assert 0.55 < acc0 < 0.95 and 0.55 < acc1 < 0.95, (acc0, acc1)
+    m = tr.double().mean(dim=(0, 1)).cpu().numpy()
+    v = tr.double().reshape(-1, D).std(dim=0).cpu().numpy()
+    # S * Cn = 524 288 nearly independent draws: Monte-Carlo error of a mean ~ sd / 700
+    assert np.abs((m - mean) / sd).max() < 0.02
+    assert np.abs(m[:3] - mean[:3]).max() <= 0.01 * np.abs(mean[:3]).max()
+    assert np.abs(v / sd - 1).max() < 0.02
+
+
 @pytest.mark.parametrize("mname", ["8schools", "radon_PA", "election", "german", "radon_sd_MN", "funnel", "electric", "time_series"])
 def test_interleaved_matches_oracle(oracle_lib, gpu, mname):
     """Interleaved CP/NCP kernel (interleaved.py:113-155) against the float32 oracle:
