@@ -63,7 +63,7 @@ class ViIO(C.Structure):
 # every symbol include/autoreparam.h declares
 SYMBOLS = ["arp_version", "arp_last_error", "arp_model_create", "arp_model_destroy", "arp_model_dim",
            "arp_model_logp_const", "arp_model_set_param", "arp_logp_grad", "arp_transform",
-           "arp_hmc_run", "arp_interleaved_run", "arp_vi_run"]
+           "arp_hmc_run", "arp_interleaved_run", "arp_vi_run", "arp_ess"]
 
 _lib = None
 
@@ -93,6 +93,7 @@ def lib():
     L.arp_interleaved_run.argtypes = [C.c_void_p, C.POINTER(HmcConfig), C.c_int,
                                       C.POINTER(InterleavedIO), C.c_void_p]
     L.arp_vi_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(ViConfig), C.POINTER(ViIO), C.c_void_p]
+    L.arp_ess.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

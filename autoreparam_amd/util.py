@@ -35,7 +35,24 @@ def variational_inits_from_params(learned_variational_params, param_names, num_i
 
 def effective_sample_size(states, max_chains_per_batch=None):
     """tfp.mcmc.effective_sample_size with its defaults (filter_threshold=0), per chain
-    and element: `states` [S, C, D] (torch, any device) -> [C, D].
+    and element: `states` [S, C, D] (torch) -> [C, D].  A float32 trace on the GPU goes to the
+    engine's own kernel (`arp_ess`: direct auto-covariances up to the first negative one);
+    anything else (the CPU tests) to the FFT form below."""
+    if states.is_cuda and states.dtype == torch.float32:
+        import ctypes as C
+        from . import _lib
+        x = states if states.is_contiguous() else states.contiguous()
+        S, Cn, D = x.shape
+        out = torch.empty(Cn, D, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().arp_ess(C.c_void_p(x.data_ptr()), S, Cn * D, Cn * D, C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
+    return effective_sample_size_fft(states, max_chains_per_batch)
+
+
+def effective_sample_size_fft(states, max_chains_per_batch=None):
+    """The same statistic by FFT: `states` [S, C, D] (torch, any device) -> [C, D].
 
     Restated from the published definition: auto-correlation by FFT of the
     mean-removed series, lag k divided by (S - k) and normalised by lag 0; every

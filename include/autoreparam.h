@@ -173,6 +173,12 @@ typedef struct arp_vi_io {
 } arp_vi_io;
 int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_io* io, void* stream);
 
+/* Effective sample size of every series of a recorded trace (replaces tfp.mcmc.effective_sample_size with its
+ * defaults, inference.py:240, 327): `trace` holds n_samples rows of `row_stride` floats, series i is column i
+ * (i < n_series, e.g. n_series = C*D of a [S][C][D] trace); ess[i] = S / (-1 + 2 sum_k (S-k)/S rho_k) with the
+ * auto-correlations cut at the first negative one.  A constant series gives NaN (0/0), as the reference's does. */
+int arp_ess(const float* trace, int64_t n_samples, int64_t n_series, int64_t row_stride, float* ess, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

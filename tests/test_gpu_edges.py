@@ -109,3 +109,32 @@ def test_electric_rejects_data_its_cell_collapse_cannot_hold(gpu):
     bad.raw["treatment"] = t
     with pytest.raises(RuntimeError, match="0/1"):
         engine.Engine(bad, gpu)
+
+
+def test_native_ess_matches_fft_form_and_ar1(gpu):
+    """arp_ess (direct auto-covariances, cut at the first negative one) against the FFT restatement of
+    tfp.mcmc.effective_sample_size on the same traces, and against the AR(1) known answer
+    ESS / S -> (1 - rho) / (1 + rho)."""
+    from autoreparam_amd import util
+    g = torch.Generator(device="cpu").manual_seed(5)
+    S, Cn, D = 600, 37, 5
+    rho = torch.tensor([0.0, 0.3, 0.6, 0.9, -0.4])
+    e = torch.randn(S, Cn, D, generator=g)
+    x = torch.zeros(S, Cn, D)
+    x[0] = e[0]
+    for t in range(1, S):
+        x[t] = rho * x[t - 1] + torch.sqrt(1 - rho ** 2) * e[t]
+    x = x * torch.tensor([1.0, 10.0, 0.1, 3.0, 1.0]) + torch.tensor([0.0, 100.0, -5.0, 1e3, 0.0])   # scales / offsets
+    xd = x.to(gpu)
+    native = util.effective_sample_size(xd).cpu().numpy()
+    fft = util.effective_sample_size_fft(xd).cpu().numpy()
+    np.testing.assert_allclose(native, fft, rtol=2e-3)
+    expect = ((1 - rho) / (1 + rho)).numpy() * S
+    got = native.mean(axis=0)
+    # positive rho: the truncated estimator is consistent (at rho = 0.9 a 600-sample series is short: looser)
+    assert np.all(np.abs(got[:3] / expect[:3] - 1) < 0.1) and abs(got[3] / expect[3] - 1) < 0.35, (got, expect)
+    # a strided view (sub-range of chains) and a constant series
+    sub = util.effective_sample_size(xd[:, 3:11, :]).cpu().numpy()
+    np.testing.assert_allclose(sub, native[3:11], rtol=1e-6)
+    const = torch.ones(50, 2, 3, device=gpu)
+    assert torch.isnan(util.effective_sample_size(const)).all()
