@@ -221,7 +221,7 @@ def main():
         st3 = engine.ChainState(q0[:Ce])
         tr3 = torch.empty(S_ess, Ce, D, dtype=torch.float32, device=dev)
         tot = 1 + burn + 2 * (S_ess - 1)
-        util.effective_sample_size(tr3[:, :64])          # rocFFT plan creation is not part of the figure
+        util.effective_sample_size(tr3[:, :64])          # first-call (module load) cost is not part of the figure
         torch.cuda.synchronize(); te = time.perf_counter()
         if inter:
             eng.interleaved_run(st3, eps_i, eps_i, num_ls, num_ls, tot, seed=11, adapt_kind=_lib.ADAPT_SIMPLE,
