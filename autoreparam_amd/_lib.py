@@ -51,7 +51,7 @@ class InterleavedIO(C.Structure):
 
 class ViConfig(C.Structure):
     _fields_ = [("n_lr", C.c_int32), ("n_steps", C.c_int32), ("n_mc", C.c_int32),
-                ("learn_a", C.c_int32), ("tied_b", C.c_int32), ("reserved", C.c_int32),
+                ("learn_a", C.c_int32), ("tied_b", C.c_int32), ("a_prior", C.c_int32),
                 ("seed", C.c_uint64)]
 
 

@@ -499,7 +499,7 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   const LaneOps* o = pick(*fam, m->n_groups, Kmax, 1 << 30, m->model != ARP_MODEL_GERMAN_CREDIT);
   if (!o || !o->vi) { set_error("no VI kernel instantiation covers this group count"); return 1; }
   ViParams P;
-  P.n_steps = cfg->n_steps; P.n_mc = cfg->n_mc; P.learn_a = cfg->learn_a; P.tied_b = cfg->tied_b; P.D = m->D;
+  P.n_steps = cfg->n_steps; P.n_mc = cfg->n_mc; P.learn_a = cfg->learn_a; P.tied_b = cfg->tied_b; P.a_prior = cfg->a_prior; P.D = m->D;
   P.seed = cfg->seed;
   P.const_base = (float)m->const_base;
   P.n_top = (int)m->top_scale.size();

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
 constexpr int kViDmax = kMaxD;
 
 struct ViParams {
-  int n_steps, n_mc, learn_a, tied_b, D;
+  int n_steps, n_mc, learn_a, tied_b, a_prior, D;
   unsigned long long seed;
   float const_base;            // parameterisation independent part of the dropped constant
   int n_top; int top_idx[4]; float top_logscale[4];   // -b_i log(scale_i) of the top-level latents
@@ -568,6 +568,15 @@ ARP_DEV float chain_sum(float v) {  // sum over the 64/K chains of a wave, resul
 #pragma unroll
   for (int off = K; off < 64; off <<= 1) v += __shfl_xor(v, off);
   return v;
+}
+
+// d/dx log of the reference's --discrete_prior density on a learnable parameter x in (0,1) (main.py:244-253):
+// Mixture(logits (0,5,0); Laplace(0, 0.1), Uniform(0,1), Laplace(1, 0.1))
+ARP_DEV float discrete_prior_dlogp(float x) {
+  const float w1 = 148.4131591025766f;                 // e^5 (the Laplace components have weight 1 before normalisation)
+  const float l0 = 5.0f * fast_exp(-10.0f * x);          // Laplace(0, 0.1) density at x > 0
+  const float l1 = 5.0f * fast_exp(-10.0f * (1.0f - x)); // Laplace(1, 0.1) density at x < 1
+  return 10.0f * (l1 - l0) / (l0 + w1 + l1);
 }
 
 template <class Lane>
@@ -693,9 +702,11 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
       gr[0] = -s_acc[0][tid] * inv;
       gr[1] = -(s_acc[1][tid] * inv + 1.0f / sgm) * sigmoidf_(rho);
       float a = s_a[tid];
-      gr[2] = P.learn_a ? -((s_acc[2][tid] + (P.tied_b ? s_acc[3][tid] : 0.f)) * inv) * a * (1.0f - a) : 0.f;
+      const float pa = P.a_prior ? discrete_prior_dlogp(a) : 0.f;
+      gr[2] = P.learn_a ? -((s_acc[2][tid] + (P.tied_b ? s_acc[3][tid] : 0.f)) * inv + pa) * a * (1.0f - a) : 0.f;
       float bb = s_b[tid];
-      gr[3] = P.wb ? -(s_acc[3][tid] * inv) * bb * (1.0f - bb) : 0.f;
+      const float pb = P.a_prior ? discrete_prior_dlogp(bb) : 0.f;
+      gr[3] = P.wb ? -(s_acc[3][tid] * inv + pb) * bb * (1.0f - bb) : 0.f;
       float* par[4] = {&loc, &rho, &w, &wb};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {

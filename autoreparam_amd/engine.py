@@ -173,7 +173,7 @@ class Engine(object):
 
 
     # -- mean-field VI ----------------------------------------------------------
-    def vi_run(self, lr, loc, rho, n_steps, n_mc, which=0, w=None, tied_b=False, wb=None, seed=0):
+    def vi_run(self, lr, loc, rho, n_steps, n_mc, which=0, w=None, tied_b=False, wb=None, seed=0, a_prior=False):
         """Run len(lr) independent Adam optimisations of the mean-field ELBO in one launch.
 
         loc, rho (and w, the unconstrained VIP parameter, when given) are [n_lr, D]
@@ -186,6 +186,7 @@ class Engine(object):
         cfg.n_lr, cfg.n_steps, cfg.n_mc = n_lr, int(n_steps), int(n_mc)
         cfg.learn_a = 1 if w is not None else 0
         cfg.tied_b = 1 if tied_b else 0
+        cfg.a_prior = 1 if a_prior else 0   # --discrete_prior on the learnable parameters
         cfg.seed = int(seed)
         io = _lib.ViIO()
         io.lr, io.loc, io.rho, io.w, io.elbo = _ptr(lr_t), _ptr(loc), _ptr(rho), _ptr(w), _ptr(elbo)

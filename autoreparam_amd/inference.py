@@ -22,13 +22,27 @@ InterleavedKernelResults = collections.namedtuple("InterleavedKernelResults", ["
 _MAX_STEPS_PER_LAUNCH = 4096
 
 
+class DiscretePrior(object):
+    """The reference's --discrete_prior (main.py:244-253): Mixture(Categorical(logits=[0, 5, 0]),
+    [Laplace(0, 0.1), Uniform(0, 1), Laplace(1, 0.1)]) on every learnable parameterisation parameter;
+    its log density is added to the VI objective (inference.py:50-54).  Evaluated inside the VI kernel
+    (`arp_vi_config.a_prior`); this object only selects it."""
+
+    def log_prob(self, x):
+        x = np.asarray(x, np.float64)
+        lap0, lap1 = 5.0 * np.exp(-np.abs(x) * 10.0), 5.0 * np.exp(-np.abs(x - 1.0) * 10.0)
+        uni = ((x >= 0) & (x <= 1)).astype(np.float64)
+        return np.log((lap0 + np.exp(5.0) * uni + lap1) / (2.0 + np.exp(5.0)))
+
+
 def find_best_learning_rate(elbo, variational_parameters, learnable_parameters_prior=None,
                             learnable_parameters=None, flags=FLAGS):
     """Optimise the ELBO with every learning rate of the sweep and keep the best run
     (reference inference.py:26-154).  All learning rates run concurrently, one
     workgroup each, inside one kernel launch."""
-    if learnable_parameters_prior is not None:
-        raise NotImplementedError("a prior on the learnable parameterisation (--discrete_prior) is not built")
+    if learnable_parameters_prior is not None and not isinstance(learnable_parameters_prior, DiscretePrior):
+        raise NotImplementedError("the only prior on the learnable parameterisation the engine evaluates is "
+                                  "inference.DiscretePrior (the reference's --discrete_prior mixture)")
     spec = elbo.target.spec
     dev = torch.device(flags.device)
     eng = _engine.engine_for(spec, dev)
@@ -47,7 +61,8 @@ def find_best_learning_rate(elbo, variational_parameters, learnable_parameters_p
         if not elbo.tied:
             wb = torch.zeros(n_lr, D, device=dev)
     timeline = eng.vi_run(lrs, loc, rho, flags.num_optimization_steps, flags.num_mc_samples, which=0, w=w, wb=wb,
-                          seed=flags.seed).cpu().numpy().astype(np.float64)
+                          seed=flags.seed, a_prior=learnable_parameters_prior is not None
+                          ).cpu().numpy().astype(np.float64)
     loc, rho = loc.cpu().numpy(), rho.cpu().numpy()
     scale = np.where(rho > 20, rho, np.log1p(np.exp(np.minimum(rho, 20))))
 

@@ -92,7 +92,8 @@ def run_vi(model_config, results_dir, file_path, flags=FLAGS):
         return
     prior = None
     if flags.discrete_prior:
-        raise NotImplementedError("--discrete_prior is not built")
+        # a mixture of Laplace (not Beta or Kumaraswamy): finite at 0 and 1 (reference main.py:244-253)
+        prior = inference.DiscretePrior()
     start_time = time.time()
     (elbo_final, elbo_timeline, learning_rate, initial_step_size, learned_variational_params,
      learned_reparam) = inference.find_best_learning_rate(

@@ -160,7 +160,9 @@ typedef struct arp_vi_config {
   int32_t n_mc;              /* num_mc_samples (<= 1024) */
   int32_t learn_a;           /* 1: also optimise the VIP parameter a = sigmoid(w) (cVIP) */
   int32_t tied_b;            /* 1: b := a in the density (tied_pparams as intended); 0: b from set_param, or learned via io.wb */
-  int32_t reserved;
+  int32_t a_prior;           /* 0: none; 1: the reference's --discrete_prior on the learnable parameters (main.py:244-253):
+                              * Mixture(logits (0,5,0); Laplace(0,0.1), Uniform(0,1), Laplace(1,0.1)), its log density
+                              * added to the objective (inference.py:50-54) */
   uint64_t seed;
 } arp_vi_config;
 typedef struct arp_vi_io {

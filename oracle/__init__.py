@@ -174,7 +174,7 @@ _TOP = {"8schools": lambda D: [(0, 5.0), (1, 5.0)], "radon": lambda D: [], "rado
 
 
 def _vi_run(self, a, b, lr, loc, rho, w, n_steps, n_mc, learn_a=False, tied_b=False, seed=0, lanes=16, block=512,
-            wb=None):
+            wb=None, a_prior=False):
     """find_best_learning_rate's optimisation loops: returns (elbo [n_lr, n_steps]); loc/rho/w updated in place."""
     dtype = loc.dtype
     n_lr = len(lr)
@@ -187,7 +187,8 @@ def _vi_run(self, a, b, lr, loc, rho, w, n_steps, n_mc, learn_a=False, tied_b=Fa
     f32 = lambda v: np.ascontiguousarray(v, np.float32)
     a, b, lr = f32(a), f32(b), f32(lr)
     getattr(lib(), "orc_vi_run" + self._sfx(dtype))(
-        self._h, _p(a), _p(b), n_lr, n_steps, n_mc, int(learn_a), int(tied_b), C.c_uint64(seed), lanes, block, _p(lr),
+        self._h, _p(a), _p(b), n_lr, n_steps, n_mc, int(learn_a) | (int(a_prior) << 1), int(tied_b), C.c_uint64(seed), lanes, block,
+        _p(lr),
         _p(loc), _p(rho), _p(w) if w is not None else C.c_void_p(0), _p(wb) if wb is not None else C.c_void_p(0),
         _p(elbo), C.c_double(base), len(top), _p(idx), _p(lsc))
     return elbo

@@ -818,10 +818,18 @@ int FN(orc_dparam)(const orc_model* M, const float* a, const float* b, const REA
  * gradients zeroed; learning rate base, base/5 after a third, base/20 after two
  * thirds of the steps.  Draw layout: `block/lanes` streams per slot, sample s uses
  * stream s mod (block/lanes). */
+/* d/dx log Mixture(logits (0,5,0); Laplace(0,0.1), Uniform(0,1), Laplace(1,0.1))(x), 0 < x < 1 (main.py:244-253) */
+static REAL FN(discrete_prior_dlogp)(REAL x) {
+  const double l0 = 5.0 * exp(-10.0 * (double)x), l1 = 5.0 * exp(-10.0 * (1.0 - (double)x));
+  return (REAL)(10.0 * (l1 - l0) / (l0 + exp(5.0) + l1));
+}
+
+/* learn_a: bit 0 = optimise a (cVIP), bit 1 = add the --discrete_prior term (inference.py:50-54) */
 int FN(orc_vi_run)(const orc_model* M, const float* a_in, const float* b_in, int n_lr, int n_steps, int n_mc,
-                   int learn_a, int tied_b, uint64_t seed, int lanes, int block, const float* lr_in,
+                   int learn_a_flags, int tied_b, uint64_t seed, int lanes, int block, const float* lr_in,
                    REAL* loc_io, REAL* rho_io, REAL* w_io, REAL* wb_io, REAL* elbo_out, double const_base, int n_top,
                    const int* top_idx, const double* top_logscale) {
+  const int learn_a = learn_a_flags & 1, a_prior = (learn_a_flags >> 1) & 1;
   const int D = M->D, NG = M->n_glob, G = M->n_groups, P = M->n_local_parts;
   const int per_lane = (G + lanes - 1) / lanes, nd = NG + P * per_lane;
   const int cpp = block / lanes, passes = (n_mc + cpp - 1) / cpp;
@@ -894,8 +902,9 @@ int FN(orc_vi_run)(const orc_model* M, const float* a_in, const float* b_in, int
         REAL gr[4];
         gr[0] = -acc[d] / n_mc;
         gr[1] = -(acc[D + d] / n_mc + 1 / sig[d]) * (REAL)(1.0 / (1.0 + exp(-(double)rho[d])));
-        gr[2] = learn_a ? -((acc[2 * D + d] + (tied_b ? acc[3 * D + d] : 0)) / n_mc) * a[d] * (1 - a[d]) : 0;
-        gr[3] = wb ? -(acc[3 * D + d] / n_mc) * b[d] * (1 - b[d]) : 0;
+        const REAL pa = a_prior ? FN(discrete_prior_dlogp)((REAL)a[d]) : 0, pb = a_prior ? FN(discrete_prior_dlogp)((REAL)b[d]) : 0;
+        gr[2] = learn_a ? -((acc[2 * D + d] + (tied_b ? acc[3 * D + d] : 0)) / n_mc + pa) * a[d] * (1 - a[d]) : 0;
+        gr[3] = wb ? -(acc[3 * D + d] / n_mc + pb) * b[d] * (1 - b[d]) : 0;
         REAL* par[4] = {&loc[d], &rho[d], learn_a ? &w[d] : NULL, wb ? &wb[d] : NULL};
         for (int k = 0; k < 4; ++k) {
           REAL gk = gr[k];

@@ -58,3 +58,36 @@ def test_cvip_learns_parameterisation(oracle_lib, gpu, mname):
     wg = w.cpu().numpy()
     assert np.abs(wg).max() > 0.05                      # the parameterisation moved
     np.testing.assert_allclose(wg, wo, rtol=0, atol=0.1 * (np.abs(wo).max() + 0.5))
+
+
+def test_discrete_prior_term(oracle_lib, gpu):
+    """--discrete_prior (reference main.py:244-253, inference.py:50-54): the mixture's log density on the learnable
+    parameters is added to the objective.  Same run with and without it, against the oracle; the prior term is
+    analytic, so its finite-difference derivative pins the kernel's formula."""
+    from autoreparam_amd import engine, inference
+    sp = helpers.spec("8schools")
+    eng = engine.Engine(sp, gpu)
+    orc = oracle_lib.OracleModel(sp)
+    a = np.full(sp.D, 0.5, np.float32); b = np.ones(sp.D, np.float32)
+    eng.set_param(0, (a, b))
+    rs = np.random.RandomState(2)
+    loc0 = (1e-2 * rs.randn(1, sp.D)).astype(np.float32); rho0 = np.full((1, sp.D), -2.0, np.float32)
+    out = {}
+    for prior in (False, True):
+        loc, rho, w = (torch.as_tensor(v.copy(), device=gpu) for v in (loc0, rho0, np.zeros((1, sp.D), np.float32)))
+        eng.vi_run([0.05], loc, rho, 300, 256, w=w, seed=4, a_prior=prior)
+        lo, ro, wo = loc0.copy(), rho0.copy(), np.zeros((1, sp.D), np.float32)
+        orc.vi_run(a, b, [0.05], lo, ro, wo, 300, 256, learn_a=True, seed=4, lanes=VI_LANES["8schools"], a_prior=prior)
+        # mu and log_tau have no parent, so their `a` sees no likelihood gradient: under the prior a = 1/2 is an
+        # unstable equilibrium there (any rounding tips it to an end) -- compare the theta parameters only
+        wg = w.cpu().numpy()[:, 2:]; wo = wo[:, 2:]
+        np.testing.assert_allclose(wg, wo, rtol=0, atol=0.1 * (np.abs(wo).max() + 0.5))
+        out[prior] = 1.0 / (1.0 + np.exp(-wg))
+    # the term is active (near 1/2 the mixture is almost flat -- weight e^5 on the uniform -- so the shift is small)
+    assert np.abs(out[True] - out[False]).max() > 1e-4
+    # analytic derivative used by the kernel == finite difference of DiscretePrior.log_prob
+    p = inference.DiscretePrior()
+    x = np.linspace(0.02, 0.98, 49); h = 1e-5
+    fd = (p.log_prob(x + h) - p.log_prob(x - h)) / (2 * h)
+    l0, l1 = 5 * np.exp(-10 * x), 5 * np.exp(-10 * (1 - x))
+    np.testing.assert_allclose(10 * (l1 - l0) / (l0 + np.exp(5.0) + l1), fd, rtol=1e-5, atol=1e-8)
