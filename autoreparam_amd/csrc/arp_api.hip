@@ -349,12 +349,13 @@ int arp_model_set_param(arp_model* m, int which, const float* a_host, const floa
   ARP_HIP_OK(hipMemcpy(m->dev_ab[which], a_host, m->D * sizeof(float), hipMemcpyHostToDevice));
   ARP_HIP_OK(hipMemcpy(m->dev_ab[which] + m->D, b_host, m->D * sizeof(float), hipMemcpyHostToDevice));
   m->has_param[which] = true;
-  bool all1 = true, all0 = true;
+  bool all1 = true, all0 = true, b1 = true;
   for (int d = 0; d < m->D; ++d) {
     all1 = all1 && a_host[d] == 1.0f && b_host[d] == 1.0f;
     all0 = all0 && a_host[d] == 0.0f && b_host[d] == 0.0f;
+    b1 = b1 && b_host[d] == 1.0f;
   }
-  m->param_kind[which] = all1 ? kModeCP : (all0 ? kModeNCP : kModeVIP);
+  m->param_kind[which] = all1 ? kModeCP : (all0 ? kModeNCP : (b1 ? kModeB1 : kModeVIP));
   // dropped constant: -sum_i b_i log(prior scale_i) over the top-level latents, plus the base
   double c = m->const_base;
   for (const auto& ts : m->top_scale) c -= (double)b_host[ts.first] * ts.second;
@@ -451,6 +452,7 @@ int arp_hmc_run(arp_model* m, int which, const arp_hmc_config* cfg, const arp_hm
   auto fn = o->hmc;
   if (m->param_kind[which] == kModeCP && o->hmc_cp) fn = o->hmc_cp;
   if (m->param_kind[which] == kModeNCP && o->hmc_ncp) fn = o->hmc_ncp;
+  if (m->param_kind[which] == kModeB1 && o->hmc_b1) fn = o->hmc_b1;
   fn(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, (hipStream_t)stream);
   ARP_HIP_OK(hipGetLastError());
   return 0;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 #include "../../include/autoreparam.h"
@@ -47,6 +48,8 @@ struct LaneOps {
   void (*hmc_ncp)(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s);
   void (*interleaved_cp_ncp)(const void* args, const float* a0, const float* b0, const float* a1, const float* b1,
                              const HmcParams& P, hipStream_t s);
+  // hmc for "a free, b = 1" (nullptr when the lane model has no such form)
+  void (*hmc_b1)(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s);
 };
 
 template <class Lane>
@@ -88,13 +91,16 @@ struct Launch {
   }
   // only the VI launcher (a lane sized for the VI kernel's workgroup; nothing else is instantiated)
   static LaneOps vi_only() {
-    LaneOps o{Lane::K, Lane::NGRP, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    LaneOps o{Lane::K, Lane::NGRP, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if constexpr (Lane::HAS_VI) o.vi = &vi;
     return o;
   }
+  template <class L, class = void> struct has_b1 : std::false_type {};
+  template <class L> struct has_b1<L, std::enable_if_t<L::HAS_MODE_B1>> : std::true_type {};
   static LaneOps ops() {
-    LaneOps o{Lane::K, Lane::NGRP, &logp_grad, &transform, &hmc, &interleaved, nullptr, nullptr, nullptr, nullptr};
+    LaneOps o{Lane::K, Lane::NGRP, &logp_grad, &transform, &hmc, &interleaved, nullptr, nullptr, nullptr, nullptr, nullptr};
     if constexpr (Lane::HAS_VI) o.vi = &vi;
+    if constexpr (has_b1<Lane>::value) o.hmc_b1 = &hmc_m<kModeB1>;
     if constexpr (Lane::HAS_MODES) {
       o.hmc_cp = &hmc_m<kModeCP>;
       o.hmc_ncp = &hmc_m<kModeNCP>;
@@ -124,7 +130,7 @@ struct arp_model {
   float* dev_tables = nullptr;   // one allocation holding all frozen tables
   float* dev_ab[2] = {nullptr, nullptr};  // [2][D]: a then b, per parameterisation
   bool has_param[2] = {false, false};
-  int param_kind[2] = {0, 0};   // kModeVIP / kModeCP / kModeNCP, detected in arp_model_set_param
+  int param_kind[2] = {0, 0};   // kModeVIP / kModeCP / kModeNCP / kModeB1, detected in arp_model_set_param
   double logp_const[2] = {0.0, 0.0};
   arp::RadonArgs radon{};
   arp::SchoolsArgs schools{};

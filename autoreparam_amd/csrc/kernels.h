@@ -106,9 +106,10 @@ ARP_DEV void store_row_wave(const Lane& M, float* stage, float* gdst, int cl, in
 // (a,b) held in registers; lane models that set HAS_MODES also provide
 // compile-time specialisations for the two parameterisations every run uses,
 // MODE 1 = centred (a=b=1) and MODE 2 = non-centred (a=b=0): fewer VALU ops per
-// group and no (a,b) registers.
+// group and no (a,b) registers.  MODE 3 (lane models with HAS_MODE_B1) is "a free,
+// b = 1": what the reference's tied cVIP / dVIP runs execute.
 // ---------------------------------------------------------------------------
-constexpr int kModeVIP = 0, kModeCP = 1, kModeNCP = 2;
+constexpr int kModeVIP = 0, kModeCP = 1, kModeNCP = 2, kModeB1 = 3;
 
 template <int MODE, bool LOGP, class Lane>
 ARP_DEV float lane_grad(const Lane& M, const float (&q)[Lane::ND], float (&g)[Lane::ND]) {

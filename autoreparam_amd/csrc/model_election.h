@@ -42,6 +42,7 @@ struct ElectionLane {
   static constexpr bool HAS_FUSED = true;    // kick_drift below
   static constexpr bool HAS_VI = true;
   static constexpr bool HAS_MODE_STATE = true;    // si / cs of the top-level scalars follow b (set_mode)
+  static constexpr bool HAS_MODE_B1 = true;       // MODE 3: a free, b = 1 (tied cVIP / dVIP as the reference executes them)
   static constexpr int MINW = K_ == 4 ? 2 : 1;   // waves per SIMD the register allocator must leave room for
   using Args = ElectionArgs;
 
@@ -52,11 +53,11 @@ struct ElectionLane {
   // (a, b) of slice i under the compile-time parameterisations
   // (a non-latent slice has a = b = 0 in every mode: its prior terms vanish and q stays 0)
   template <int MODE> ARP_DEV float A(int i) const { return MODE == 1 ? lat(i) : (MODE == 2 ? 0.0f : al[i]); }
-  template <int MODE> ARP_DEV float B(int i) const { return MODE == 1 ? lat(i) : (MODE == 2 ? 0.0f : be[i]); }
+  template <int MODE> ARP_DEV float B(int i) const { return (MODE == 1 || MODE == 3) ? lat(i) : (MODE == 2 ? 0.0f : be[i]); }
   // exp(-b_i ls): shared by all slices when b is uniform (always so for CP, NCP and the reference's tied cVIP/dVIP)
   template <int MODE> ARP_DEV float E(int i, float ls, float eu) const {
     if (MODE == 2) return 1.0f;
-    if (MODE == 1) return i < NL - 1 ? eu : (lat_last != 0.0f ? eu : 1.0f);
+    if (MODE == 1 || MODE == 3) return i < NL - 1 ? eu : (lat_last != 0.0f ? eu : 1.0f);
     return buni ? eu : fast_exp(-be[i] * ls);
   }
   float si[4], cs[4];   // 1/s^b and s^(1-b) for mua, lsa, b1, b2
@@ -91,8 +92,8 @@ struct ElectionLane {
     const float sc[4] = {100.0f, 10.0f, 100.0f, 100.0f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      si[i] = MODE == 1 ? 1.0f / sc[i] : 1.0f;
-      cs[i] = MODE == 1 ? 1.0f : sc[i];
+      si[i] = (MODE == 1 || MODE == 3) ? 1.0f / sc[i] : 1.0f;
+      cs[i] = (MODE == 1 || MODE == 3) ? 1.0f : sc[i];
     }
   }
   ARP_DEV void set_param(const float* av, const float* bv) {
@@ -127,7 +128,7 @@ struct ElectionLane {
     const float mua = cs[0] * q[0], ls = cs[1] * q[1], b1 = cs[2] * q[2], b2 = cs[3] * q[3];
     const float sig = fast_exp(ls);
     const float E1 = fast_exp(-b1), E2 = fast_exp(-b2), E12 = E1 * E2;
-    const float eu = MODE == 2 ? 1.0f : fast_exp(-(MODE == 1 ? 1.0f : bbar) * ls);
+    const float eu = MODE == 2 ? 1.0f : fast_exp(-((MODE == 1 || MODE == 3) ? 1.0f : bbar) * ls);
     float g_mua = 0.0f, g_ls = 0.0f, g_b1 = 0.0f, g_b2 = 0.0f;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -171,7 +172,7 @@ struct ElectionLane {
   ARP_DEV float grad_m(const float (&q)[ND], float (&g)[ND]) const {
     const float mua = cs[0] * q[0], ls = cs[1] * q[1], b1 = cs[2] * q[2], b2 = cs[3] * q[3];
     const float sig = fast_exp(ls);
-    const float eu = MODE == 2 ? 1.0f : fast_exp(-(MODE == 1 ? 1.0f : bbar) * ls);
+    const float eu = MODE == 2 ? 1.0f : fast_exp(-((MODE == 1 || MODE == 3) ? 1.0f : bbar) * ls);
     float g_mua = 0.0f, g_ls = 0.0f, g_b1 = 0.0f, g_b2 = 0.0f, lp = 0.0f;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -245,6 +246,7 @@ struct ElectionLane {
     for (int i = 0; i < NL; ++i) {
       if (MODE == 1) x[NG + i] = q[NG + i];                             // a = b = 1: identity
       else if (MODE == 2) x[NG + i] = lat(i) * fmaf(sig, q[NG + i], mua);   // a = b = 0: mua + sigma q
+      else if (MODE == 3) x[NG + i] = fmaf(lat(i) - al[i], mua, q[NG + i]);   // b = 1: q + (1 - a) mua
       else x[NG + i] = fmaf(fast_exp((1.0f - be[i]) * ls), q[NG + i] - al[i] * mua, mua);
     }
   }
@@ -257,6 +259,7 @@ struct ElectionLane {
     for (int i = 0; i < NL; ++i) {
       if (MODE == 1) q[NG + i] = lvalid(i) ? x[NG + i] : 0.0f;
       else if (MODE == 2) q[NG + i] = lvalid(i) ? (x[NG + i] - mua) * isig : 0.0f;
+      else if (MODE == 3) q[NG + i] = lvalid(i) ? fmaf(al[i] - 1.0f, mua, x[NG + i]) : 0.0f;
       else q[NG + i] = lvalid(i) ? fmaf(x[NG + i] - mua, fast_exp(-(1.0f - be[i]) * ls), al[i] * mua) : 0.0f;
     }
   }

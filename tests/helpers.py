@@ -24,10 +24,12 @@ def spec(name):
 
 
 def params(sp, kind, seed=0):
-    """(a, b) float32 [D] for 'CP', 'NCP' or a seeded 'VIP'."""
+    """(a, b) float32 [D] for 'CP', 'NCP', a seeded 'VIP' (a and b free) or 'B1' (a free, b = 1)."""
     if kind in ("CP", "NCP"):
         return sp.ab_from_reparam(kind)
     rs = np.random.RandomState(1000 + seed)
+    if kind == "B1":   # a free, b = 1: what the reference's tied cVIP / dVIP runs execute (SURVEY.md 8a-4)
+        return rs.rand(sp.D).astype(np.float32), np.ones(sp.D, np.float32)
     return rs.rand(sp.D).astype(np.float32), rs.rand(sp.D).astype(np.float32)
 
 

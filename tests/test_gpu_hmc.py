@@ -81,6 +81,19 @@ def test_trajectories_match_oracle_fixed_step(oracle_lib, gpu, mname, kind):
         assert np.array_equal(st.rng.cpu().numpy().view(np.uint32)[:, :lanes], so["rng"][:, :lanes])
 
 
+@pytest.mark.parametrize("mname", ["election", "radon_PA", "german"])
+def test_trajectories_match_oracle_b_equal_one(oracle_lib, gpu, mname):
+    """a free, b = 1 (the parameterisation tied cVIP / dVIP runs execute): election has a compile-time form
+    for it, the other models take the general path; both against the oracle."""
+    for lanes in LANES[mname]:
+        err, terr, st, so, ta, tao = _compare(oracle_lib, gpu, mname, "B1", lanes, 0, 0.05, 4, 12)
+        ok = err <= 1e-4
+        assert ok.mean() >= 0.95, (lanes, ok.mean(), np.sort(err)[-5:])
+        assert (terr[ok] <= 1e-4).mean() >= 0.98 and (terr[ok] <= 1e-2).all()
+        assert np.array_equal(st.accept_count.cpu().numpy()[ok], so["accept_count"][ok])
+        assert np.array_equal(st.rng.cpu().numpy().view(np.uint32)[:, :lanes], so["rng"][:, :lanes])
+
+
 @pytest.mark.parametrize("mname,kind", [("8schools", "NCP"), ("radon_MN", "NCP"), ("election", "CP")])
 @pytest.mark.parametrize("adapt", [1, 2])
 def test_adaptation_matches_oracle(oracle_lib, gpu, mname, kind, adapt):
