@@ -35,18 +35,20 @@ class HmcConfig(C.Structure):
                 ("adapt_kind", C.c_int32), ("n_adapt", C.c_int32),
                 ("adapt_target", C.c_float), ("adapt_rate", C.c_float),
                 ("n_burnin", C.c_int32), ("thin", C.c_int32), ("n_samples", C.c_int32),
-                ("trace_centered", C.c_int32), ("lanes_per_chain", C.c_int32), ("reserved", C.c_int32)]
+                ("trace_centered", C.c_int32), ("lanes_per_chain", C.c_int32), ("stats_batch", C.c_int32),
+                ("trace_chains", C.c_int32), ("reserved", C.c_int32)]
 
 
 class HmcIO(C.Structure):
     _fields_ = [("q", C.c_void_p), ("grad", C.c_void_p), ("logp", C.c_void_p), ("adapt", C.c_void_p),
                 ("rng", C.c_void_p), ("accept_count", C.c_void_p), ("eps0", C.c_void_p),
-                ("trace", C.c_void_p), ("trace_accept", C.c_void_p), ("moments", C.c_void_p)]
+                ("trace", C.c_void_p), ("trace_accept", C.c_void_p), ("stats", C.c_void_p),
+                ("rec_accept_count", C.c_void_p)]
 
 
 class InterleavedIO(C.Structure):
     _fields_ = [("k0", HmcIO), ("adapt1", C.c_void_p), ("accept_count1", C.c_void_p),
-                ("eps0_1", C.c_void_p), ("trace_accept1", C.c_void_p)]
+                ("eps0_1", C.c_void_p), ("trace_accept1", C.c_void_p), ("rec_accept_count1", C.c_void_p)]
 
 
 class ViConfig(C.Structure):

@@ -419,7 +419,8 @@ static int fill_params(arp_model* m, const arp_hmc_config* cfg, const arp_hmc_io
   P.adapt_log_target = logf(cfg->adapt_target > 0.f ? cfg->adapt_target : 1e-30f);
   P.adapt_inv_opr = 1.0f / (1.0f + cfg->adapt_rate);
   P.n_burnin = cfg->n_burnin; P.thin = cfg->thin;
-  P.n_samples = (io->trace || io->trace_accept) ? cfg->n_samples : 0;
+  P.n_samples = (io->trace || io->trace_accept || io->stats || io->rec_accept_count) ? cfg->n_samples : 0;
+  if (io->stats && cfg->stats_batch < 1) { set_error("stats_batch must be >= 1 when stats is given"); return 1; }
   P.trace_centered = cfg->trace_centered;
   {
     // result r is taken after transition n = 1 + burnin + r*thin (1-based, global);
@@ -433,12 +434,16 @@ static int fill_params(arp_model* m, const arp_hmc_config* cfg, const arp_hmc_io
     long long s0 = first_n - cfg->step_base - 1;
     P.rec_step = s0 < cfg->n_steps ? (int)s0 : -1;
     P.rec_row = (int)(r0 < 0x7fffffff ? r0 : 0x7fffffff);
+    P.stats_batch = cfg->stats_batch > 0 ? cfg->stats_batch : 1;
+    P.stats_bpos = (int)(r0 % P.stats_batch);
   }
   P.D = m->D;
   P.q = io->q; P.grad = io->grad; P.logp = io->logp; P.adapt = io->adapt;
   P.rng = io->rng; P.accept_count = io->accept_count; P.eps0 = io->eps0;
-  P.trace = io->trace; P.trace_accept = io->trace_accept; P.moments = io->moments;
+  P.trace = io->trace; P.trace_accept = io->trace_accept; P.stats = io->stats; P.rec_accept = io->rec_accept_count;
+  P.trace_chains = (cfg->trace_chains > 0 && cfg->trace_chains < cfg->n_chains) ? cfg->trace_chains : cfg->n_chains;
   P.L1 = 0; P.adapt1 = nullptr; P.accept_count1 = nullptr; P.eps0_1 = nullptr; P.trace_accept1 = nullptr;
+  P.rec_accept1 = nullptr;
   return 0;
 }
 
@@ -469,7 +474,7 @@ int arp_interleaved_run(arp_model* m, const arp_hmc_config* cfg, int n_leapfrog_
   if (fill_params(m, cfg, &io->k0, false, &P)) return 1;
   if (io->trace_accept1 && !P.n_samples) P.n_samples = cfg->n_samples;
   P.L1 = n_leapfrog_1; P.adapt1 = io->adapt1; P.accept_count1 = io->accept_count1;
-  P.eps0_1 = io->eps0_1; P.trace_accept1 = io->trace_accept1;
+  P.eps0_1 = io->eps0_1; P.trace_accept1 = io->trace_accept1; P.rec_accept1 = io->rec_accept_count1;
   if (cfg->n_steps == 0) return 0;
   const LaneOps* o = select_ops(m, cfg->lanes_per_chain, cfg->n_chains);
   if (!o) return 1;

@@ -26,10 +26,14 @@ struct HmcParams {
   float* q; float* grad; float* logp; float* adapt;
   uint32_t* rng; uint32_t* accept_count;
   const float* eps0;
-  float* trace; uint8_t* trace_accept; float* moments;
+  float* trace; uint8_t* trace_accept;
+  int trace_chains;                 // chains a trace row holds (== C unless only the first few are recorded)
+  float* stats;                     // [6][C][D] streaming statistics of the recorded samples, or nullptr
+  int stats_batch, stats_bpos;      // batch length; recorded samples already in the current batch at launch
+  uint32_t* rec_accept;             // [C] accepted among the recorded transitions, or nullptr
   // interleaved kernel only: second transition kernel (parameterisation 1)
   int L1;
-  float* adapt1; uint32_t* accept_count1; const float* eps0_1; uint8_t* trace_accept1;
+  float* adapt1; uint32_t* accept_count1; const float* eps0_1; uint8_t* trace_accept1; uint32_t* rec_accept1;
 };
 
 
@@ -98,6 +102,66 @@ ARP_DEV void store_row_wave(const Lane& M, float* stage, float* gdst, int cl, in
   } else {
     for (int k = lane; k < nvalid; k += 64) gdst[k] = stage[k];
   }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Streaming statistics of a recorded sample (arp_hmc_io.stats, [6][C][D]): the wave stages its chains'
+// rows in LDS as store_row_wave does (stage_row_wave) and then walks the six component planes, whose
+// blocks for the wave's chains have the same [chains][D] shape, with 16-byte accesses.  x - ref keeps
+// the sums well conditioned in float32 (ref = the first recorded sample of that element).
+// The walk is a real function call: inlined, its temporaries push the chain kernels (which sit at
+// the 256-VGPR edge) into spilling inside the sampling loop even when no statistics are requested.
+__device__ __noinline__ void stats_update_staged(const float* stage, float* g, size_t comp, int nvalid, bool first,
+                                                 bool batch_end, float invb) {
+  const int lane = threadIdx.x & 63;
+  auto upd = [&](float x, float& ref, float& s1, float& s2, float& cur, float& sb1, float& sb2) {
+    ref = first ? x : ref;
+    const float dx = x - ref;
+    s1 += dx; s2 = fmaf(dx, dx, s2); cur += dx;
+    if (batch_end) { const float bm = cur * invb; sb1 += bm; sb2 = fmaf(bm, bm, sb2); cur = 0.0f; }
+  };
+  const bool aligned = ((reinterpret_cast<uintptr_t>(g) | (comp * sizeof(float))) & 15) == 0;
+  for (int k = lane * 4; k < nvalid; k += 256) {
+    if (aligned && k + 3 < nvalid) {
+      const float4 x = *reinterpret_cast<const float4*>(stage + k);
+      float4 ref = *reinterpret_cast<float4*>(g + k), s1 = *reinterpret_cast<float4*>(g + comp + k);
+      float4 s2 = *reinterpret_cast<float4*>(g + 2 * comp + k), cur = *reinterpret_cast<float4*>(g + 3 * comp + k);
+      float4 sb1 = make_float4(0, 0, 0, 0), sb2 = sb1;
+      if (batch_end) { sb1 = *reinterpret_cast<float4*>(g + 4 * comp + k); sb2 = *reinterpret_cast<float4*>(g + 5 * comp + k); }
+      upd(x.x, ref.x, s1.x, s2.x, cur.x, sb1.x, sb2.x);
+      upd(x.y, ref.y, s1.y, s2.y, cur.y, sb1.y, sb2.y);
+      upd(x.z, ref.z, s1.z, s2.z, cur.z, sb1.z, sb2.z);
+      upd(x.w, ref.w, s1.w, s2.w, cur.w, sb1.w, sb2.w);
+      if (first) *reinterpret_cast<float4*>(g + k) = ref;
+      *reinterpret_cast<float4*>(g + comp + k) = s1; *reinterpret_cast<float4*>(g + 2 * comp + k) = s2;
+      *reinterpret_cast<float4*>(g + 3 * comp + k) = cur;
+      if (batch_end) { *reinterpret_cast<float4*>(g + 4 * comp + k) = sb1; *reinterpret_cast<float4*>(g + 5 * comp + k) = sb2; }
+    } else {   // unaligned planes or the ragged tail of the wave's block: element by element, nothing past it is touched
+      for (int j = k; j < nvalid && j < k + 4; ++j) {
+        float ref = g[j], s1 = g[comp + j], s2 = g[2 * comp + j], cur = g[3 * comp + j];
+        float sb1 = batch_end ? g[4 * comp + j] : 0.0f, sb2 = batch_end ? g[5 * comp + j] : 0.0f;
+        upd(stage[j], ref, s1, s2, cur, sb1, sb2);
+        if (first) g[j] = ref;
+        g[comp + j] = s1; g[2 * comp + j] = s2; g[3 * comp + j] = cur;
+        if (batch_end) { g[4 * comp + j] = sb1; g[5 * comp + j] = sb2; }
+      }
+    }
+  }
+}
+
+template <class Lane>
+ARP_DEV void stats_update_wave(const Lane& M, float* stage, const HmcParams& P, long long cw0, int cl, int D,
+                               int nvalid, const float (&v)[Lane::ND], bool first, bool batch_end) {
+  float* row = stage + cl * D;
+  if (M.slot == 0) {
+#pragma unroll
+    for (int i = 0; i < Lane::NG; ++i) row[M.gg(i)] = v[i];
+  }
+#pragma unroll
+  for (int i = 0; i < Lane::NL; ++i)
+    if (M.lvalid(i)) (row + M.lbase(i))[Lane::loff(i)] = v[Lane::NG + i];
+  __builtin_amdgcn_wave_barrier();
+  stats_update_staged(stage, P.stats + cw0 * D, (size_t)P.C * D, nvalid, first, batch_end, 1.0f / (float)P.stats_batch);
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -352,7 +416,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
   }
   uint32_t nacc = (P.step_base == 0) ? 0u : P.accept_count[c];
 
-  int next_rec = P.rec_step, rec_row = P.rec_row;
+  int next_rec = P.rec_step, rec_row = P.rec_row, bpos = P.stats_bpos;
   // everything loaded so far has landed: no load result is awaited inside the loop, so the
   // in-order vmcnt never makes a wave wait for its own trace stores
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -368,17 +432,30 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
 
     // sample_chain schedule: result r is the state after transition 1 + burnin + r*thin
     if (s == next_rec && rec_row < P.n_samples) {
-      if (P.trace) {
-        float* wrow = P.trace + ((size_t)rec_row * P.C + cw0) * D;
+      const bool to_trace = P.trace && cw0 < P.trace_chains;
+      auto record = [&](const float (&v)[ND]) {
+        if (to_trace) {
+          const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
+          store_row_wave(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, v);
+        }
+        if (P.stats) {
+          stats_update_wave(M, stage, P, cw0, cl, D, nvalid, v, rec_row == 0, bpos + 1 == P.stats_batch);
+          bpos = bpos + 1 == P.stats_batch ? 0 : bpos + 1;
+        }
+      };
+      if (to_trace || P.stats) {
         if (P.trace_centered) {
           float x[ND];
           lane_to_centered<MODE>(M, q, x);
-          store_row_wave(M, stage, wrow, cl, D, nvalid, x);
+          record(x);
         } else {
-          store_row_wave(M, stage, wrow, cl, D, nvalid, q);
+          record(q);
         }
       }
-      if (P.trace_accept && live && slot == 0) P.trace_accept[(size_t)rec_row * P.C + c] = acc ? 1 : 0;
+      if (live && slot == 0) {
+        if (P.trace_accept) P.trace_accept[(size_t)rec_row * P.C + c] = acc ? 1 : 0;
+        if (P.rec_accept) P.rec_accept[c] += acc ? 1u : 0u;
+      }
       next_rec += P.thin;
       rec_row += 1;
     }
@@ -472,7 +549,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
       lp = P.logp[c];
     }
   }
-  int next_rec = P.rec_step, rec_row = P.rec_row;
+  int next_rec = P.rec_step, rec_row = P.rec_row, bpos = P.stats_bpos;
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see hmc_kernel
   for (int s = 0; s < P.n_steps; ++s) {
     const long long n = P.step_base + s + 1;
@@ -509,16 +586,26 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
     }
 
     if (s == next_rec && rec_row < P.n_samples) {
-      if (P.trace) {
-        float* wrow = P.trace + ((size_t)rec_row * P.C + cw0) * D;
-        // x holds the centred state (CARRY: CP coordinates are the centred ones); q the
-        // parameterisation-0 state the reference records
-        if (P.trace_centered && !CARRY) store_row_wave(M, stage, wrow, cl, D, nvalid, x);
-        else store_row_wave(M, stage, wrow, cl, D, nvalid, q);
+      // x holds the centred state (CARRY: CP coordinates are the centred ones); q the
+      // parameterisation-0 state the reference records
+      const bool use_x = P.trace_centered && !CARRY;
+      if (P.trace && cw0 < P.trace_chains) {
+        const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
+        float* wrow = P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D;
+        if (use_x) store_row_wave(M, stage, wrow, cl, D, nv, x);
+        else store_row_wave(M, stage, wrow, cl, D, nv, q);
+      }
+      if (P.stats) {
+        const bool bend = bpos + 1 == P.stats_batch;
+        if (use_x) stats_update_wave(M, stage, P, cw0, cl, D, nvalid, x, rec_row == 0, bend);
+        else stats_update_wave(M, stage, P, cw0, cl, D, nvalid, q, rec_row == 0, bend);
+        bpos = bend ? 0 : bpos + 1;
       }
       if (live && slot == 0) {
         if (P.trace_accept) P.trace_accept[(size_t)rec_row * P.C + c] = acc0 ? 1 : 0;
         if (P.trace_accept1) P.trace_accept1[(size_t)rec_row * P.C + c] = acc1 ? 1 : 0;
+        if (P.rec_accept) P.rec_accept[c] += acc0 ? 1u : 0u;
+        if (P.rec_accept1) P.rec_accept1[c] += acc1 ? 1u : 0u;
       }
       next_rec += P.thin;
       rec_row += 1;

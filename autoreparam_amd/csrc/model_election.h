@@ -102,8 +102,12 @@ struct ElectionLane {
     const float sc[4] = {100.0f, 10.0f, 100.0f, 100.0f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      si[i] = __builtin_amdgcn_exp2f(-bv[gmap[i]] * lg[i]);
-      cs[i] = sc[i] * si[i];
+      // b = 1 and b = 0 get the exact constants set_mode<> uses, so the general kernel, the compile-time forms
+      // and a run cut into several launches all see the same numbers
+      const float bb = bv[gmap[i]];
+      const float e = __builtin_amdgcn_exp2f(-bb * lg[i]);
+      si[i] = bb == 1.0f ? 1.0f / sc[i] : (bb == 0.0f ? 1.0f : e);
+      cs[i] = bb == 1.0f ? 1.0f : (bb == 0.0f ? sc[i] : sc[i] * e);
     }
     bbar = bv[LBASE + slot];     // slice 0 is a latent in every lane
     float lo = bbar, hi = bbar;

@@ -418,7 +418,6 @@ struct GermanLane {
   ARP_DEV float likelihood_mfma(const float (&beta)[NLS], float (&v)[NLS]) const {
     static_assert(NLS == 16, "K = 4 owns 16 features per lane");
     float* tile = tile_mem();
-    const float* ytile = tile + kRows * kStride;
     const int lane = threadIdx.x & 63;
     float* xch = tile + kRows * kStride + kRows + (threadIdx.x >> 6) * kXch;
     float* lpx = xch + 16 * kStride;

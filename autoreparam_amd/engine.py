@@ -102,8 +102,15 @@ class Engine(object):
     # -- HMC ----------------------------------------------------------------
     def hmc_run(self, state, eps0, n_leapfrog, n_steps, which=0, seed=0, chain_offset=0,
                 adapt_kind=_lib.ADAPT_NONE, n_adapt=0, adapt_target=0.75, adapt_rate=0.05,
-                n_burnin=0, thin=1, trace=None, trace_accept=None, trace_centered=True, lanes=0):
-        """Advance `state` by n_steps transitions (one kernel launch)."""
+                n_burnin=0, thin=1, trace=None, trace_accept=None, trace_centered=True, lanes=0,
+                stats=None, stats_batch=1, n_samples=None, trace_chains=0, rec_accept=None):
+        """Advance `state` by n_steps transitions (one kernel launch).
+
+        `stats` ([6, C, D] float32, zeroed before the first call) accumulates the streaming statistics of the
+        recorded samples inside the kernel (`stats_summary`), `rec_accept` ([C] int32) the accepted recorded
+        transitions; with them a run needs no trace, or only one of the first `trace_chains` chains
+        (`trace` is then [S, trace_chains, D]).  `n_samples` = recorded samples of the whole run when no
+        trace buffer gives it."""
         cfg = _lib.HmcConfig()
         cfg.n_chains = state.q.shape[0]
         cfg.n_leapfrog = int(n_leapfrog)
@@ -117,16 +124,19 @@ class Engine(object):
         cfg.adapt_rate = float(adapt_rate)
         cfg.n_burnin = int(n_burnin)
         cfg.thin = int(thin)
-        cfg.n_samples = int(trace.shape[0]) if trace is not None else (
-            int(trace_accept.shape[0]) if trace_accept is not None else 0)
+        cfg.n_samples = int(n_samples) if n_samples is not None else (int(trace.shape[0]) if trace is not None else (
+            int(trace_accept.shape[0]) if trace_accept is not None else 0))
         cfg.trace_centered = 1 if trace_centered else 0
         cfg.lanes_per_chain = int(lanes)
+        cfg.stats_batch = int(stats_batch)
+        cfg.trace_chains = int(trace_chains)
         io = _lib.HmcIO()
         io.q, io.grad, io.logp = _ptr(state.q), _ptr(state.grad), _ptr(state.logp)
         io.adapt, io.rng, io.accept_count = _ptr(state.adapt), _ptr(state.rng), _ptr(state.accept_count)
         self._eps0 = self._dev(eps0)
         io.eps0 = _ptr(self._eps0)
-        io.trace, io.trace_accept, io.moments = _ptr(trace), _ptr(trace_accept), C.c_void_p(0)
+        io.trace, io.trace_accept, io.stats = _ptr(trace), _ptr(trace_accept), _ptr(stats)
+        io.rec_accept_count = _ptr(rec_accept)
         with torch.cuda.device(self.device):
             _lib.check(self._L.arp_hmc_run(self._h, which, C.byref(cfg), C.byref(io), _stream()))
         state.step += int(n_steps)
@@ -136,8 +146,10 @@ class Engine(object):
     def interleaved_run(self, state, eps0_0, eps0_1, n_leapfrog_0, n_leapfrog_1, n_steps, seed=0,
                         chain_offset=0, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=0, adapt_target=0.75,
                         adapt_rate=0.05, n_burnin=0, thin=1, trace=None, trace_accept0=None,
-                        trace_accept1=None, trace_centered=True, lanes=0):
-        """Advance `state` by n_steps interleaved steps (parameterisation 0 then 1 per step)."""
+                        trace_accept1=None, trace_centered=True, lanes=0, stats=None, stats_batch=1, n_samples=None,
+                        trace_chains=0, rec_accept0=None, rec_accept1=None):
+        """Advance `state` by n_steps interleaved steps (parameterisation 0 then 1 per step);
+        stats / rec_accept* / trace_chains / n_samples as in hmc_run."""
         cfg = _lib.HmcConfig()
         cfg.n_chains = state.q.shape[0]
         cfg.n_leapfrog = int(n_leapfrog_0)
@@ -151,10 +163,12 @@ class Engine(object):
         cfg.adapt_rate = float(adapt_rate)
         cfg.n_burnin = int(n_burnin)
         cfg.thin = int(thin)
-        cfg.n_samples = int(trace.shape[0]) if trace is not None else (
-            int(trace_accept0.shape[0]) if trace_accept0 is not None else 0)
+        cfg.n_samples = int(n_samples) if n_samples is not None else (int(trace.shape[0]) if trace is not None else (
+            int(trace_accept0.shape[0]) if trace_accept0 is not None else 0))
         cfg.trace_centered = 1 if trace_centered else 0
         cfg.lanes_per_chain = int(lanes)
+        cfg.stats_batch = int(stats_batch)
+        cfg.trace_chains = int(trace_chains)
         io = _lib.InterleavedIO()
         io.k0.q = _ptr(state.q)
         io.k0.grad, io.k0.logp = _ptr(state.grad), _ptr(state.logp)   # carried gradient / log density
@@ -163,6 +177,7 @@ class Engine(object):
         self._eps1 = self._dev(eps0_1)
         io.k0.eps0 = _ptr(self._eps0)
         io.k0.trace, io.k0.trace_accept = _ptr(trace), _ptr(trace_accept0)
+        io.k0.stats, io.k0.rec_accept_count, io.rec_accept_count1 = _ptr(stats), _ptr(rec_accept0), _ptr(rec_accept1)
         io.adapt1, io.accept_count1 = _ptr(state.adapt1), _ptr(state.accept_count1)
         io.eps0_1 = _ptr(self._eps1)
         io.trace_accept1 = _ptr(trace_accept1)
@@ -194,6 +209,20 @@ class Engine(object):
         with torch.cuda.device(self.device):
             _lib.check(self._L.arp_vi_run(self._h, which, C.byref(cfg), C.byref(io), _stream()))
         return elbo
+
+
+def stats_summary(stats, n, batch):
+    """(mean, var, ess) [C, D] float64 tensors from an `arp_hmc_io.stats` buffer after `n` recorded samples:
+    mean = ref + s1/n, var = (s2 - s1^2/n)/(n-1), ESS by batch means, n var / (batch var(batch means)), capped at n."""
+    ref, s1, s2, _, sb1, sb2 = (stats[k].to(torch.float64) for k in range(6))
+    mean = ref + s1 / n
+    var = ((s2 - s1 * s1 / n) / max(n - 1, 1)).clamp_min(0)
+    nb = n // batch
+    if nb < 2:
+        raise ValueError("batch-means ESS needs at least two complete batches")
+    vb = ((sb2 - sb1 * sb1 / nb) / (nb - 1)).clamp_min(0)
+    ess = torch.minimum(n * var / (batch * vb), torch.full_like(var, float(n)))
+    return mean, var, ess
 
 
 # ---------------------------------------------------------------------------

@@ -89,6 +89,9 @@ typedef struct arp_hmc_config {
   int32_t n_samples;         /* S: capacity of the trace buffers (rows) */
   int32_t trace_centered;    /* 1: trace rows are mapped to centred coordinates (inference.py:238-239) */
   int32_t lanes_per_chain;   /* 0 = library default; otherwise 1,2,4,8,16 (also partitions the RNG streams) */
+  int32_t stats_batch;       /* io.stats: samples per batch of the batch-means accumulators (>= 1) */
+  int32_t trace_chains;      /* 0 or >= n_chains: trace rows hold every chain; otherwise only chains [0, trace_chains)
+                              * are recorded and a trace row is [trace_chains][D] (a few chains kept next to io.stats) */
   int32_t reserved;
 } arp_hmc_config;
 
@@ -103,7 +106,13 @@ typedef struct arp_hmc_io {
   const float* eps0;         /* [D] base step size per element (VI posterior std / (L/4)^2, inference.py:212-216) */
   float* trace;              /* [S][C][D] or NULL */
   uint8_t* trace_accept;     /* [S][C] is_accepted of recorded transitions, or NULL */
-  float* moments;            /* reserved, must be NULL (streaming moments are accumulated by the host from trace chunks) */
+  float* stats;              /* [6][C][D] in/out or NULL: streaming statistics of the recorded samples (same schedule and
+                              * coordinates as the trace rows), accumulated in the kernel so that a run needs no trace:
+                              * {ref = first recorded sample, s1 = sum (x - ref), s2 = sum (x - ref)^2, cur = running sum of
+                              * the current batch, sb1 = sum of batch means (of x - ref), sb2 = sum of their squares}; zero it
+                              * before the first call.  mean = ref + s1/n, var = (s2 - s1^2/n)/(n-1), batch-means ESS =
+                              * n var / (stats_batch var(batch means)) */
+  uint32_t* rec_accept_count; /* [C] in/out or NULL: accepted transitions among the recorded ones (sum of is_accepted) */
 } arp_hmc_io;
 
 int arp_version(void);
@@ -147,6 +156,7 @@ typedef struct arp_interleaved_io {
   uint32_t* accept_count1;   /* [C] */
   const float* eps0_1;       /* [D] */
   uint8_t* trace_accept1;    /* [S][C] or NULL */
+  uint32_t* rec_accept_count1; /* [C] in/out or NULL, as k0.rec_accept_count for kernel 1 */
 } arp_interleaved_io;
 int arp_interleaved_run(arp_model* m, const arp_hmc_config* cfg, int n_leapfrog_1,
                         const arp_interleaved_io* io, void* stream);

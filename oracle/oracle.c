@@ -54,6 +54,12 @@ typedef struct orc_hmc_cfg {
   float adapt_target, adapt_rate;
   int n_burnin, thin, n_samples, trace_centered;
   int lanes;
+  /* streaming statistics of the recorded samples (arp_hmc_io.stats: [6][C][D] in the run's REAL type, zeroed by the
+   * caller), samples per batch, chains a trace row holds (0 = all), accepted-among-recorded counters */
+  int stats_batch, trace_chains;
+  void* stats;
+  uint32_t* rec_accept;
+  uint32_t* rec_accept1;
 } orc_hmc_cfg;
 
 /* ---- RNG: MWC64X streams seeded by Philox4x32-10 (DESIGN.md "Randomness").  The stream record

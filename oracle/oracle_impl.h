@@ -644,6 +644,25 @@ void FN(orc_adapt_update)(int kind, long long n, int n_adapt, REAL target, REAL 
 /* A run of n_steps transitions for C chains, same contract as arp_hmc_run
  * (include/autoreparam.h) with host buffers; `rng` holds [C][16] stream states
  * and is seeded here when step_base == 0. */
+/* arp_hmc_io.stats: one recorded sample x[D] of chain c, sample index r (0-based over the whole run) */
+static void FN(stats_update)(const orc_hmc_cfg* cfg, int C, int D, int c, long long r, const REAL* x) {
+  REAL* S = (REAL*)cfg->stats;
+  const size_t comp = (size_t)C * D, o = (size_t)c * D;
+  const int batch = cfg->stats_batch > 0 ? cfg->stats_batch : 1;
+  const int batch_end = (r + 1) % batch == 0;
+  for (int d = 0; d < D; ++d) {
+    if (r == 0) S[o + d] = x[d];
+    const REAL dx = x[d] - S[o + d];
+    S[comp + o + d] += dx;
+    S[2 * comp + o + d] += dx * dx;
+    S[3 * comp + o + d] += dx;
+    if (batch_end) {
+      const REAL bm = S[3 * comp + o + d] / (REAL)batch;
+      S[4 * comp + o + d] += bm; S[5 * comp + o + d] += bm * bm; S[3 * comp + o + d] = 0;
+    }
+  }
+}
+
 int FN(orc_hmc_run)(const orc_model* M, const float* a, const float* b, const orc_hmc_cfg* cfg,
                     REAL* q, REAL* grad, REAL* logp, REAL* adapt, uint32_t* rng, uint32_t* accept_count,
                     const float* eps0, REAL* trace, uint8_t* trace_accept) {
@@ -682,12 +701,13 @@ int FN(orc_hmc_run)(const orc_model* M, const float* a, const float* b, const or
         const long long k = n - 1 - cfg->n_burnin;
         if (k >= 0 && k % cfg->thin == 0 && k / cfg->thin < cfg->n_samples) {
           const long long r = k / cfg->thin;
-          if (trace) {
-            REAL* row = trace + ((size_t)r * C + c) * D;
-            if (cfg->trace_centered) { FN(to_centered)(M, a, b, qc, xc); memcpy(row, xc, sizeof(REAL) * D); }
-            else memcpy(row, qc, sizeof(REAL) * D);
-          }
+          const int tc = (cfg->trace_chains > 0 && cfg->trace_chains < C) ? cfg->trace_chains : C;
+          const REAL* x = qc;
+          if (cfg->trace_centered && (trace || cfg->stats)) { FN(to_centered)(M, a, b, qc, xc); x = xc; }
+          if (trace && c < tc) memcpy(trace + ((size_t)r * tc + c) * D, x, sizeof(REAL) * D);
+          if (cfg->stats) FN(stats_update)(cfg, C, D, c, r, x);
           if (trace_accept) trace_accept[(size_t)r * C + c] = (uint8_t)acc;
+          if (cfg->rec_accept) cfg->rec_accept[c] += (uint32_t)acc;
         }
       }
       logp[c] = lp;
@@ -750,9 +770,14 @@ int FN(orc_interleaved_run)(const orc_model* M, const float* a0, const float* b0
         const long long k = n - 1 - cfg->n_burnin;
         if (k >= 0 && k % cfg->thin == 0 && k / cfg->thin < cfg->n_samples) {
           const long long r = k / cfg->thin;
-          if (trace) memcpy(trace + ((size_t)r * C + c) * D, cfg->trace_centered ? xc : qc, sizeof(REAL) * D);
+          const int tc = (cfg->trace_chains > 0 && cfg->trace_chains < C) ? cfg->trace_chains : C;
+          const REAL* x = cfg->trace_centered ? xc : qc;
+          if (trace && c < tc) memcpy(trace + ((size_t)r * tc + c) * D, x, sizeof(REAL) * D);
+          if (cfg->stats) FN(stats_update)(cfg, C, D, c, r, x);
           if (trace_acc0) trace_acc0[(size_t)r * C + c] = (uint8_t)a_0;
           if (trace_acc1) trace_acc1[(size_t)r * C + c] = (uint8_t)a_1;
+          if (cfg->rec_accept) cfg->rec_accept[c] += (uint32_t)a_0;
+          if (cfg->rec_accept1) cfg->rec_accept1[c] += (uint32_t)a_1;
         }
       }
       adapt0[c * 4] = k0; adapt0[c * 4 + 1] = e0; adapt0[c * 4 + 2] = l0;

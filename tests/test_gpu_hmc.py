@@ -346,3 +346,83 @@ def test_posterior_moments_against_long_cpu_run(gpu, mname, kind, L, Cn):
     big = (np.abs(mean_g) > 5 * sd_g) & (4 * err < 0.01 * np.abs(mean_g))
     if big.any():
         assert (np.abs(mean[big] / mean_g[big] - 1) < 0.01).all()
+
+
+@pytest.mark.parametrize("mname,lanes", [("radon_PA", 4), ("radon_PA", 8), ("election", 4), ("german", 4), ("8schools", 2)])
+def test_in_kernel_statistics_match_trace_and_oracle(oracle_lib, gpu, mname, lanes):
+    """arp_hmc_io.stats / rec_accept_count / trace_chains: the statistics the kernel accumulates while sampling
+    equal (i) the oracle's, (ii) the moments and batch-means ESS of the full trace of the same run, over a
+    chunked run with a ragged chain count; the partial trace equals the first chains of the full one."""
+    from autoreparam_amd import engine, inference
+    sp = helpers.spec(mname)
+    eng = _eng(mname, gpu)
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "NCP")
+    eng.set_param(0, (a, b))
+    Cn, S, batch, keep, burn, thin = 75, 24, 4, 5, 3, 2
+    q0 = helpers.states(sp, Cn, seed=4, scale=0.1)
+    eps0 = _eps0(oracle_lib, sp, a, b, q0, 0.05)
+    total = 1 + burn + thin * (S - 1)
+    kw = dict(seed=8, n_burnin=burn, thin=thin, trace_centered=True, lanes=lanes)
+    # full trace run
+    st_a = engine.ChainState(torch.as_tensor(q0, device=gpu))
+    tr_a = torch.zeros(S, Cn, sp.D, device=gpu); ta_a = torch.zeros(S, Cn, dtype=torch.uint8, device=gpu)
+    eng.hmc_run(st_a, eps0, 3, total, trace=tr_a, trace_accept=ta_a, **kw)
+    # statistics run, chunked into uneven launches, partial trace of the first `keep` chains
+    st_b = engine.ChainState(torch.as_tensor(q0, device=gpu))
+    stats = torch.zeros(6, Cn, sp.D, device=gpu); racc = torch.zeros(Cn, dtype=torch.int32, device=gpu)
+    tr_b = torch.zeros(S, keep, sp.D, device=gpu)
+    for n in (5, 1, 17, total - 23):
+        eng.hmc_run(st_b, eps0, 3, n, stats=stats, stats_batch=batch, n_samples=S, trace=tr_b, trace_chains=keep,
+                    rec_accept=racc, **kw)
+    assert torch.equal(st_a.q, st_b.q) and torch.equal(st_a.rng, st_b.rng)
+    assert torch.equal(tr_b, tr_a[:, :keep])
+    assert torch.equal(racc.long(), ta_a.long().sum(dim=0))
+    mean, var, ess = engine.stats_summary(stats, S, batch)
+    x = tr_a.double()
+    scale = x.abs().amax(dim=0) + 1
+    assert ((mean - x.mean(dim=0)).abs() / scale).max() < 2e-6
+    assert ((var - x.var(dim=0, unbiased=True)).abs() / (scale * scale)).max() < 2e-6
+    ss = inference.StreamingStats(Cn, sp.D, batch, gpu); ss.update(tr_a)
+    ok = torch.isfinite(ss.ess()) & (ss.ess() < S)
+    assert torch.allclose(ess.float()[ok], ss.ess()[ok], rtol=2e-3)
+    # oracle, float32, same schedule
+    so = oracle_lib.new_state(q0, np.float32)
+    stats_o = np.zeros((6, Cn, sp.D), np.float32); racc_o = np.zeros(Cn, np.uint32)
+    orc.hmc_run(so, a, b, eps0, 3, total, stats=stats_o, stats_batch=batch, n_samples=S, rec_accept=racc_o, **kw)
+    same = np.abs(st_b.q.cpu().numpy() - so["q"]).max(axis=1) <= 1e-4 * (np.abs(so["q"]).max() + 1)
+    assert same.mean() >= 0.9
+    sg = stats.cpu().numpy()
+    tol = 1e-4 * (np.abs(stats_o).max(axis=(1, 2), keepdims=True) + 1)
+    assert (np.abs(sg - stats_o)[:, same] <= tol).all()
+    assert np.array_equal(racc.cpu().numpy()[same], racc_o[same].astype(np.int64))
+
+
+def test_in_kernel_statistics_interleaved(oracle_lib, gpu):
+    """The same for the interleaved kernel (carried-gradient radon form and a re-bootstrapping model)."""
+    from autoreparam_amd import engine
+    for mname, lanes in (("radon_PA", 4), ("election", 8)):
+        sp = helpers.spec(mname)
+        eng = _eng(mname, gpu)
+        eng.set_param(0, "CP"); eng.set_param(1, "NCP")
+        Cn, S, batch, burn, thin = 70, 12, 3, 2, 2
+        q0 = helpers.states(sp, Cn, seed=5, scale=0.1)
+        e = np.full(sp.D, 1e-3, np.float32)
+        total = 1 + burn + thin * (S - 1)
+        kw = dict(seed=3, n_burnin=burn, thin=thin, trace_centered=False, lanes=lanes)
+        st_a = engine.ChainState(torch.as_tensor(q0, device=gpu))
+        tr = torch.zeros(S, Cn, sp.D, device=gpu)
+        t0 = torch.zeros(S, Cn, dtype=torch.uint8, device=gpu); t1 = torch.zeros(S, Cn, dtype=torch.uint8, device=gpu)
+        eng.interleaved_run(st_a, e, e, 2, 2, total, trace=tr, trace_accept0=t0, trace_accept1=t1, **kw)
+        st_b = engine.ChainState(torch.as_tensor(q0, device=gpu))
+        stats = torch.zeros(6, Cn, sp.D, device=gpu)
+        r0 = torch.zeros(Cn, dtype=torch.int32, device=gpu); r1 = torch.zeros(Cn, dtype=torch.int32, device=gpu)
+        for n in (4, total - 4):
+            eng.interleaved_run(st_b, e, e, 2, 2, n, stats=stats, stats_batch=batch, n_samples=S, rec_accept0=r0,
+                                rec_accept1=r1, **kw)
+        assert torch.equal(st_a.q, st_b.q)
+        assert torch.equal(r0.long(), t0.long().sum(dim=0)) and torch.equal(r1.long(), t1.long().sum(dim=0))
+        mean, var, _ = engine.stats_summary(stats, S, batch)
+        x = tr.double(); scale = x.abs().amax(dim=0) + 1
+        assert ((mean - x.mean(dim=0)).abs() / scale).max() < 2e-6
+        assert ((var - x.var(dim=0, unbiased=True)).abs() / (scale * scale)).max() < 2e-6
