@@ -31,8 +31,9 @@ _DEFS = [
     # build-specific additions (the reference is unseeded and single-device)
     ("seed", int, 0, "Seed of the sampler's counter-based RNG and of the variational initial states."),
     ("device", str, "cuda:0", "GPU to run on."),
-    ("trace_chunk_rows", int, None, "Force the streaming trace mode with this many rows per chunk (default: "
-                                    "automatic, only when the [S, C, D] trace does not fit in HBM)."),
+    ("trace_chunk_rows", int, None, "Force the streaming mode (statistics accumulated inside the kernels, no [S, C, D] "
+                                    "trace; batch length of the batch-means ESS = this / 8).  Default: automatic, only "
+                                    "when the trace does not fit in HBM."),
     ("lanes_per_chain", int, 0, "Lanes of a wave64 a chain is spread over (0 = automatic)."),
 ]
 

@@ -135,7 +135,8 @@ class _LazyOriginalStates(object):
 
 
 class StreamingStats(object):
-    """Statistics of a trace that is produced chunk by chunk (and then discarded):
+    """Host-side restatement of the kernels' streaming statistics (arp_hmc_io.stats), kept as their checker.
+    Statistics of a trace that is produced chunk by chunk (and then discarded):
     running first/second moments per (chain, element) and means of consecutive
     batches of `batch` samples, from which ESS is estimated by batch means,
     ESS = S * var / (batch * var(batch means)).  Used when the reference's
@@ -178,7 +179,8 @@ class StreamingStats(object):
 
 
 def _trace_plan(S, C, D, dev, force_chunk=None):
-    """(rows per chunk, streaming?) -- the whole trace if it fits in 60 % of the free HBM."""
+    """(rows, streaming?) -- the whole trace if it fits in 60 % of the free HBM; `rows` only sets the batch
+    length of the batch-means ESS in streaming mode."""
     free, _ = torch.cuda.mem_get_info(dev)
     row = 4.0 * C * D + C
     if force_chunk:
@@ -192,40 +194,38 @@ def _trace_plan(S, C, D, dev, force_chunk=None):
 
 
 def _sample(run_segment, st, S, B, thin, C, D, dev, keep_chains, n_acc, chunk_rows=None):
-    """Drive `run_segment(n_steps, n_burnin, trace, accept_buffers)` over the whole
-    sample_chain schedule (result r after transition 1 + B + r*thin), whole-trace or
-    chunked.  Returns (trace or None, kept host trace, accept arrays, ess [C, D], estimator)."""
+    """Drive `run_segment(n_steps, n_burnin, trace, accept_buffers, **extra)` over the whole
+    sample_chain schedule (result r after transition 1 + B + r*thin).  Whole-trace mode keeps the
+    reference's [S, C, D] trace; when that does not fit in HBM (or --trace_chunk_rows forces it) the
+    kernels accumulate the statistics themselves (arp_hmc_io.stats) and only the first `keep_chains`
+    chains keep a trace.  Returns (trace or None, kept host trace, accept arrays, ess [C, D], estimator)."""
     rows, streaming = _trace_plan(S, C, D, dev, chunk_rows)
-    trace = torch.empty(rows, C, D, dtype=torch.float32, device=dev)
-    accs = [torch.empty(rows, C, dtype=torch.uint8, device=dev) for _ in range(n_acc)]
+    total = 1 + B + thin * (S - 1)
     if not streaming:
-        total = 1 + B + thin * (S - 1)
+        trace = torch.empty(rows, C, D, dtype=torch.float32, device=dev)
+        accs = [torch.empty(rows, C, dtype=torch.uint8, device=dev) for _ in range(n_acc)]
         done = 0
         while done < total:
             n = min(_MAX_STEPS_PER_LAUNCH, total - done)
             run_segment(n, B, trace, accs)
             done += n
         ess = util.effective_sample_size(trace)
-        return trace, None, [a.cpu().numpy().astype(bool) for a in accs], ess, "fft"
+        return trace, None, [a.cpu().numpy().astype(bool) for a in accs], ess, "autocorrelation"
     batch = max(8, min(rows, S) // 8)
-    stats = StreamingStats(C, D, batch, dev)
-    kept = np.empty((S, keep_chains, D), np.float32)
-    acc_counts = [torch.zeros(C, dtype=torch.int64, device=dev) for _ in range(n_acc)]
-    r0 = 0
-    while r0 < S:
-        nr = min(rows, S - r0)
-        last = 1 + B + thin * (r0 + nr - 1)           # transition index of the chunk's last sample
-        while st.step < last:
-            n = min(_MAX_STEPS_PER_LAUNCH, last - st.step)
-            # shifting the burn-in makes row 0 of the buffer the chunk's first sample
-            run_segment(n, B + thin * r0, trace[:nr], [a[:nr] for a in accs])
-        stats.update(trace[:nr])
-        kept[r0:r0 + nr] = trace[:nr, :keep_chains].cpu().numpy()
-        for k in range(n_acc):
-            acc_counts[k] += accs[k][:nr].sum(dim=0, dtype=torch.int64)
-        r0 += nr
-    ess = stats.ess()
-    return None, kept, [a.cpu().numpy()[np.newaxis, :] for a in acc_counts], ess, "batch_means(%d)" % batch
+    stats = torch.zeros(6, C, D, dtype=torch.float32, device=dev)
+    kept = torch.zeros(S, keep_chains, D, dtype=torch.float32, device=dev)
+    racc = [torch.zeros(C, dtype=torch.int32, device=dev) for _ in range(n_acc)]
+    extra = dict(stats=stats, stats_batch=batch, n_samples=S, trace_chains=keep_chains)
+    for k in range(n_acc):
+        extra["rec_accept%d" % k] = racc[k]
+    done = 0
+    while done < total:
+        n = min(_MAX_STEPS_PER_LAUNCH, total - done)
+        run_segment(n, B, kept, [None] * n_acc, **extra)
+        done += n
+    _, _, ess = _engine.stats_summary(stats, S, batch)
+    return None, kept.cpu().numpy(), [a.cpu().numpy()[np.newaxis, :] for a in racc], ess.to(torch.float32), \
+        "batch_means(%d)" % batch
 
 
 def _check_trace_fits(S, C, D, dev):
@@ -256,11 +256,11 @@ def hmc(target, model_config, step_size_init, initial_states, reparam, flags=FLA
     thin = 2                                      # num_steps_between_results=1 (inference.py:234)
     st = _engine.ChainState(q0)
 
-    def run_segment(n, n_burnin, trace, accs):
+    def run_segment(n, n_burnin, trace, accs, rec_accept0=None, **extra):
         eng.hmc_run(st, eps0, L, n, which=0, seed=flags.seed, chain_offset=chain_offset,
                     adapt_kind=_lib.ADAPT_DUAL, n_adapt=int(flags.num_adaptation_steps), adapt_target=0.75,
                     n_burnin=n_burnin, thin=thin, trace=trace, trace_accept=accs[0], trace_centered=True,
-                    lanes=flags.lanes_per_chain)
+                    lanes=flags.lanes_per_chain, rec_accept=rec_accept0, **extra)
 
     keep = max(1, int(flags.num_chains_to_save))
     trace, kept, accs, ess_flat, estimator = _sample(run_segment, st, S, B, thin, C, spec.D, dev, min(keep, C), 1,
@@ -300,12 +300,12 @@ def hmc_interleaved(model_config, target_cp, target_ncp, num_leapfrog_steps_cp, 
     thin = 2
     st = _engine.ChainState(q0)
 
-    def run_segment(n, n_burnin, trace, accs):
+    def run_segment(n, n_burnin, trace, accs, **extra):
         eng.interleaved_run(st, e_cp, e_ncp, int(num_leapfrog_steps_cp), int(num_leapfrog_steps_ncp), n,
                             seed=flags.seed, chain_offset=chain_offset, adapt_kind=_lib.ADAPT_SIMPLE,
                             n_adapt=int(flags.num_adaptation_steps), adapt_target=0.75, adapt_rate=0.05,
                             n_burnin=n_burnin, thin=thin, trace=trace, trace_accept0=accs[0], trace_accept1=accs[1],
-                            trace_centered=False, lanes=flags.lanes_per_chain)
+                            trace_centered=False, lanes=flags.lanes_per_chain, **extra)
 
     keep = max(1, int(flags.num_chains_to_save))
     trace, kept, accs, ess_flat, estimator = _sample(run_segment, st, S, B, thin, C, spec.D, dev, min(keep, C), 2,

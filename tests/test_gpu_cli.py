@@ -97,7 +97,7 @@ def test_streaming_trace_mode_equals_whole_trace(gpu):
     init = [0.1 * rs.randn(64, *s).astype(np.float32) for s in sp.part_shapes]
     step = [0.15] * 3 + [np.full(85, 0.3)]
     _, kr_a, st_a, ess_a = inference.hmc(target, cfg, step, init, "CP", flags=f)
-    assert inference.hmc.last_ess_estimator == "fft"
+    assert inference.hmc.last_ess_estimator == "autocorrelation"
     f2 = f.copy(); f2.trace_chunk_rows = 96
     so, kr_b, st_b, ess_b = inference.hmc(target, cfg, step, init, "CP", flags=f2)
     assert inference.hmc.last_ess_estimator.startswith("batch_means") and so is None
