@@ -114,36 +114,44 @@ ARP_DEV void store_row_wave(const Lane& M, float* stage, float* gdst, int cl, in
 __device__ __noinline__ void stats_update_staged(const float* stage, float* g, size_t comp, int nvalid, bool first,
                                                  bool batch_end, float invb) {
   const int lane = threadIdx.x & 63;
+  // per sample only ref (read), s1 and s2 (read-modify-write) are touched; `cur` holds s1 as it was when the
+  // current batch began and is visited at batch ends only: batch sum = s1 - cur
   auto upd = [&](float x, float& ref, float& s1, float& s2, float& cur, float& sb1, float& sb2) {
     ref = first ? x : ref;
     const float dx = x - ref;
-    s1 += dx; s2 = fmaf(dx, dx, s2); cur += dx;
-    if (batch_end) { const float bm = cur * invb; sb1 += bm; sb2 = fmaf(bm, bm, sb2); cur = 0.0f; }
+    s1 += dx; s2 = fmaf(dx, dx, s2);
+    if (batch_end) { const float bm = (s1 - cur) * invb; sb1 += bm; sb2 = fmaf(bm, bm, sb2); cur = s1; }
   };
   const bool aligned = ((reinterpret_cast<uintptr_t>(g) | (comp * sizeof(float))) & 15) == 0;
   for (int k = lane * 4; k < nvalid; k += 256) {
     if (aligned && k + 3 < nvalid) {
       const float4 x = *reinterpret_cast<const float4*>(stage + k);
       float4 ref = *reinterpret_cast<float4*>(g + k), s1 = *reinterpret_cast<float4*>(g + comp + k);
-      float4 s2 = *reinterpret_cast<float4*>(g + 2 * comp + k), cur = *reinterpret_cast<float4*>(g + 3 * comp + k);
-      float4 sb1 = make_float4(0, 0, 0, 0), sb2 = sb1;
-      if (batch_end) { sb1 = *reinterpret_cast<float4*>(g + 4 * comp + k); sb2 = *reinterpret_cast<float4*>(g + 5 * comp + k); }
+      float4 s2 = *reinterpret_cast<float4*>(g + 2 * comp + k);
+      float4 cur = make_float4(0, 0, 0, 0), sb1 = cur, sb2 = cur;
+      if (batch_end) {
+        cur = *reinterpret_cast<float4*>(g + 3 * comp + k);
+        sb1 = *reinterpret_cast<float4*>(g + 4 * comp + k); sb2 = *reinterpret_cast<float4*>(g + 5 * comp + k);
+      }
       upd(x.x, ref.x, s1.x, s2.x, cur.x, sb1.x, sb2.x);
       upd(x.y, ref.y, s1.y, s2.y, cur.y, sb1.y, sb2.y);
       upd(x.z, ref.z, s1.z, s2.z, cur.z, sb1.z, sb2.z);
       upd(x.w, ref.w, s1.w, s2.w, cur.w, sb1.w, sb2.w);
       if (first) *reinterpret_cast<float4*>(g + k) = ref;
       *reinterpret_cast<float4*>(g + comp + k) = s1; *reinterpret_cast<float4*>(g + 2 * comp + k) = s2;
-      *reinterpret_cast<float4*>(g + 3 * comp + k) = cur;
-      if (batch_end) { *reinterpret_cast<float4*>(g + 4 * comp + k) = sb1; *reinterpret_cast<float4*>(g + 5 * comp + k) = sb2; }
+      if (batch_end) {
+        *reinterpret_cast<float4*>(g + 3 * comp + k) = cur;
+        *reinterpret_cast<float4*>(g + 4 * comp + k) = sb1; *reinterpret_cast<float4*>(g + 5 * comp + k) = sb2;
+      }
     } else {   // unaligned planes or the ragged tail of the wave's block: element by element, nothing past it is touched
       for (int j = k; j < nvalid && j < k + 4; ++j) {
-        float ref = g[j], s1 = g[comp + j], s2 = g[2 * comp + j], cur = g[3 * comp + j];
-        float sb1 = batch_end ? g[4 * comp + j] : 0.0f, sb2 = batch_end ? g[5 * comp + j] : 0.0f;
+        float ref = g[j], s1 = g[comp + j], s2 = g[2 * comp + j];
+        float cur = batch_end ? g[3 * comp + j] : 0.0f, sb1 = batch_end ? g[4 * comp + j] : 0.0f;
+        float sb2 = batch_end ? g[5 * comp + j] : 0.0f;
         upd(stage[j], ref, s1, s2, cur, sb1, sb2);
         if (first) g[j] = ref;
-        g[comp + j] = s1; g[2 * comp + j] = s2; g[3 * comp + j] = cur;
-        if (batch_end) { g[4 * comp + j] = sb1; g[5 * comp + j] = sb2; }
+        g[comp + j] = s1; g[2 * comp + j] = s2;
+        if (batch_end) { g[3 * comp + j] = cur; g[4 * comp + j] = sb1; g[5 * comp + j] = sb2; }
       }
     }
   }

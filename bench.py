@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="diagnostic: do not record trace rows")
+    ap.add_argument("--stats", action="store_true", help="diagnostic: accumulate the in-kernel streaming statistics "
+                                                         "(arp_hmc_io.stats) every step instead of writing trace rows")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,13 +120,18 @@ def main():
     eps_i = np.full(D, 0.08 / (max(num_ls, 1) / 4.0) ** 2, np.float32)   # interleaved: eps0/(num_ls/4)^2
     eps_i[2] = 0.02 / (max(num_ls, 1) / 4.0) ** 2
 
+    stats = torch.zeros(6, C, D, dtype=torch.float32, device=dev) if args.stats else None
+    skw = dict(stats=stats, stats_batch=8, n_samples=1 << 30) if args.stats else {}
+
     def launch(record, plain=False):
         # trace rows cycle through a bounded buffer so a long bench does not need S*C*D floats
+        if args.stats and not plain:
+            record = False
         if inter and not plain:
             eng.interleaved_run(st, eps_i, eps_i, num_ls, num_ls, T, seed=7, chain_offset=rank * C,
                                 adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=10 ** 9, adapt_target=0.75, adapt_rate=0.05,
-                                n_burnin=st.step, thin=1, trace=trace[:T] if record else None, trace_centered=False,
-                                lanes=args.lanes)
+                                n_burnin=st.step if not args.stats else 0, thin=1, trace=trace[:T] if record else None,
+                                trace_centered=False, lanes=args.lanes, **skw)
         else:
             eng.hmc_run(st, eps0, L, T, seed=7, chain_offset=rank * C, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9,
                         n_burnin=st.step, thin=1, trace=trace[:T] if record else None, trace_centered=True,

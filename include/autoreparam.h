@@ -108,7 +108,7 @@ typedef struct arp_hmc_io {
   uint8_t* trace_accept;     /* [S][C] is_accepted of recorded transitions, or NULL */
   float* stats;              /* [6][C][D] in/out or NULL: streaming statistics of the recorded samples (same schedule and
                               * coordinates as the trace rows), accumulated in the kernel so that a run needs no trace:
-                              * {ref = first recorded sample, s1 = sum (x - ref), s2 = sum (x - ref)^2, cur = running sum of
+                              * {ref = first recorded sample, s1 = sum (x - ref), s2 = sum (x - ref)^2, cur = s1 at the start of
                               * the current batch, sb1 = sum of batch means (of x - ref), sb2 = sum of their squares}; zero it
                               * before the first call.  mean = ref + s1/n, var = (s2 - s1^2/n)/(n-1), batch-means ESS =
                               * n var / (stats_batch var(batch means)) */

@@ -655,10 +655,9 @@ static void FN(stats_update)(const orc_hmc_cfg* cfg, int C, int D, int c, long l
     const REAL dx = x[d] - S[o + d];
     S[comp + o + d] += dx;
     S[2 * comp + o + d] += dx * dx;
-    S[3 * comp + o + d] += dx;
-    if (batch_end) {
-      const REAL bm = S[3 * comp + o + d] / (REAL)batch;
-      S[4 * comp + o + d] += bm; S[5 * comp + o + d] += bm * bm; S[3 * comp + o + d] = 0;
+    if (batch_end) {   /* plane 3 holds s1 as it was when the batch began */
+      const REAL bm = (S[comp + o + d] - S[3 * comp + o + d]) / (REAL)batch;
+      S[4 * comp + o + d] += bm; S[5 * comp + o + d] += bm * bm; S[3 * comp + o + d] = S[comp + o + d];
     }
   }
 }
