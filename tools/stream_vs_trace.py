@@ -9,13 +9,15 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 cfg = models.get_model_by_name("german_credit_lognormalcentered")
 sp = cfg.model
 f = flags_mod.FlagValues()
-f.num_chains, f.num_samples, f.num_burnin_steps, f.num_adaptation_steps, f.num_leapfrog_steps = 16384, S, 500, 400, 4
+f.num_chains, f.num_samples, f.num_leapfrog_steps = 16384, S, 4
+f.num_burnin_steps, f.num_adaptation_steps = (10000, 6000) if S >= 50000 else (500, 400)   # reference defaults at full size
 f.num_chains_to_save = 4
 target, *_ = graphs.make_ncp_graph(cfg, flags=f)
 rs = np.random.RandomState(0)
 init = [0.1 * rs.randn(f.num_chains, *s).astype(np.float32) for s in sp.part_shapes]
 step = [0.02, np.full(62, 0.02), np.full(62, 0.02)]
-for mode in ("trace", "stats"):
+modes = ("stats",) if len(sys.argv) > 2 and sys.argv[2] == "stats" else ("trace", "stats")
+for mode in modes:
     ff = f.copy()
     if mode == "stats":
         ff.trace_chunk_rows = max(64, S // 4)
