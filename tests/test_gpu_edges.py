@@ -1,6 +1,5 @@
 """GPU: edge cases of the C ABI -- empty / tiny / ragged batches, zero-step calls,
 non-finite proposals, bad arguments, the largest BASELINE chain count."""
-import ctypes as C
 
 import numpy as np
 import pytest
