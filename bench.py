@@ -66,6 +66,52 @@ def cpu_baseline(spec, L, n_chains, n_trans, eps0, lanes, inter):
                                                  LL, cores, dt)}
 
 
+def cpu_baseline_reference_shaped(spec, L, n_chains=1024, budget_s=6.0):
+    """SURVEY.md 8(d) baseline (A): what the reference's XLA:CPU path executes, restated in torch on the host --
+    float32, the county gather as a dense [N, J] one-hot matmul batched over chains, gradients by reverse-mode
+    autodiff, one pass per leapfrog step (CP radon, momentum refresh and Metropolis test included).  Not the
+    reference itself (TF 1.14 / TFP cannot be installed here), and not the oracle: a shape-faithful stand-in."""
+    torch.manual_seed(0)
+    r = spec.raw
+    J, N = len(r["u"]), len(r["y"])
+    onehot = torch.zeros(N, J); onehot[torch.arange(N), torch.as_tensor(r["county"], dtype=torch.long)] = 1.0
+    u, x, y = (torch.as_tensor(np.asarray(r[k], np.float32)) for k in ("u", "x", "y"))
+
+    def logp(q):   # q [C, 3+J]
+        mua, b1, b2, m = q[:, 0:1], q[:, 1:2], q[:, 2:3], q[:, 3:]
+        prior = -0.5 * (q[:, :3] ** 2).sum(1) - 0.5 * ((m - (mua + u * b1)) ** 2).sum(1)
+        yhat = m @ onehot.t() + b2 * x          # [C, N]: the reference's tf.matmul(C_onehot, m) per chain
+        return prior - 0.5 * ((y - yhat) ** 2).sum(1)
+
+    def grad(q):
+        q = q.detach().requires_grad_(True)
+        lp = logp(q)
+        (g,) = torch.autograd.grad(lp.sum(), q)
+        return lp.detach(), g
+
+    q = 0.1 * torch.randn(n_chains, 3 + J)
+    eps = torch.full((3 + J,), 0.02)
+    lp, g = grad(q)
+    done, t0 = 0, time.time()
+    while time.time() - t0 < budget_s:
+        p = torch.randn_like(q)
+        h0 = -lp + 0.5 * (p * p).sum(1)
+        qn, pn = q, p + 0.5 * eps * g
+        for l in range(L):
+            qn = qn + eps * pn
+            lpn, gn = grad(qn)
+            pn = pn + (eps if l + 1 < L else 0.5 * eps) * gn
+        acc = torch.rand(n_chains).log() < h0 - (-lpn + 0.5 * (pn * pn).sum(1))
+        q = torch.where(acc[:, None], qn, q); g = torch.where(acc[:, None], gn, g); lp = torch.where(acc, lpn, lp)
+        done += 1
+    dt = time.time() - t0
+    return {"value": n_chains * done * L / dt, "unit": "leapfrog-steps/s", "cores": torch.get_num_threads(),
+            "kind": "reference-shaped stand-in",
+            "sample": "%d chains x %d transitions x %d leapfrogs of CP radon(%s), torch CPU float32, dense [N=%d, J=%d] "
+                      "one-hot matmul + autograd per leapfrog, %.1f s" % (n_chains, done, L, "PA" if J == 68 else "?",
+                                                                          N, J, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -286,6 +332,10 @@ def main():
                                                    inter)
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
+            try:
+                out["cpu_baseline_reference_shaped"] = cpu_baseline_reference_shaped(spec, L)
+            except Exception as e:
+                out["cpu_baseline_reference_shaped"] = {"value": None, "error": repr(e)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
