@@ -25,15 +25,25 @@ while time.time() - t0 < budget:
     st = engine.ChainState(torch.as_tensor(q0, device="cuda:0"))
     eps = np.full(sp.D, 1e-4 if m in ("time_series", "electric") else 1e-3, np.float32)
     S = int(rs.randint(1, 4))
-    tr = torch.zeros(S, C, sp.D, device="cuda:0")
+    tc = int(rs.choice([0, 1, min(C, 5), C]))                   # chains a trace row holds (0 = all)
+    tr = torch.zeros(S, tc if 0 < tc < C else C, sp.D, device="cuda:0")
     L, T = int(rs.randint(1, 5)), int(rs.randint(1, 9))
+    extra = {}
+    if rs.rand() < 0.5:                                         # in-kernel streaming statistics
+        extra = dict(stats=torch.zeros(6, C, sp.D, device="cuda:0"), stats_batch=int(rs.randint(1, 4)), n_samples=S,
+                     trace_chains=tc)
+    elif 0 < tc < C:
+        extra = dict(trace_chains=tc)
     if rs.rand() < 0.5:
         eng.hmc_run(st, eps, L, T, seed=int(rs.randint(1 << 30)), adapt_kind=int(rs.randint(3)), n_adapt=3, n_burnin=0,
-                    thin=max(1, T // S), trace=tr, lanes=lanes)
+                    thin=max(1, T // S), trace=tr, lanes=lanes, rec_accept=torch.zeros(C, dtype=torch.int32, device="cuda:0"),
+                    **extra)
     else:
         eng.interleaved_run(st, eps, eps, L, L, T, seed=int(rs.randint(1 << 30)), adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=3,
-                            n_burnin=0, thin=max(1, T // S), trace=tr, lanes=lanes)
+                            n_burnin=0, thin=max(1, T // S), trace=tr, lanes=lanes, **extra)
     torch.cuda.synchronize()
     assert torch.isfinite(st.q).all() and torch.isfinite(tr).all(), (m, C, lanes, kind)
+    if "stats" in extra:
+        assert torch.isfinite(extra["stats"]).all(), (m, C, lanes, kind)
     n += 1
 print("soak ok: %d launches in %.0f s" % (n, time.time() - t0))
