@@ -16,7 +16,8 @@ static const double kHalfLog2Pi = 0.9189385332046727;
 // pick the instantiation: requested lanes-per-chain (or a default from the chain
 // count) and the smallest slice size that covers `groups`.
 // `exact`: the family needs NL == ceil(groups / K) (only a lane's last slice may be padding).
-static const LaneOps* pick(const std::vector<LaneOps>& ops, int groups, int K_req, int C, bool exact) {
+static const LaneOps* pick(const std::vector<LaneOps>& ops, int groups, int K_req, int C, bool exact,
+                           long long fill_lanes = 131072) {
   auto best_for = [&](int K) -> const LaneOps* {
     const LaneOps* best = nullptr;
     for (const auto& o : ops)
@@ -25,8 +26,8 @@ static const LaneOps* pick(const std::vector<LaneOps>& ops, int groups, int K_re
     return best;
   };
   if (K_req > 0) return best_for(K_req);
-  // default: the fewest lanes per chain that still give every SIMD of the 256 CUs
-  // two waves (256 CU x 4 SIMD x 2 waves x 64 lanes = 131072 lanes)
+  // default: the fewest lanes per chain that still put `fill_lanes` lanes on the device -- two waves on every
+  // SIMD of the 256 CUs (256 x 4 x 2 x 64 = 131072) unless the family measured better with one
   std::vector<int> Ks;
   for (const auto& o : ops) if (std::find(Ks.begin(), Ks.end(), o.K) == Ks.end()) Ks.push_back(o.K);
   std::sort(Ks.begin(), Ks.end());
@@ -35,7 +36,7 @@ static const LaneOps* pick(const std::vector<LaneOps>& ops, int groups, int K_re
     const LaneOps* o = best_for(K);
     if (!o) continue;
     last = o;
-    if ((long long)C * K >= 131072) return o;
+    if ((long long)C * K >= fill_lanes) return o;
   }
   return last;
 }
@@ -373,7 +374,10 @@ static const LaneOps* select_ops(arp_model* m, int K_req, int C) {
   // german credit: the 4-lane instantiation runs its likelihood on the matrix cores and beats the
   // wider ones at every chain count (per workgroup 4x the 8-lane and 17x the 16-lane rate)
   if (K_req == 0 && m->model == ARP_MODEL_GERMAN_CREDIT) K_req = 4;
-  const LaneOps* o = pick(*fam, m->n_groups, K_req, C, m->model != ARP_MODEL_GERMAN_CREDIT);
+  // radon: a wider split costs more replicated work than a second wave per SIMD returns (bench.py --chains 8192:
+  // 1.21e10 leapfrog-steps/s at 8 lanes per chain, 1.07e10 at 16), so one wave per SIMD is enough
+  const long long fill = m->model == ARP_MODEL_RADON ? 65536 : 131072;
+  const LaneOps* o = pick(*fam, m->n_groups, K_req, C, m->model != ARP_MODEL_GERMAN_CREDIT, fill);
   if (!o) set_error("no kernel instantiation for this (lanes_per_chain, group count): add <Model>Lane<K, ceil(groups/K)> to the model's inst_*.hip");
   return o;
 }
