@@ -270,7 +270,7 @@ def main():
     if world == 1:
         from autoreparam_amd import util
         S_ess, burn = 200, 200
-        Ce = min(C, 8192)
+        Ce = C   # the headline chain count: the trace is S_ess x C x D x 4 B = 3.7 GB
         st3 = engine.ChainState(q0[:Ce])
         tr3 = torch.empty(S_ess, Ce, D, dtype=torch.float32, device=dev)
         tot = 1 + burn + 2 * (S_ess - 1)
