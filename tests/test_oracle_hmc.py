@@ -208,3 +208,34 @@ def test_interleaved_step_structure(oracle_lib):
     np.testing.assert_allclose(st["q"], q, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(st["adapt"][:, 0], ad[0][:, 0], rtol=1e-12)
     np.testing.assert_allclose(st["adapt1"][:, 0], ad[1][:, 0], rtol=1e-12)
+
+
+def test_streaming_statistics_equal_trace_moments(oracle_lib):
+    """arp_hmc_io.stats as the oracle restates it: shifted first / second moments and batch means accumulated
+    during the run equal those of the recorded trace; a chunked run equals a single one; partial traces and the
+    accepted-among-recorded counters follow the same schedule."""
+    sp = helpers.spec("radon_MN")
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "VIP", seed=3)
+    C, S, batch, burn, thin, keep = 9, 20, 4, 3, 2, 2
+    q0 = helpers.states(sp, C, seed=1, scale=0.1).astype(np.float64)
+    eps0 = np.full(sp.D, 0.02, np.float32)
+    total = 1 + burn + thin * (S - 1)
+    kw = dict(seed=5, n_burnin=burn, thin=thin, trace_centered=True, lanes=8)
+    st = oracle_lib.new_state(q0, np.float64)
+    tr = np.zeros((S, C, sp.D)); ta = np.zeros((S, C), np.uint8)
+    orc.hmc_run(st, a, b, eps0, 3, total, trace=tr, trace_accept=ta, **kw)
+    st2 = oracle_lib.new_state(q0, np.float64)
+    stats = np.zeros((6, C, sp.D)); racc = np.zeros(C, np.uint32); trk = np.zeros((S, keep, sp.D))
+    for n in (2, 11, total - 13):
+        orc.hmc_run(st2, a, b, eps0, 3, n, stats=stats, stats_batch=batch, n_samples=S, trace=trk, trace_chains=keep,
+                    rec_accept=racc, **kw)
+    assert np.array_equal(st["q"], st2["q"]) and np.array_equal(trk, tr[:, :keep])
+    assert np.array_equal(racc, ta.sum(axis=0))
+    ref, s1, s2, cur, sb1, sb2 = stats
+    np.testing.assert_allclose(ref, tr[0])
+    np.testing.assert_allclose(ref + s1 / S, tr.mean(axis=0), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose((s2 - s1 * s1 / S) / (S - 1), tr.var(axis=0, ddof=1), rtol=1e-9, atol=1e-12)
+    bm = (tr - ref).reshape(S // batch, batch, C, sp.D).mean(axis=1)
+    np.testing.assert_allclose(sb1, bm.sum(axis=0), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(sb2, (bm * bm).sum(axis=0), rtol=1e-10, atol=1e-12)
