@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--dataset", default="PA")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the secondary figures (plain_hmc, german_credit, ess): profiler runs, so that every "
+                         "launch of the headline kernel in the trace is a timed or warm-up step")
     ap.add_argument("--no-trace", action="store_true", help="diagnostic: do not record trace rows")
     ap.add_argument("--stats", action="store_true", help="diagnostic: accumulate the in-kernel streaming statistics "
                                                          "(arp_hmc_io.stats) every step instead of writing trace rows")
@@ -220,7 +223,7 @@ def main():
 
     # secondary figure, same run: the plain fused HMC kernel (CP, dual averaging, L leapfrogs)
     plain = None
-    if inter and world == 1:
+    if inter and world == 1 and not args.headline_only:
         st2, st = st, engine.ChainState(q0)
         for _ in range(2):
             launch(True, plain=True)
@@ -239,7 +242,7 @@ def main():
     # secondary figure: the one compute-bound model (BASELINE configs[2], german credit, 16 384 chains).
     # SURVEY.md 8d prices it against the f32 peak: algorithmic flops = 2 products x 2 flop x N x F per gradient.
     german = None
-    if world == 1:
+    if world == 1 and not args.headline_only:
         gspec = models._spec_german()
         geng = engine.Engine(gspec, dev)
         geng.set_param(0, "NCP")
@@ -267,7 +270,7 @@ def main():
     # ESS/sec (second half of the BASELINE metric): a separate short run with the same kernel,
     # S recorded samples at the reference's thinning, ESS by FFT on the device trace
     ess_info = None
-    if world == 1:
+    if world == 1 and not args.headline_only:
         from autoreparam_amd import util
         S_ess, burn = 200, 200
         Ce = C   # the headline chain count: the trace is S_ess x C x D x 4 B = 3.7 GB
