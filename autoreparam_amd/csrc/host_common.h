@@ -10,6 +10,7 @@
 #include "../../include/autoreparam.h"
 #include "kernels.h"
 #include "model_radon.h"
+#include "radon_fast.h"
 #include "model_schools.h"
 #include "model_election.h"
 #include "model_german.h"
@@ -109,6 +110,30 @@ struct Launch {
     return o;
   }
 };
+
+// Radon: the generic lane kernels serve the general VIP form, the packed kernels of radon_fast.h the two
+// compile-time parameterisations (centred, non-centred) and their interleaving.
+template <int K, int NL>
+LaneOps radon_lane_ops() {
+  LaneOps o = Launch<RadonLane<K, NL>>::ops();
+  if constexpr (K >= 4) {
+    using T = RadonPk<K, NL>;
+    o.hmc_cp = [](const void* args, const float*, const float*, const HmcParams& P, hipStream_t s) {
+      hipLaunchKernelGGL((radon_hmc_kernel<T, kModeCP>), dim3(Launch<RadonLane<K, NL>>::blocks(P.C)), dim3(kBlock), 0, s,
+                         *(const RadonArgs*)args, P);
+    };
+    o.hmc_ncp = [](const void* args, const float*, const float*, const HmcParams& P, hipStream_t s) {
+      hipLaunchKernelGGL((radon_hmc_kernel<T, kModeNCP>), dim3(Launch<RadonLane<K, NL>>::blocks(P.C)), dim3(kBlock), 0, s,
+                         *(const RadonArgs*)args, P);
+    };
+    o.interleaved_cp_ncp = [](const void* args, const float*, const float*, const float*, const float*,
+                              const HmcParams& P, hipStream_t s) {
+      hipLaunchKernelGGL((radon_interleaved_kernel<T>), dim3(Launch<RadonLane<K, NL>>::blocks(P.C)), dim3(kBlock), 0, s,
+                         *(const RadonArgs*)args, P);
+    };
+  }
+  return o;
+}
 
 // per-family tables (defined in inst_*.hip)
 const std::vector<LaneOps>& radon_ops();

@@ -5,6 +5,6 @@
 
 namespace arp {
 std::vector<LaneOps> radon_ops_k16() {
-  return {Launch<RadonLane<16, 4>>::ops(), Launch<RadonLane<16, 5>>::ops(), Launch<RadonLane<16, 6>>::ops(), Launch<RadonLane<16, 8>>::ops()};
+  return {radon_lane_ops<16, 4>(), radon_lane_ops<16, 5>(), radon_lane_ops<16, 6>(), radon_lane_ops<16, 8>()};
 }
 }  // namespace arp

@@ -5,6 +5,6 @@
 
 namespace arp {
 std::vector<LaneOps> radon_ops_k4() {
-  return {Launch<RadonLane<4, 14>>::ops(), Launch<RadonLane<4, 17>>::ops(), Launch<RadonLane<4, 22>>::ops(), Launch<RadonLane<4, 23>>::ops(), Launch<RadonLane<4, 29>>::ops()};
+  return {radon_lane_ops<4, 14>(), radon_lane_ops<4, 17>(), radon_lane_ops<4, 22>(), radon_lane_ops<4, 23>(), radon_lane_ops<4, 29>()};
 }
 }  // namespace arp

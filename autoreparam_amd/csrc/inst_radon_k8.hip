@@ -5,6 +5,6 @@
 
 namespace arp {
 std::vector<LaneOps> radon_ops_k8() {
-  return {Launch<RadonLane<8, 7>>::ops(), Launch<RadonLane<8, 9>>::ops(), Launch<RadonLane<8, 11>>::ops(), Launch<RadonLane<8, 12>>::ops(), Launch<RadonLane<8, 15>>::ops()};
+  return {radon_lane_ops<8, 7>(), radon_lane_ops<8, 9>(), radon_lane_ops<8, 11>(), radon_lane_ops<8, 12>(), radon_lane_ops<8, 15>()};
 }
 }  // namespace arp

@@ -4,6 +4,7 @@
 // launch, so an HMC segment of n_steps transitions touches HBM only to load and
 // store the chain state once and to append trace rows.
 #pragma once
+#include <type_traits>
 #include "arp_device.h"
 #include "../../include/autoreparam.h"
 
@@ -277,30 +278,53 @@ __global__ __launch_bounds__(kBlock) void transform_kernel(
 // only the rejecting lanes read it back, so no second copy of the state lives in
 // VGPRs and acceptance needs no per-element select.
 // ---------------------------------------------------------------------------
+// random-stream layout of a lane model's momentum draw (0 unless the model declares MOM_SPEC)
+template <class L, class = void> struct lane_mom_spec { static constexpr int value = 0; };
+template <class L> struct lane_mom_spec<L, std::void_t<decltype(L::MOM_SPEC)>> { static constexpr int value = L::MOM_SPEC; };
+
 template <class Lane, int MODE = kModeVIP>
 ARP_DEV float hmc_transition(const Lane& M, Rng& rng, int L, const float (&eps)[Lane::ND],
                              float (&q)[Lane::ND], float (&g)[Lane::ND], float& lp,
                              bool& accepted, float* save) {
   constexpr int K = Lane::K, ND = Lane::ND, NG = Lane::NG;
   float p[ND];
-  // momenta: every lane draws ND normals from its own stream; the replicated
-  // globals take slot 0's draw, padding slots get none.
+  float u;
+  if constexpr (lane_mom_spec<Lane>::value == 1) {
+    // stream layout 1 (radon): a slot draws one normal per slice it owns, then ceil(NG / K) more, of which
+    // extra x of slot s is the momentum of top-level scalar s + K*x -- no slot draws a normal it discards
+    constexpr int NLs = ND - NG, NE = (NG + K - 1) / K, NN = NLs + NE;
+    float z[NN + 1];
 #pragma unroll
-  for (int i = 0; i < ND; i += 2) {
-    // every slot draws ND = NG + ceil(groups / K) normals (the host picks NL == ceil(groups / K))
-    float z0, z1;
-    uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
-    normal_pair(w0, w1, z0, z1);
-    p[i] = z0;
-    if (i + 1 < ND) p[i + 1] = z1;
+    for (int i = 0; i < NN; i += 2) {
+      uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
+      normal_pair(w0, w1, z[i], z[i + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < NLs; ++i) p[NG + i] = z[i];
+    u = u01_open0(rng_next(rng));
+    u = group_bcast0<K>(u, M.slot);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) p[i] = group_sum<K>(M.slot == i % K ? z[NLs + i / K] : 0.0f);
+  } else {
+    // layout 0: every lane draws ND = NG + ceil(groups / K) normals from its own stream (the host picks
+    // NL == ceil(groups / K)); the replicated globals take slot 0's draw, padding slots get none
+#pragma unroll
+    for (int i = 0; i < ND; i += 2) {
+      float z0, z1;
+      uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
+      normal_pair(w0, w1, z0, z1);
+      p[i] = z0;
+      if (i + 1 < ND) p[i + 1] = z1;
+    }
+    u = u01_open0(rng_next(rng));
+    u = group_bcast0<K>(u, M.slot);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) p[i] = group_bcast0<K>(p[i], M.slot);
   }
-  float u = u01_open0(rng_next(rng));
-  u = group_bcast0<K>(u, M.slot);
   float ke0 = 0.0f, keg0 = 0.0f;
 #pragma unroll
   for (int i = 0; i < ND; ++i) {
     if (i < NG) {
-      p[i] = group_bcast0<K>(p[i], M.slot);
       keg0 = fmaf(p[i], p[i], keg0);
     } else {
       p[i] = M.lvalid(i - NG) ? p[i] : 0.0f;

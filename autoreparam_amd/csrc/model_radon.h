@@ -43,10 +43,11 @@ struct RadonLane {
   bool last_ok;
   // VALU issue needs two resident waves per SIMD: cap the allocation at 256 VGPRs where the slice fits
   static constexpr int MINW = (NL_ <= 23) ? 2 : 1;
-  static constexpr bool HAS_MODES = true;
-  static constexpr bool HAS_CARRY = true;   // carry<> below
+  static constexpr bool HAS_MODES = false;  // centred / non-centred runs use the packed kernels of radon_fast.h
+  static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = true;   // kick_drift below  // grad_m / to_centered_m / from_centered_m below
   static constexpr bool HAS_VI = true;
+  static constexpr int MOM_SPEC = 1;   // momentum stream layout 1 (kernels.h: hmc_transition, radon_fast.h)
   static constexpr bool HAS_MODE_STATE = false;   // nothing but (a, b) depends on the parameterisation
   using Args = RadonArgs;
 

@@ -1,0 +1,536 @@
+// Packed-f32 chain kernels for the radon model in its two compile-time parameterisations
+// (centred, non-centred): the headline path (BASELINE configs[1] and [3]; reference
+// inference.py:198-242, 258-329, interleaved.py:113-155, models.py:826-837).
+//
+// Same algorithm and same random streams as the generic kernels in kernels.h (which keep
+// serving the general VIP form), restated so that EVERYTHING a lane owns lives in register
+// PAIRS: a lane's counties j = slot + K*i are held two at a time (pair k = counties 2k, 2k+1)
+// and every per-county operation of a transition -- Box-Muller scaling, step sizes, kicks,
+// drifts, kinetic energies, the gradient, the log density, the change of coordinates -- is one
+// v_pk_*_f32 on a pair.  On gfx950 a v_pk_fma_f32 issues in 4.4 cycles against 2 x 2.5-2.9 for
+// two v_fma_f32 at two waves per SIMD, and, as important, the pairs never have to be packed or
+// unpacked (the generic float-array form spends ~15 % of its instructions on v_mov).
+//
+// Two algebraic facts of this model are used:
+//  * the log joint is a quadratic form with no constant term, so
+//        logp(q) = 1/2 q . (grad(q) + grad(0)),   grad(0) = (c0, c1, Sxy, Sy_j ...)
+//    -- two packed operations per county pair next to the gradient instead of six;
+//  * CP <-> NCP is a shear with unit Jacobian: logp is unchanged and the gradient follows by
+//    the chain rule (`carry`), so the interleaved kernel never re-bootstraps.
+#pragma once
+#include "kernels.h"
+#include "model_radon.h"
+
+namespace arp {
+
+template <int K, int SRC>
+ARP_DEV float group_bcast_from(float v, int slot) {
+  static_assert(SRC < 4, "source slot must lie in the first quad");
+  if (K == 1) return v;
+  if (K == 4 || K == 2) return dpp_mov<SRC * 0x55>(v);            // quad_perm [SRC, SRC, SRC, SRC]
+  return group_sum<K>(slot == SRC ? v : 0.0f);
+}
+
+ARP_DEV v2f splat(float x) { return v2f{x, x}; }
+
+// Box-Muller pair as a register pair: (r cos, r sin) = one packed multiply
+ARP_DEV v2f normal_pair2(uint32_t w0, uint32_t w1) {
+  const float u = fmaf((float)w0, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+  const float rev = (float)w1 * 2.3283064365386963e-10f;
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));
+  const v2f cs = {__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)};
+  return cs * splat(r);
+}
+
+template <int K_, int NL_>
+struct RadonPk {
+  static constexpr int K = K_, NL = NL_, NG = 3, ND = NG + NL_;
+  static constexpr int NP = (NL_ + 1) / 2;          // county pairs (the last one half padding when NL is odd)
+  static constexpr int DCAP = NG + K_ * NL_;
+  static constexpr int LBASE = 3;
+  static_assert(K_ >= 4, "the packed radon kernels deal the three top-level momenta out over slots 0..2");
+  using Args = RadonArgs;
+
+  v2f n2[NP], sx2[NP], sy2[NP], u2[NP];
+  v2f mlast;        // 1/0: which elements of the LAST pair are real counties
+  float sxy, sxx;
+  float c_sy, c_suy;   // sum_j Sy_j, sum_j u_j Sy_j over the chain's counties (grad(0) of the NCP form)
+  int slot;
+  bool last_ok;
+
+  // row I/O contract of kernels.h (load_row / store_row_wave / stats_update_wave)
+  static ARP_DEV int gg(int i) { return i; }
+  ARP_DEV int lbase(int) const { return LBASE + slot; }
+  static constexpr ARP_DEV int loff(int i) { return K * i; }
+  ARP_DEV bool lvalid(int i) const { return i < NL - 1 ? true : last_ok; }
+
+  ARP_DEV void init(const Args& A, int slot_) {
+    slot = slot_;
+    const int J = A.J;
+    last_ok = slot + K * (NL - 1) < J;
+    sxy = A.sxy; sxx = A.sxx;
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2 * NP; ++i) {
+      const int j = slot + K * i;
+      const bool ok = i < NL && j < J;
+      const float nj = ok ? A.n[j] : 0.0f, sxj = ok ? A.sx[j] : 0.0f, syj = ok ? A.sy[j] : 0.0f, uj = ok ? A.u[j] : 0.0f;
+      n2[i >> 1][i & 1] = nj; sx2[i >> 1][i & 1] = sxj; sy2[i >> 1][i & 1] = syj; u2[i >> 1][i & 1] = uj;
+      s0 += syj; s1 = fmaf(uj, syj, s1);
+    }
+    c_sy = group_sum<K>(s0);
+    c_suy = group_sum<K>(s1);
+    if (NL & 1) mlast = v2f{last_ok ? 1.0f : 0.0f, 0.0f};
+    else mlast = v2f{1.0f, last_ok ? 1.0f : 0.0f};
+  }
+
+  // state <-> flattened float row (register renaming only)
+  static ARP_DEV void unpack(const float (&v)[ND], float (&g3)[3], v2f (&c)[NP]) {
+    g3[0] = v[0]; g3[1] = v[1]; g3[2] = v[2];
+#pragma unroll
+    for (int i = 0; i < 2 * NP; ++i) c[i >> 1][i & 1] = i < NL ? v[NG + i] : 0.0f;
+  }
+  static ARP_DEV void pack(const float (&g3)[3], const v2f (&c)[NP], float (&v)[ND]) {
+    v[0] = g3[0]; v[1] = g3[1]; v[2] = g3[2];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) v[NG + i] = c[i >> 1][i & 1];
+  }
+
+  // One pass over the lane's county pairs at position (qg, qc).
+  //   PASS 0  interior leapfrog step: gradient, full kick, drift (q, p updated in place)
+  //   PASS 1  closing: gradient -> (gg, gc), logp, and 1/2 |p + eps/2 g|^2 (the momentum itself is dead afterwards)
+  //   PASS 2  bootstrap: gradient -> (gg, gc) and logp
+  // MODE kModeCP:  r = mt - mu, m = mt,      dlogp/dmu = r
+  // MODE kModeNCP: r = mt,      m = mt + mu, dlogp/dmu = l          (model_radon.h has the derivation)
+  template <int MODE, int PASS>
+  ARP_DEV void pass(float (&qg)[3], v2f (&qc)[NP], float (&pg)[3], v2f (&pc)[NP], const float (&eg)[3],
+                    const v2f (&ec)[NP], float (&gg_)[3], v2f (&gc)[NP], float& lp, float& ke) const {
+    const float mua = qg[0], b1 = qg[1], b2 = qg[2];
+    const v2f vb1 = splat(b1), vnb2 = splat(-b2), vmua = splat(mua);
+    const v2f vmua_last = vmua * mlast;     // padding: mu = 0 there (its u is 0), so r = m = 0
+    v2f ah[2] = {splat(0.0f), splat(0.0f)}, auh[2] = {splat(0.0f), splat(0.0f)}, ams[2] = {splat(0.0f), splat(0.0f)};
+    v2f alp = splat(0.0f), ake = splat(0.0f);
+    const v2f half = splat(0.5f);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const v2f mt = qc[k];
+      const v2f mu = vfma(u2[k], vb1, (k == NP - 1 && MODE == kModeCP) ? vmua_last : vmua);
+      const v2f t = vfma(vnb2, sx2[k], sy2[k]);
+      v2f r, m;
+      if (MODE == kModeCP) { r = mt - mu; m = mt; } else { r = mt; m = mt + mu; }
+      const v2f l = vfma(-n2[k], m, t);
+      const v2f gm = l - r;
+      const v2f h = (MODE == kModeCP) ? r : l;
+      ah[k & 1] += h;
+      auh[k & 1] = vfma(u2[k], h, auh[k & 1]);
+      ams[k & 1] = vfma(m, sx2[k], ams[k & 1]);
+      if (PASS == 0) {
+        const v2f pn = vfma(ec[k], gm, pc[k]);
+        pc[k] = pn;
+        qc[k] = vfma(ec[k], pn, mt);
+      } else {
+        gc[k] = gm;
+        alp = vfma(mt, gm + sy2[k], alp);
+        if (PASS == 1) {
+          const v2f pf = vfma(half, ec[k] * gm, pc[k]);
+          ake = vfma(pf, pf, ake);
+        }
+      }
+    }
+    const v2f th = ah[0] + ah[1], tuh = auh[0] + auh[1], tms = ams[0] + ams[1];
+    const float s_h = group_sum<K>(th[0] + th[1]);
+    const float s_uh = group_sum<K>(tuh[0] + tuh[1]);
+    const float s_ms = group_sum<K>(tms[0] + tms[1]);
+    const float g0 = s_h - mua, g1 = s_uh - b1, g2 = fmaf(-b2, sxx, sxy) - s_ms - b2;
+    if (PASS == 0) {
+      pg[0] = fmaf(eg[0], g0, pg[0]); qg[0] = fmaf(eg[0], pg[0], mua);
+      pg[1] = fmaf(eg[1], g1, pg[1]); qg[1] = fmaf(eg[1], pg[1], b1);
+      pg[2] = fmaf(eg[2], g2, pg[2]); qg[2] = fmaf(eg[2], pg[2], b2);
+    } else {
+      gg_[0] = g0; gg_[1] = g1; gg_[2] = g2;
+      // logp = 1/2 q . (g + g(0)); g(0) = (0, 0, Sxy, Sy_j) centred, (sum Sy, sum u Sy, Sxy, Sy_j) non-centred
+      const float c0 = MODE == kModeCP ? 0.0f : c_sy, c1 = MODE == kModeCP ? 0.0f : c_suy;
+      float top = mua * (g0 + c0);
+      top = fmaf(b1, g1 + c1, top);
+      top = fmaf(b2, g2 + sxy, top);
+      lp = 0.5f * (group_sum<K>(alp[0] + alp[1]) + top);
+      if (PASS == 1) {
+        float kg = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const float pf = fmaf(0.5f * eg[i], gg_[i], pg[i]);
+          kg = fmaf(pf, pf, kg);
+        }
+        ke = 0.5f * (group_sum<K>(ake[0] + ake[1]) + kg);
+      }
+    }
+  }
+
+  // Change of coordinates of the state AND its cached gradient (the shear m = mt + mu(mua, b1)):
+  // FROM == kModeCP: CP -> NCP, FROM == kModeNCP: NCP -> CP.
+  template <int FROM>
+  ARP_DEV void carry(float (&qg)[3], v2f (&qc)[NP], float (&gg_)[3], const v2f (&gc)[NP]) const {
+    const v2f vb1 = splat(qg[1]), vmua = splat(qg[0]);
+    const v2f vmua_last = vmua * mlast;
+    v2f s = splat(0.0f), su = splat(0.0f);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const v2f mu = vfma(u2[k], vb1, k == NP - 1 ? vmua_last : vmua);
+      s += gc[k];                                  // gradients of padding elements are 0
+      su = vfma(u2[k], gc[k], su);
+      qc[k] = (FROM == kModeCP) ? qc[k] - mu : qc[k] + mu;
+    }
+    const float ts = group_sum<K>(s[0] + s[1]), tsu = group_sum<K>(su[0] + su[1]);
+    gg_[0] += (FROM == kModeCP) ? ts : -ts;
+    gg_[1] += (FROM == kModeCP) ? tsu : -tsu;
+  }
+
+  // centred coordinates of a state held in parameterisation MODE
+  template <int MODE>
+  ARP_DEV void to_centered(const float (&qg)[3], const v2f (&qc)[NP], v2f (&xc)[NP]) const {
+    const v2f vb1 = splat(qg[1]), vmua = splat(qg[0]);
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+      xc[k] = (MODE == kModeNCP) ? qc[k] + vfma(u2[k], vb1, k == NP - 1 ? vmua * mlast : vmua) : qc[k];
+  }
+};
+
+// Parked start-of-trajectory state: pairs as 8-byte columns, the six top-level floats as 4-byte columns
+// (all conflict free: consecutive lanes touch consecutive 8- or 4-byte words).
+template <class T> constexpr int radon_save_floats() { return (4 * T::NP + 6) * kBlock; }
+
+// One HMC transition (mcmc.HamiltonianMonteCarlo.one_step as wired at inference.py:218-222); the contract of
+// kernels.h: hmc_transition with the state in pairs.  Random stream layout 1 (DESIGN.md "Randomness"): a slot
+// draws one normal per county it owns, then one more, which is the momentum of top-level scalar `slot`
+// (slots 0..2), then the Metropolis word (slot 0's is used).
+template <int MODE, class T>
+ARP_DEV float radon_transition(const T& M, Rng& rng, int L, float kappa, const float* __restrict__ s_eps,
+                               float (&qg)[3], v2f (&qc)[T::NP], float (&gg_)[3], v2f (&gc)[T::NP], float& lp,
+                               bool& accepted, float* __restrict__ save) {
+  constexpr int K = T::K, NP = T::NP, NL = T::NL;
+  // step sizes: base steps from LDS (zero beyond D, so padding elements never move) times the chain's multiplier
+  float eg[3]; v2f ec[NP];
+  {
+    const float* e = s_eps + T::LBASE + M.slot;
+    const v2f vk = splat(kappa);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) ec[k] = v2f{e[K * 2 * k], e[K * (2 * k + 1)]} * vk;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) eg[i] = s_eps[i] * kappa;
+  }
+  // park the start state
+  {
+    v2f* s2 = reinterpret_cast<v2f*>(save);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { s2[k * kBlock] = qc[k]; s2[(NP + k) * kBlock] = gc[k]; }
+    float* s1 = save + 4 * NP * kBlock - threadIdx.x;   // float columns behind the pair columns
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { s1[i * kBlock] = qg[i]; s1[(3 + i) * kBlock] = gg_[i]; }
+  }
+  // momenta
+  float pg[3]; v2f pc[NP];
+  float extra;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
+    pc[k] = normal_pair2(w0, w1);
+  }
+  if (NL & 1) {
+    extra = pc[NP - 1][1];
+  } else {
+    const uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
+    extra = normal_pair2(w0, w1)[0];
+  }
+  pc[NP - 1] *= M.mlast;
+  float u = u01_open0(rng_next(rng));
+  u = group_bcast_from<K, 0>(u, M.slot);
+  pg[0] = group_bcast_from<K, 0>(extra, M.slot);
+  pg[1] = group_bcast_from<K, 1>(extra, M.slot);
+  pg[2] = group_bcast_from<K, 2>(extra, M.slot);
+  float ke0;
+  {
+    v2f a = splat(0.0f);
+    const v2f half = splat(0.5f);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      a = vfma(pc[k], pc[k], a);
+      // first half kick and first drift
+      pc[k] = vfma(half, ec[k] * gc[k], pc[k]);
+      qc[k] = vfma(ec[k], pc[k], qc[k]);
+    }
+    float kg = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      kg = fmaf(pg[i], pg[i], kg);
+      pg[i] = fmaf(0.5f * eg[i], gg_[i], pg[i]);
+      qg[i] = fmaf(eg[i], pg[i], qg[i]);
+    }
+    ke0 = 0.5f * (group_sum<K>(a[0] + a[1]) + kg);
+  }
+  float dlp, dke;
+  for (int l = 1; l < L; ++l) M.template pass<MODE, 0>(qg, qc, pg, pc, eg, ec, gg_, gc, dlp, dke);
+  float lp1, ke1;
+  M.template pass<MODE, 1>(qg, qc, pg, pc, eg, ec, gg_, gc, lp1, ke1);
+
+  // log accept ratio; any non-finite energy error rejects (TFP safe_sum semantics)
+  float la = (lp1 - lp) + (ke0 - ke1);
+  if (!(fabsf(la) <= 3.0e38f)) la = -INFINITY;
+  accepted = fast_log(u) < la;
+  if (!accepted) {
+    const v2f* s2 = reinterpret_cast<const v2f*>(save);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { qc[k] = s2[k * kBlock]; gc[k] = s2[(NP + k) * kBlock]; }
+    const float* s1 = save + 4 * NP * kBlock - threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { qg[i] = s1[i * kBlock]; gg_[i] = s1[(3 + i) * kBlock]; }
+  }
+  lp = accepted ? lp1 : lp;
+  return la;
+}
+
+// Shared prologue / epilogue pieces of the two kernels -------------------------------------------------
+
+template <class T>
+struct RadonBlock {
+  // LDS of one 256-thread workgroup
+  static constexpr int kSave = radon_save_floats<T>();
+  static constexpr int kStage = (kBlock / 64) * stage_floats<T>();
+};
+
+template <class T, int MODE>
+__global__ __launch_bounds__(kBlock, 2) void radon_hmc_kernel(RadonArgs A, HmcParams P) {
+  constexpr int K = T::K, NP = T::NP, ND = T::ND;
+  long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const int slot = (int)(t % K);
+  long long c = t / K;
+  const bool live = c < P.C;
+  if (!live) c = P.C - 1;  // shadow lanes compute on the last chain but never store
+  const int D = P.D;
+  T M;
+  M.init(A, slot);
+
+  __shared__ float s_eps[kMaxD];
+  __shared__ __attribute__((aligned(16))) float s_save[RadonBlock<T>::kSave];
+  __shared__ __attribute__((aligned(16))) float s_stage[RadonBlock<T>::kStage];
+  // pair columns are addressed as v2f[threadIdx.x], the float columns behind them as float[threadIdx.x]
+  float* save = s_save + 2 * threadIdx.x;
+  float* stage = s_stage + (threadIdx.x >> 6) * stage_floats<T>();
+  const long long cw0 = ((long long)blockIdx.x * kBlock + (threadIdx.x & ~63)) / K;
+  const int cl = (threadIdx.x & 63) / K;
+  const int nvalid = (int)(P.C - cw0 < 64 / K ? (P.C - cw0 > 0 ? P.C - cw0 : 0) : 64 / K) * D;
+  for (int d = threadIdx.x; d < kMaxD; d += kBlock) s_eps[d] = d < D ? P.eps0[d] : 0.0f;
+  __syncthreads();
+
+  float qg[3], gg_[3]; v2f qc[NP], gc[NP];
+  float lp;
+  {
+    float v[ND];
+    load_row(M, P.q + c * D, v);
+    T::unpack(v, qg, qc);
+    if (P.step_base == 0) {
+      float pg[3] = {0.f, 0.f, 0.f}, eg[3] = {0.f, 0.f, 0.f}; v2f pc[NP], ec[NP]; float ke;
+      M.template pass<MODE, 2>(qg, qc, pg, pc, eg, ec, gg_, gc, lp, ke);
+    } else {
+      load_row(M, P.grad + c * D, v);
+      T::unpack(v, gg_, gc);
+      lp = P.logp[c];
+    }
+  }
+  float kappa, esum, logavg;
+  Rng rng;
+  uint32_t* rs = P.rng + ((size_t)c * kRngSlots + slot) * 4;
+  if (P.step_base == 0) {
+    kappa = 1.0f; esum = 0.0f; logavg = 0.0f;
+    rng = rng_seed(P.seed, (unsigned long long)(P.chain_offset + c), (uint32_t)slot, (uint32_t)K);
+  } else {
+    kappa = P.adapt[c * 4 + 0]; esum = P.adapt[c * 4 + 1]; logavg = P.adapt[c * 4 + 2];
+    rng = Rng{rs[0], rs[1]};
+  }
+  uint32_t nacc = (P.step_base == 0) ? 0u : P.accept_count[c];
+
+  int next_rec = P.rec_step, rec_row = P.rec_row, bpos = P.stats_bpos;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing loaded is awaited inside the loop (kernels.h: hmc_kernel)
+  for (int s = 0; s < P.n_steps; ++s) {
+    bool acc;
+    const float la = radon_transition<MODE>(M, rng, P.L, kappa, s_eps, qg, qc, gg_, gc, lp, acc, save);
+    nacc += acc ? 1u : 0u;
+    const long long n = P.step_base + s + 1;
+    adapt_update(P, n, la, kappa, esum, logavg);
+
+    if (s == next_rec && rec_row < P.n_samples) {
+      const bool to_trace = P.trace && cw0 < P.trace_chains;
+      if (to_trace || P.stats) {
+        float x[ND];
+        if (P.trace_centered && MODE == kModeNCP) {
+          v2f xc[NP];
+          M.template to_centered<MODE>(qg, qc, xc);
+          T::pack(qg, xc, x);
+        } else {
+          T::pack(qg, qc, x);
+        }
+        if (to_trace) {
+          const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
+          store_row_wave(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, x);
+        }
+        if (P.stats) {
+          stats_update_wave(M, stage, P, cw0, cl, D, nvalid, x, rec_row == 0, bpos + 1 == P.stats_batch);
+          bpos = bpos + 1 == P.stats_batch ? 0 : bpos + 1;
+        }
+      }
+      if (live && slot == 0) {
+        if (P.trace_accept) P.trace_accept[(size_t)rec_row * P.C + c] = acc ? 1 : 0;
+        if (P.rec_accept) P.rec_accept[c] += acc ? 1u : 0u;
+      }
+      next_rec += P.thin;
+      rec_row += 1;
+    }
+  }
+
+  long long c2 = c;
+  asm volatile("" : "+v"(c2));
+  long long cw2 = cw0;
+  asm volatile("" : "+v"(cw2));
+  {
+    float v[ND];
+    T::pack(qg, qc, v);
+    store_row_wave(M, stage, P.q + cw2 * D, cl, D, nvalid, v);
+    T::pack(gg_, gc, v);
+    store_row_wave(M, stage, P.grad + cw2 * D, cl, D, nvalid, v);
+  }
+  if (live) {
+    uint32_t* rs2 = P.rng + ((size_t)c2 * kRngSlots + slot) * 4;
+    rs2[0] = rng.x; rs2[1] = rng.c; rs2[2] = 0u; rs2[3] = 0u;
+    if (slot == 0) {
+      P.logp[c2] = lp;
+      P.adapt[c2 * 4 + 0] = kappa; P.adapt[c2 * 4 + 1] = esum; P.adapt[c2 * 4 + 2] = logavg;
+      P.accept_count[c2] = nacc;
+    }
+  }
+}
+
+// Interleaved CP / NCP sampling (interleaved.Interleaved.one_step, interleaved.py:113-155): a centred transition,
+// the change of coordinates, a non-centred transition, the change back; each inner kernel keeps its own
+// step-size adaptation state (inference.py:288-306).  The gradient and log density are carried across the
+// shear instead of being recomputed (kernels.h: interleaved_kernel, CARRY), 2*num_ls gradient evaluations per step.
+template <class T>
+__global__ __launch_bounds__(kBlock, 2) void radon_interleaved_kernel(RadonArgs A, HmcParams P) {
+  constexpr int K = T::K, NP = T::NP, ND = T::ND;
+  long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const int slot = (int)(t % K);
+  long long c = t / K;
+  const bool live = c < P.C;
+  if (!live) c = P.C - 1;
+  const int D = P.D;
+  T M;
+  M.init(A, slot);
+
+  __shared__ float s_eps[2][kMaxD];
+  __shared__ __attribute__((aligned(16))) float s_save[RadonBlock<T>::kSave];
+  __shared__ __attribute__((aligned(16))) float s_stage[RadonBlock<T>::kStage];
+  float* save = s_save + 2 * threadIdx.x;
+  float* stage = s_stage + (threadIdx.x >> 6) * stage_floats<T>();
+  const long long cw0 = ((long long)blockIdx.x * kBlock + (threadIdx.x & ~63)) / K;
+  const int cl = (threadIdx.x & 63) / K;
+  const int nvalid = (int)(P.C - cw0 < 64 / K ? (P.C - cw0 > 0 ? P.C - cw0 : 0) : 64 / K) * D;
+  for (int d = threadIdx.x; d < kMaxD; d += kBlock) {
+    s_eps[0][d] = d < D ? P.eps0[d] : 0.0f;
+    s_eps[1][d] = d < D ? P.eps0_1[d] : 0.0f;
+  }
+  __syncthreads();
+
+  float qg[3], gg_[3]; v2f qc[NP], gc[NP];
+  float lp;
+  {
+    float v[ND];
+    load_row(M, P.q + c * D, v);
+    T::unpack(v, qg, qc);
+    if (P.step_base == 0 || !P.grad) {
+      float pg[3] = {0.f, 0.f, 0.f}, eg[3] = {0.f, 0.f, 0.f}; v2f pc[NP], ec[NP]; float ke;
+      M.template pass<kModeCP, 2>(qg, qc, pg, pc, eg, ec, gg_, gc, lp, ke);
+    } else {
+      load_row(M, P.grad + c * D, v);
+      T::unpack(v, gg_, gc);
+      lp = P.logp[c];
+    }
+  }
+  float kap[2], es[2], la_[2];
+  Rng rng;
+  uint32_t* rs = P.rng + ((size_t)c * kRngSlots + slot) * 4;
+  uint32_t nacc0, nacc1;
+  if (P.step_base == 0) {
+    kap[0] = kap[1] = 1.0f; es[0] = es[1] = 0.0f; la_[0] = la_[1] = 0.0f;
+    nacc0 = nacc1 = 0u;
+    rng = rng_seed(P.seed, (unsigned long long)(P.chain_offset + c), (uint32_t)slot, (uint32_t)K);
+  } else {
+    kap[0] = P.adapt[c * 4 + 0]; es[0] = P.adapt[c * 4 + 1]; la_[0] = P.adapt[c * 4 + 2];
+    kap[1] = P.adapt1[c * 4 + 0]; es[1] = P.adapt1[c * 4 + 1]; la_[1] = P.adapt1[c * 4 + 2];
+    nacc0 = P.accept_count[c]; nacc1 = P.accept_count1[c];
+    rng = Rng{rs[0], rs[1]};
+  }
+  int next_rec = P.rec_step, rec_row = P.rec_row, bpos = P.stats_bpos;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  for (int s = 0; s < P.n_steps; ++s) {
+    const long long n = P.step_base + s + 1;
+    bool acc0, acc1;
+    float la = radon_transition<kModeCP>(M, rng, P.L, kap[0], s_eps[0], qg, qc, gg_, gc, lp, acc0, save);
+    nacc0 += acc0 ? 1u : 0u;
+    adapt_update(P, n, la, kap[0], es[0], la_[0]);
+    M.template carry<kModeCP>(qg, qc, gg_, gc);
+    la = radon_transition<kModeNCP>(M, rng, P.L1, kap[1], s_eps[1], qg, qc, gg_, gc, lp, acc1, save);
+    nacc1 += acc1 ? 1u : 0u;
+    adapt_update(P, n, la, kap[1], es[1], la_[1]);
+    M.template carry<kModeNCP>(qg, qc, gg_, gc);
+
+    if (s == next_rec && rec_row < P.n_samples) {
+      // the state is back in centred coordinates, which are also the ones the reference records
+      const bool to_trace = P.trace && cw0 < P.trace_chains;
+      if (to_trace || P.stats) {
+        float x[ND];
+        T::pack(qg, qc, x);
+        if (to_trace) {
+          const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
+          store_row_wave(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, x);
+        }
+        if (P.stats) {
+          const bool bend = bpos + 1 == P.stats_batch;
+          stats_update_wave(M, stage, P, cw0, cl, D, nvalid, x, rec_row == 0, bend);
+          bpos = bend ? 0 : bpos + 1;
+        }
+      }
+      if (live && slot == 0) {
+        if (P.trace_accept) P.trace_accept[(size_t)rec_row * P.C + c] = acc0 ? 1 : 0;
+        if (P.trace_accept1) P.trace_accept1[(size_t)rec_row * P.C + c] = acc1 ? 1 : 0;
+        if (P.rec_accept) P.rec_accept[c] += acc0 ? 1u : 0u;
+        if (P.rec_accept1) P.rec_accept1[c] += acc1 ? 1u : 0u;
+      }
+      next_rec += P.thin;
+      rec_row += 1;
+    }
+  }
+
+  long long c2 = c;
+  asm volatile("" : "+v"(c2));
+  long long cw2 = cw0;
+  asm volatile("" : "+v"(cw2));
+  {
+    float v[ND];
+    T::pack(qg, qc, v);
+    store_row_wave(M, stage, P.q + cw2 * D, cl, D, nvalid, v);
+    if (P.grad) {
+      T::pack(gg_, gc, v);
+      store_row_wave(M, stage, P.grad + cw2 * D, cl, D, nvalid, v);
+    }
+  }
+  if (live) {
+    uint32_t* rs2 = P.rng + ((size_t)c2 * kRngSlots + slot) * 4;
+    rs2[0] = rng.x; rs2[1] = rng.c; rs2[2] = 0u; rs2[3] = 0u;
+    if (slot == 0) {
+      if (P.grad) P.logp[c2] = lp;
+      P.adapt[c2 * 4 + 0] = kap[0]; P.adapt[c2 * 4 + 1] = es[0]; P.adapt[c2 * 4 + 2] = la_[0];
+      P.adapt1[c2 * 4 + 0] = kap[1]; P.adapt1[c2 * 4 + 1] = es[1]; P.adapt1[c2 * 4 + 2] = la_[1];
+      P.accept_count[c2] = nacc0; P.accept_count1[c2] = nacc1;
+    }
+  }
+}
+
+}  // namespace arp

@@ -27,6 +27,9 @@ typedef struct orc_model {
   int n_groups;    /* sliced axis length (RNG stream layout) */
   int n_local_parts; /* latent parts sliced along that axis (german: beta_log_scales and beta) */
   int contig;      /* 1: slot s owns consecutive elements s*per_lane + i (german); 0: s + lanes*i */
+  int mom_spec;    /* momentum stream layout: 0 = top-level scalars first, drawn by every slot, slot 0's used;
+                    * 1 = sliced elements first, then ceil(n_glob / lanes) extra normals per slot of which extra x of
+                    * slot s is top-level scalar s + lanes*x (radon: no slot draws a normal it discards) */
   int glob_idx[16]; /* flattened index of each top-level scalar */
   int* group_idx;  /* [n_local_parts][n_groups] flattened index of element j, -1 if it has no latent */
   /* radon sufficient statistics */
@@ -127,7 +130,7 @@ orc_model* orc_radon_create(int N, int J, const int32_t* county, const float* u,
                             const float* y) {
   orc_model* M = (orc_model*)calloc(1, sizeof(orc_model));
   M->model = 1; M->J = J; M->D = 3 + J;
-  M->n_glob = 3; M->n_groups = J; M->n_local_parts = 1;
+  M->n_glob = 3; M->n_groups = J; M->n_local_parts = 1; M->mom_spec = 1;
   M->glob_idx[0] = 0; M->glob_idx[1] = 1; M->glob_idx[2] = 2;
   M->group_idx = (int*)malloc(sizeof(int) * J);
   M->n = (float*)calloc(J, sizeof(float)); M->sx = (float*)calloc(J, sizeof(float));

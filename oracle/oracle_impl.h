@@ -522,14 +522,19 @@ int FN(orc_transform)(const orc_model* M, const float* a, const float* b, int di
 
 /* ------------------------------------------------------------------------
  * Momentum and Metropolis draws of one transition for one chain.
- * Stream partition: slot s of `lanes` owns the replicated top-level scalars
+ * Stream partition (layout 0): slot s of `lanes` owns the replicated top-level scalars
  * (only slot 0's draw is used) followed, for each sliced latent part in trace
- * order, by its elements j = s + lanes*i.
+ * order, by its elements j = s + lanes*i.  Layout 1 (orc_model.mom_spec, radon): the
+ * slices come first and the top-level scalars are dealt out over the slots after them.
  * ---------------------------------------------------------------------- */
 static void FN(draw_momentum)(const orc_model* M, orc_rng* streams, int lanes, REAL* p, REAL* u_out) {
   const int NG = M->n_glob, G = M->n_groups, P = M->n_local_parts;
   const int per_lane = (G + lanes - 1) / lanes;
-  const int nd = NG + P * per_lane;   /* normals every slot draws: scalars, then part by part */
+  const int spec1 = M->mom_spec == 1;
+  const int extra = spec1 ? (NG + lanes - 1) / lanes : 0;
+  /* normals every slot draws.  layout 0: scalars, then part by part; layout 1: the slices, then `extra` scalars */
+  const int nd = spec1 ? P * per_lane + extra : NG + P * per_lane;
+  const int first_local = spec1 ? 0 : NG;
   for (int s = 0; s < lanes; ++s) {
     orc_rng* r = &streams[s];
     for (int i = 0; i < nd; i += 2) {
@@ -540,11 +545,14 @@ static void FN(draw_momentum)(const orc_model* M, orc_rng* streams, int lanes, R
         int ii = i + k;
         float z = k ? z1 : z0;
         if (ii >= nd) break;
-        if (ii < NG) {
+        if (!spec1 && ii < NG) {
           if (s == 0) p[M->glob_idx[ii]] = (REAL)z;
+        } else if (spec1 && ii >= P * per_lane) {
+          const int gk = s + lanes * (ii - P * per_lane);
+          if (gk < NG) p[M->glob_idx[gk]] = (REAL)z;
         } else {
-          int part = (ii - NG) / per_lane;
-          int j = M->contig ? s * per_lane + (ii - NG) % per_lane : s + lanes * ((ii - NG) % per_lane);
+          int part = (ii - first_local) / per_lane;
+          int j = M->contig ? s * per_lane + (ii - first_local) % per_lane : s + lanes * ((ii - first_local) % per_lane);
           if (j < G && M->group_idx[part * G + j] >= 0) p[M->group_idx[part * G + j]] = (REAL)z;
         }
       }
