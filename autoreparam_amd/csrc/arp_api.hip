@@ -103,6 +103,10 @@ static int build_radon(arp_model* m, const arp_dataset* d) {
   m->radon.u = m->dev_tables + 3 * J;
   m->radon.sxy = (float)sxy;
   m->radon.sxx = (float)sxx;
+  double sy_tot = 0, suy_tot = 0;
+  for (int j = 0; j < J; ++j) { sy_tot += sy[j]; suy_tot += (double)d->u_host[j] * sy[j]; }
+  m->radon.sy_tot = (float)sy_tot;
+  m->radon.suy_tot = (float)suy_tot;
   m->radon.J = J;
   // every Normal has unit scale under every (a,b): const = -(3+J+N) 0.5 log 2pi - 0.5 Syy
   m->const_base = -(3.0 + J + N) * kHalfLog2Pi - 0.5 * syy;

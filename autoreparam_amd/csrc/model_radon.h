@@ -23,6 +23,7 @@ struct RadonArgs {
   const float* sy;   // [J] sum of log radon
   const float* u;    // [J] log uranium
   float sxy, sxx;    // totals over all observations
+  float sy_tot, suy_tot;   // sum_j Sy_j, sum_j u_j Sy_j: gradient of the non-centred log joint at the origin (radon_fast.h)
   int J;
 };
 

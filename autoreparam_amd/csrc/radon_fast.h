@@ -48,13 +48,14 @@ struct RadonPk {
   static constexpr int NP = (NL_ + 1) / 2;          // county pairs (the last one half padding when NL is odd)
   static constexpr int DCAP = NG + K_ * NL_;
   static constexpr int LBASE = 3;
+  static_assert(NL_ >= 3, "at least two county pairs per lane");
   static_assert(K_ >= 4, "the packed radon kernels deal the three top-level momenta out over slots 0..2");
   using Args = RadonArgs;
 
   v2f n2[NP], sx2[NP], sy2[NP], u2[NP];
   v2f mlast;        // 1/0: which elements of the LAST pair are real counties
   float sxy, sxx;
-  float c_sy, c_suy;   // sum_j Sy_j, sum_j u_j Sy_j over the chain's counties (grad(0) of the NCP form)
+  float c_sy, c_suy;   // sum_j Sy_j, sum_j u_j Sy_j over all counties (grad(0) of the NCP form; wave-uniform)
   int slot;
   bool last_ok;
 
@@ -69,17 +70,14 @@ struct RadonPk {
     const int J = A.J;
     last_ok = slot + K * (NL - 1) < J;
     sxy = A.sxy; sxx = A.sxx;
-    float s0 = 0.0f, s1 = 0.0f;
+    c_sy = A.sy_tot; c_suy = A.suy_tot;
 #pragma unroll
     for (int i = 0; i < 2 * NP; ++i) {
       const int j = slot + K * i;
       const bool ok = i < NL && j < J;
       const float nj = ok ? A.n[j] : 0.0f, sxj = ok ? A.sx[j] : 0.0f, syj = ok ? A.sy[j] : 0.0f, uj = ok ? A.u[j] : 0.0f;
       n2[i >> 1][i & 1] = nj; sx2[i >> 1][i & 1] = sxj; sy2[i >> 1][i & 1] = syj; u2[i >> 1][i & 1] = uj;
-      s0 += syj; s1 = fmaf(uj, syj, s1);
     }
-    c_sy = group_sum<K>(s0);
-    c_suy = group_sum<K>(s1);
     if (NL & 1) mlast = v2f{last_ok ? 1.0f : 0.0f, 0.0f};
     else mlast = v2f{1.0f, last_ok ? 1.0f : 0.0f};
   }
@@ -108,7 +106,7 @@ struct RadonPk {
     const float mua = qg[0], b1 = qg[1], b2 = qg[2];
     const v2f vb1 = splat(b1), vnb2 = splat(-b2), vmua = splat(mua);
     const v2f vmua_last = vmua * mlast;     // padding: mu = 0 there (its u is 0), so r = m = 0
-    v2f ah[2] = {splat(0.0f), splat(0.0f)}, auh[2] = {splat(0.0f), splat(0.0f)}, ams[2] = {splat(0.0f), splat(0.0f)};
+    v2f ah[2], auh[2], ams[2];      // two accumulator sets (even / odd pairs), seeded by their first terms
     v2f alp = splat(0.0f), ake = splat(0.0f);
     const v2f half = splat(0.5f);
 #pragma unroll
@@ -121,19 +119,23 @@ struct RadonPk {
       const v2f l = vfma(-n2[k], m, t);
       const v2f gm = l - r;
       const v2f h = (MODE == kModeCP) ? r : l;
-      ah[k & 1] += h;
-      auh[k & 1] = vfma(u2[k], h, auh[k & 1]);
-      ams[k & 1] = vfma(m, sx2[k], ams[k & 1]);
+      if (k < 2) {
+        ah[k & 1] = h; auh[k & 1] = u2[k] * h; ams[k & 1] = m * sx2[k];
+      } else {
+        ah[k & 1] += h;
+        auh[k & 1] = vfma(u2[k], h, auh[k & 1]);
+        ams[k & 1] = vfma(m, sx2[k], ams[k & 1]);
+      }
       if (PASS == 0) {
         const v2f pn = vfma(ec[k], gm, pc[k]);
         pc[k] = pn;
         qc[k] = vfma(ec[k], pn, mt);
       } else {
         gc[k] = gm;
-        alp = vfma(mt, gm + sy2[k], alp);
+        alp = k == 0 ? mt * (gm + sy2[k]) : vfma(mt, gm + sy2[k], alp);
         if (PASS == 1) {
           const v2f pf = vfma(half, ec[k] * gm, pc[k]);
-          ake = vfma(pf, pf, ake);
+          ake = k == 0 ? pf * pf : vfma(pf, pf, ake);
         }
       }
     }
@@ -172,12 +174,11 @@ struct RadonPk {
   ARP_DEV void carry(float (&qg)[3], v2f (&qc)[NP], float (&gg_)[3], const v2f (&gc)[NP]) const {
     const v2f vb1 = splat(qg[1]), vmua = splat(qg[0]);
     const v2f vmua_last = vmua * mlast;
-    v2f s = splat(0.0f), su = splat(0.0f);
+    v2f s = gc[0], su = u2[0] * gc[0];             // gradients of padding elements are 0
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       const v2f mu = vfma(u2[k], vb1, k == NP - 1 ? vmua_last : vmua);
-      s += gc[k];                                  // gradients of padding elements are 0
-      su = vfma(u2[k], gc[k], su);
+      if (k > 0) { s += gc[k]; su = vfma(u2[k], gc[k], su); }
       qc[k] = (FROM == kModeCP) ? qc[k] - mu : qc[k] + mu;
     }
     const float ts = group_sum<K>(s[0] + s[1]), tsu = group_sum<K>(su[0] + su[1]);
@@ -249,11 +250,11 @@ ARP_DEV float radon_transition(const T& M, Rng& rng, int L, float kappa, const f
   pg[2] = group_bcast_from<K, 2>(extra, M.slot);
   float ke0;
   {
-    v2f a = splat(0.0f);
+    v2f a = pc[0] * pc[0];
     const v2f half = splat(0.5f);
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      a = vfma(pc[k], pc[k], a);
+      if (k > 0) a = vfma(pc[k], pc[k], a);
       // first half kick and first drift
       pc[k] = vfma(half, ec[k] * gc[k], pc[k]);
       qc[k] = vfma(ec[k], pc[k], qc[k]);
@@ -288,6 +289,66 @@ ARP_DEV float radon_transition(const T& M, Rng& rng, int L, float kappa, const f
   return la;
 }
 
+// the copy half of kernels.h: store_row_wave as a real call (cold path; keeps its address arithmetic out of the callers)
+__device__ __noinline__ void copy_stage_rows(const float* stage, float* gdst, int nvalid) {
+  const int lane = threadIdx.x & 63;
+  if ((reinterpret_cast<uintptr_t>(gdst) & 15) == 0) {
+    for (int k = lane * 4; k < nvalid; k += 256) {
+      const float4 t = *reinterpret_cast<const float4*>(stage + k);
+      if (k + 3 < nvalid) {
+        *reinterpret_cast<float4*>(gdst + k) = t;
+      } else {
+        gdst[k] = t.x;
+        if (k + 1 < nvalid) gdst[k + 1] = t.y;
+        if (k + 2 < nvalid) gdst[k + 2] = t.z;
+      }
+    }
+  } else {
+    for (int k = lane; k < nvalid; k += 64) gdst[k] = stage[k];
+  }
+}
+
+// A wave's rows (its 64/K consecutive chains) to a [C][D] array: store_row_wave of kernels.h with the state in pairs and,
+// when the wave is full and D is the instantiation's own dimension (the reference's PA: 68 = 4 x 17 counties), every
+// offset a compile-time constant -- the staging writes are ds_write2_b32 off one base, the copy is an unrolled run of
+// ds_read_b128 / global_store_dwordx4 off a wave-uniform base: no address arithmetic on the vector pipe.
+template <class T>
+ARP_DEV void radon_store_rows(const T& M, float* stage, float* gdst, int cl, int D, int nvalid,
+                              const float (&xg)[3], const v2f (&xc)[T::NP]) {
+  constexpr int K = T::K, NL = T::NL, DC = T::DCAP, NV = (64 / K) * DC;
+  if (D == DC && nvalid == NV && (NV & 3) == 0 && (reinterpret_cast<uintptr_t>(gdst) & 15) == 0) {
+    float* row = stage + cl * DC;
+    if (M.slot == 0) { row[0] = xg[0]; row[1] = xg[1]; row[2] = xg[2]; }
+    float* e = row + T::LBASE + M.slot;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) e[K * i] = xc[i >> 1][i & 1];      // D == DCAP: every slice is a real county
+    __builtin_amdgcn_wave_barrier();
+    // the lane's word index is formed afresh here: kept live across the sampling loop it would cost a register the
+    // chain kernels do not have
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    lane &= 63;
+    const float4* s4 = reinterpret_cast<const float4*>(stage);
+    float4* g4 = reinterpret_cast<float4*>(gdst);
+#pragma unroll
+    for (int it = 0; it < (NV / 4 + 63) / 64; ++it) {
+      const int k = lane + 64 * it;
+      if ((it + 1) * 64 <= NV / 4 || k < NV / 4) g4[k] = s4[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+  } else {   // ragged tail of the launch, or a county count that leaves padding: general offsets, out-of-line copy
+    float* row = stage + cl * D;
+    if (M.slot == 0) { row[0] = xg[0]; row[1] = xg[1]; row[2] = xg[2]; }
+    float* e = row + T::LBASE + M.slot;
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (M.lvalid(i)) e[K * i] = xc[i >> 1][i & 1];
+    __builtin_amdgcn_wave_barrier();
+    copy_stage_rows(stage, gdst, nvalid);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // Shared prologue / epilogue pieces of the two kernels -------------------------------------------------
 
 template <class T>
@@ -300,9 +361,10 @@ struct RadonBlock {
 template <class T, int MODE>
 __global__ __launch_bounds__(kBlock, 2) void radon_hmc_kernel(RadonArgs A, HmcParams P) {
   constexpr int K = T::K, NP = T::NP, ND = T::ND;
-  long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+  // chain of this lane (a launch holds fewer than 2^31 / K chains: 32-bit lane arithmetic)
+  const unsigned t = blockIdx.x * (unsigned)kBlock + threadIdx.x;
   const int slot = (int)(t % K);
-  long long c = t / K;
+  int c = (int)(t / K);
   const bool live = c < P.C;
   if (!live) c = P.C - 1;  // shadow lanes compute on the last chain but never store
   const int D = P.D;
@@ -314,8 +376,9 @@ __global__ __launch_bounds__(kBlock, 2) void radon_hmc_kernel(RadonArgs A, HmcPa
   __shared__ __attribute__((aligned(16))) float s_stage[RadonBlock<T>::kStage];
   // pair columns are addressed as v2f[threadIdx.x], the float columns behind them as float[threadIdx.x]
   float* save = s_save + 2 * threadIdx.x;
-  float* stage = s_stage + (threadIdx.x >> 6) * stage_floats<T>();
-  const long long cw0 = ((long long)blockIdx.x * kBlock + (threadIdx.x & ~63)) / K;
+  float* stage = s_stage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * stage_floats<T>();
+  // first chain of this wave: wave-uniform, kept in SGPRs so that row addresses are scalar arithmetic
+  const long long cw0 = (long long)((blockIdx.x * (unsigned)kBlock + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x & ~63)) / K);
   const int cl = (threadIdx.x & 63) / K;
   const int nvalid = (int)(P.C - cw0 < 64 / K ? (P.C - cw0 > 0 ? P.C - cw0 : 0) : 64 / K) * D;
   for (int d = threadIdx.x; d < kMaxD; d += kBlock) s_eps[d] = d < D ? P.eps0[d] : 0.0f;
@@ -325,13 +388,13 @@ __global__ __launch_bounds__(kBlock, 2) void radon_hmc_kernel(RadonArgs A, HmcPa
   float lp;
   {
     float v[ND];
-    load_row(M, P.q + c * D, v);
+    load_row(M, P.q + (size_t)c * D, v);
     T::unpack(v, qg, qc);
     if (P.step_base == 0) {
       float pg[3] = {0.f, 0.f, 0.f}, eg[3] = {0.f, 0.f, 0.f}; v2f pc[NP], ec[NP]; float ke;
       M.template pass<MODE, 2>(qg, qc, pg, pc, eg, ec, gg_, gc, lp, ke);
     } else {
-      load_row(M, P.grad + c * D, v);
+      load_row(M, P.grad + (size_t)c * D, v);
       T::unpack(v, gg_, gc);
       lp = P.logp[c];
     }
@@ -343,7 +406,7 @@ __global__ __launch_bounds__(kBlock, 2) void radon_hmc_kernel(RadonArgs A, HmcPa
     kappa = 1.0f; esum = 0.0f; logavg = 0.0f;
     rng = rng_seed(P.seed, (unsigned long long)(P.chain_offset + c), (uint32_t)slot, (uint32_t)K);
   } else {
-    kappa = P.adapt[c * 4 + 0]; esum = P.adapt[c * 4 + 1]; logavg = P.adapt[c * 4 + 2];
+    kappa = P.adapt[(size_t)c * 4 + 0]; esum = P.adapt[(size_t)c * 4 + 1]; logavg = P.adapt[(size_t)c * 4 + 2];
     rng = Rng{rs[0], rs[1]};
   }
   uint32_t nacc = (P.step_base == 0) ? 0u : P.accept_count[c];
@@ -360,43 +423,37 @@ __global__ __launch_bounds__(kBlock, 2) void radon_hmc_kernel(RadonArgs A, HmcPa
     if (s == next_rec && rec_row < P.n_samples) {
       const bool to_trace = P.trace && cw0 < P.trace_chains;
       if (to_trace || P.stats) {
-        float x[ND];
-        if (P.trace_centered && MODE == kModeNCP) {
-          v2f xc[NP];
-          M.template to_centered<MODE>(qg, qc, xc);
-          T::pack(qg, xc, x);
-        } else {
-          T::pack(qg, qc, x);
-        }
+        v2f xc[NP];
+        if (P.trace_centered) M.template to_centered<MODE>(qg, qc, xc);
+        else M.template to_centered<kModeCP>(qg, qc, xc);   // the state as it is
         if (to_trace) {
           const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
-          store_row_wave(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, x);
+          radon_store_rows(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, qg, xc);
         }
         if (P.stats) {
+          float x[ND];
+          T::pack(qg, xc, x);
           stats_update_wave(M, stage, P, cw0, cl, D, nvalid, x, rec_row == 0, bpos + 1 == P.stats_batch);
           bpos = bpos + 1 == P.stats_batch ? 0 : bpos + 1;
         }
       }
       if (live && slot == 0) {
-        if (P.trace_accept) P.trace_accept[(size_t)rec_row * P.C + c] = acc ? 1 : 0;
-        if (P.rec_accept) P.rec_accept[c] += acc ? 1u : 0u;
+        // 32-bit lane offsets off wave-uniform bases, formed here: no per-lane pointer stays live across the sampling loop
+        unsigned ci = (unsigned)c;
+        asm volatile("" : "+v"(ci));
+        if (P.trace_accept) (P.trace_accept + (size_t)rec_row * P.C)[ci] = acc ? 1 : 0;
+        if (P.rec_accept) P.rec_accept[ci] += acc ? 1u : 0u;
       }
       next_rec += P.thin;
       rec_row += 1;
     }
   }
 
-  long long c2 = c;
+  size_t c2 = (size_t)c;
   asm volatile("" : "+v"(c2));
-  long long cw2 = cw0;
-  asm volatile("" : "+v"(cw2));
-  {
-    float v[ND];
-    T::pack(qg, qc, v);
-    store_row_wave(M, stage, P.q + cw2 * D, cl, D, nvalid, v);
-    T::pack(gg_, gc, v);
-    store_row_wave(M, stage, P.grad + cw2 * D, cl, D, nvalid, v);
-  }
+  const long long cw2 = cw0;
+  radon_store_rows(M, stage, P.q + cw2 * D, cl, D, nvalid, qg, qc);
+  radon_store_rows(M, stage, P.grad + cw2 * D, cl, D, nvalid, gg_, gc);
   if (live) {
     uint32_t* rs2 = P.rng + ((size_t)c2 * kRngSlots + slot) * 4;
     rs2[0] = rng.x; rs2[1] = rng.c; rs2[2] = 0u; rs2[3] = 0u;
@@ -415,9 +472,9 @@ __global__ __launch_bounds__(kBlock, 2) void radon_hmc_kernel(RadonArgs A, HmcPa
 template <class T>
 __global__ __launch_bounds__(kBlock, 2) void radon_interleaved_kernel(RadonArgs A, HmcParams P) {
   constexpr int K = T::K, NP = T::NP, ND = T::ND;
-  long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const unsigned t = blockIdx.x * (unsigned)kBlock + threadIdx.x;
   const int slot = (int)(t % K);
-  long long c = t / K;
+  int c = (int)(t / K);
   const bool live = c < P.C;
   if (!live) c = P.C - 1;
   const int D = P.D;
@@ -428,8 +485,9 @@ __global__ __launch_bounds__(kBlock, 2) void radon_interleaved_kernel(RadonArgs 
   __shared__ __attribute__((aligned(16))) float s_save[RadonBlock<T>::kSave];
   __shared__ __attribute__((aligned(16))) float s_stage[RadonBlock<T>::kStage];
   float* save = s_save + 2 * threadIdx.x;
-  float* stage = s_stage + (threadIdx.x >> 6) * stage_floats<T>();
-  const long long cw0 = ((long long)blockIdx.x * kBlock + (threadIdx.x & ~63)) / K;
+  float* stage = s_stage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * stage_floats<T>();
+  // first chain of this wave: wave-uniform, kept in SGPRs so that row addresses are scalar arithmetic
+  const long long cw0 = (long long)((blockIdx.x * (unsigned)kBlock + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x & ~63)) / K);
   const int cl = (threadIdx.x & 63) / K;
   const int nvalid = (int)(P.C - cw0 < 64 / K ? (P.C - cw0 > 0 ? P.C - cw0 : 0) : 64 / K) * D;
   for (int d = threadIdx.x; d < kMaxD; d += kBlock) {
@@ -442,13 +500,13 @@ __global__ __launch_bounds__(kBlock, 2) void radon_interleaved_kernel(RadonArgs 
   float lp;
   {
     float v[ND];
-    load_row(M, P.q + c * D, v);
+    load_row(M, P.q + (size_t)c * D, v);
     T::unpack(v, qg, qc);
     if (P.step_base == 0 || !P.grad) {
       float pg[3] = {0.f, 0.f, 0.f}, eg[3] = {0.f, 0.f, 0.f}; v2f pc[NP], ec[NP]; float ke;
       M.template pass<kModeCP, 2>(qg, qc, pg, pc, eg, ec, gg_, gc, lp, ke);
     } else {
-      load_row(M, P.grad + c * D, v);
+      load_row(M, P.grad + (size_t)c * D, v);
       T::unpack(v, gg_, gc);
       lp = P.logp[c];
     }
@@ -462,8 +520,8 @@ __global__ __launch_bounds__(kBlock, 2) void radon_interleaved_kernel(RadonArgs 
     nacc0 = nacc1 = 0u;
     rng = rng_seed(P.seed, (unsigned long long)(P.chain_offset + c), (uint32_t)slot, (uint32_t)K);
   } else {
-    kap[0] = P.adapt[c * 4 + 0]; es[0] = P.adapt[c * 4 + 1]; la_[0] = P.adapt[c * 4 + 2];
-    kap[1] = P.adapt1[c * 4 + 0]; es[1] = P.adapt1[c * 4 + 1]; la_[1] = P.adapt1[c * 4 + 2];
+    kap[0] = P.adapt[(size_t)c * 4 + 0]; es[0] = P.adapt[(size_t)c * 4 + 1]; la_[0] = P.adapt[(size_t)c * 4 + 2];
+    kap[1] = P.adapt1[(size_t)c * 4 + 0]; es[1] = P.adapt1[(size_t)c * 4 + 1]; la_[1] = P.adapt1[(size_t)c * 4 + 2];
     nacc0 = P.accept_count[c]; nacc1 = P.accept_count1[c];
     rng = Rng{rs[0], rs[1]};
   }
@@ -484,43 +542,35 @@ __global__ __launch_bounds__(kBlock, 2) void radon_interleaved_kernel(RadonArgs 
     if (s == next_rec && rec_row < P.n_samples) {
       // the state is back in centred coordinates, which are also the ones the reference records
       const bool to_trace = P.trace && cw0 < P.trace_chains;
-      if (to_trace || P.stats) {
+      if (to_trace) {
+        const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
+        radon_store_rows(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, qg, qc);
+      }
+      if (P.stats) {
         float x[ND];
         T::pack(qg, qc, x);
-        if (to_trace) {
-          const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
-          store_row_wave(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, x);
-        }
-        if (P.stats) {
-          const bool bend = bpos + 1 == P.stats_batch;
-          stats_update_wave(M, stage, P, cw0, cl, D, nvalid, x, rec_row == 0, bend);
-          bpos = bend ? 0 : bpos + 1;
-        }
+        const bool bend = bpos + 1 == P.stats_batch;
+        stats_update_wave(M, stage, P, cw0, cl, D, nvalid, x, rec_row == 0, bend);
+        bpos = bend ? 0 : bpos + 1;
       }
       if (live && slot == 0) {
-        if (P.trace_accept) P.trace_accept[(size_t)rec_row * P.C + c] = acc0 ? 1 : 0;
-        if (P.trace_accept1) P.trace_accept1[(size_t)rec_row * P.C + c] = acc1 ? 1 : 0;
-        if (P.rec_accept) P.rec_accept[c] += acc0 ? 1u : 0u;
-        if (P.rec_accept1) P.rec_accept1[c] += acc1 ? 1u : 0u;
+        unsigned ci = (unsigned)c;
+        asm volatile("" : "+v"(ci));
+        if (P.trace_accept) (P.trace_accept + (size_t)rec_row * P.C)[ci] = acc0 ? 1 : 0;
+        if (P.trace_accept1) (P.trace_accept1 + (size_t)rec_row * P.C)[ci] = acc1 ? 1 : 0;
+        if (P.rec_accept) P.rec_accept[ci] += acc0 ? 1u : 0u;
+        if (P.rec_accept1) P.rec_accept1[ci] += acc1 ? 1u : 0u;
       }
       next_rec += P.thin;
       rec_row += 1;
     }
   }
 
-  long long c2 = c;
+  size_t c2 = (size_t)c;
   asm volatile("" : "+v"(c2));
-  long long cw2 = cw0;
-  asm volatile("" : "+v"(cw2));
-  {
-    float v[ND];
-    T::pack(qg, qc, v);
-    store_row_wave(M, stage, P.q + cw2 * D, cl, D, nvalid, v);
-    if (P.grad) {
-      T::pack(gg_, gc, v);
-      store_row_wave(M, stage, P.grad + cw2 * D, cl, D, nvalid, v);
-    }
-  }
+  const long long cw2 = cw0;
+  radon_store_rows(M, stage, P.q + cw2 * D, cl, D, nvalid, qg, qc);
+  if (P.grad) radon_store_rows(M, stage, P.grad + cw2 * D, cl, D, nvalid, gg_, gc);
   if (live) {
     uint32_t* rs2 = P.rng + ((size_t)c2 * kRngSlots + slot) * 4;
     rs2[0] = rng.x; rs2[1] = rng.c; rs2[2] = 0u; rs2[3] = 0u;

@@ -52,6 +52,7 @@ class Engine(object):
         self.D = self._L.arp_model_dim(self._h)
         assert self.D == spec.D, (self.D, spec.D)
         self._ab = [None, None]
+        self._cache = {}
 
     def __del__(self):
         try:
@@ -76,6 +77,16 @@ class Engine(object):
 
     def logp_const(self, which=0):
         return self._L.arp_model_logp_const(self._h, which)
+
+    def _dev_cached(self, key, x):
+        """Device copy of a small host array that is re-used while its contents do not change (the base step
+        sizes of consecutive launches): no host-to-device copy, and no host synchronisation, per launch."""
+        a = np.ascontiguousarray(x, np.float32)
+        hit = self._cache.get(key)
+        if hit is None or hit[0].shape != a.shape or not np.array_equal(hit[0], a):
+            hit = (a.copy(), self._dev(a))
+            self._cache[key] = hit
+        return hit[1]
 
     # -- density / converters --------------------------------------------
     def _dev(self, x):
@@ -133,7 +144,7 @@ class Engine(object):
         io = _lib.HmcIO()
         io.q, io.grad, io.logp = _ptr(state.q), _ptr(state.grad), _ptr(state.logp)
         io.adapt, io.rng, io.accept_count = _ptr(state.adapt), _ptr(state.rng), _ptr(state.accept_count)
-        self._eps0 = self._dev(eps0)
+        self._eps0 = eps0 if torch.is_tensor(eps0) else self._dev_cached("eps0", eps0)
         io.eps0 = _ptr(self._eps0)
         io.trace, io.trace_accept, io.stats = _ptr(trace), _ptr(trace_accept), _ptr(stats)
         io.rec_accept_count = _ptr(rec_accept)
@@ -173,8 +184,8 @@ class Engine(object):
         io.k0.q = _ptr(state.q)
         io.k0.grad, io.k0.logp = _ptr(state.grad), _ptr(state.logp)   # carried gradient / log density
         io.k0.adapt, io.k0.rng, io.k0.accept_count = _ptr(state.adapt), _ptr(state.rng), _ptr(state.accept_count)
-        self._eps0 = self._dev(eps0_0)
-        self._eps1 = self._dev(eps0_1)
+        self._eps0 = eps0_0 if torch.is_tensor(eps0_0) else self._dev_cached("eps0", eps0_0)
+        self._eps1 = eps0_1 if torch.is_tensor(eps0_1) else self._dev_cached("eps1", eps0_1)
         io.k0.eps0 = _ptr(self._eps0)
         io.k0.trace, io.k0.trace_accept = _ptr(trace), _ptr(trace_accept0)
         io.k0.stats, io.k0.rec_accept_count, io.rec_accept_count1 = _ptr(stats), _ptr(rec_accept0), _ptr(rec_accept1)
