@@ -1,28 +1,36 @@
 #!/usr/bin/env python3
-"""Headline benchmark: leapfrog-steps/sec over all chains, radon(PA), 65 536 chains
-per GPU (BASELINE.json metric; workload = configs[3]: radon --dataset=PA --method=i,
-interleaved CP/NCP, 4 + 4 = "8 leapfrog steps" per step, main.py:493), on the fused
-HIP kernels.
+"""Headline benchmark: leapfrog-steps/sec over all chains (+ ESS/sec), radon(PA), 65 536 chains
+per GPU (BASELINE.json metric; workload = configs[3]: radon --dataset=PA --method=i, interleaved
+CP/NCP, 4 + 4 = "8 leapfrog steps" per step, main.py:493), on the fused HIP kernels.
 
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one launch of the hot path over the whole chain batch: `--transitions`
-sampler steps for every chain on the rank.  With --method i (default) a sampler
-step is one interleaved step: bootstrap + num_ls leapfrogs in CP coordinates,
-to_ncp, bootstrap + num_ls leapfrogs in NCP coordinates, to_cp, two Metropolis
-tests, two simple step-size adaptations (counted as 2*num_ls leapfrog steps, the
-two bootstrap gradient evaluations are extra work that is not counted).  With
---method CP it is one plain HMC transition of `--leapfrog` steps with dual averaging.  Chains are independent, so ranks shard
-them with no data-path collective (weak scaling: the per-GPU batch is fixed); one
-RCCL all-gather of the acceptance statistics runs after the timed region.
+A "step" is one launch of the hot path over the rank's whole chain batch: `--transitions`
+(default 256) sampler steps for every chain.  A sampler step (--method i) is one interleaved step:
+num_ls leapfrogs in CP coordinates, to_ncp, num_ls leapfrogs in NCP coordinates, to_cp, two
+Metropolis tests, two simple step-size adaptations (counted as 2*num_ls leapfrog steps; the
+reference's two bootstrap gradient evaluations per step are not needed -- the kernel carries the
+gradient across the change of coordinates -- and are not counted).  A CP trace row is written
+every `--thin`-th step (default 2 = the reference's sample_chain(num_steps_between_results=1),
+inference.py:228-236); `trace_every_step` re-times round 1's harsher variant (a row every step,
+32 steps per launch).  Chains are independent, so ranks shard them with no data-path collective
+(`--scaling weak`: the per-GPU batch is fixed; `--scaling strong`: `--chains` is the job total and
+is split over the ranks, BASELINE configs[3] read literally); one RCCL all-gather of the per-chain
+statistics runs after the timed region.
 
-Prints ONE JSON line (see DESIGN.md "Measurement" for the roofline definition).
+Prints ONE JSON line.  `roofline` prices the dominant kernel against the resource that binds it,
+FP32 vector issue: achieved = SURVEY 8(d) algorithmic flops / kernel time
+from HIP events of this run.  The HBM side is reported next to it (`hbm_algorithmic_GBps` is the
+SURVEY 8(d) byte model, which the fused kernel does not perform; `traffic` is measured FETCH_SIZE +
+WRITE_SIZE of a profiled pass of the SAME configuration, copied from profiles/ with its source).
 """
 import argparse
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -31,10 +39,31 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+FP32_PEAK_TFLOPS = 157.3      # MI355X vector FP32 (guides/MI355X_MICROARCH.md); the f32 MFMA peak is the same
+HBM_PEAK_GBPS = 8000.0
+
 
 def algorithmic_bytes_per_transition(D, trace=True):
     # read q, grad, logp, 3 adaptation scalars; write the same + accept byte (+ trace row)
     return 4 * ((5 if trace else 4) * D + 8) + 1
+
+
+def radon_flop_per_leapfrog(J, D):
+    # ~30 J + 20 per logp+grad, 4 D for the leapfrog update
+    return 30.0 * J + 20.0 + 4.0 * D
+
+
+def _time_launches(fn, n, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
 
 
 def cpu_baseline(spec, L, n_chains, n_trans, eps0, lanes, inter):
@@ -112,24 +141,90 @@ def cpu_baseline_reference_shaped(spec, L, n_chains=1024, budget_s=6.0):
                                                                           N, J, dt)}
 
 
+def reference_flow_ess(dataset, chains, dev_index, samples=1000, burnin=1000, adapt=600, tune_chains=4096):
+    """ESS/sec from the reference's own flow (main.py:190-231, 292-336, 452-528) on the engine's CLI: mean-field VI
+    under CP and NCP -> HMCtuning sweeps (leapfrog counts 2, 4, 8) -> --inference=HMC --method=i at the headline
+    chain count with the reference's thinning; ESS = tfp-style autocorrelation ESS of every centred element
+    (arp_ess on the device trace), per chain the minimum over elements (util.get_min_ess)."""
+    from autoreparam_amd import main as cli
+    from autoreparam_amd.flags import FLAGS
+    tmp = tempfile.mkdtemp(prefix="arp_bench_")
+    try:
+        base = ["--model=radon", "--dataset=%s" % dataset, "--results_dir=%s" % tmp, "--seed=1",
+                "--device=cuda:%d" % dev_index]
+        t0 = time.perf_counter()
+        for m in ("CP", "NCP"):
+            cli.main(base + ["--inference=VI", "--method=%s" % m], flags=FLAGS.copy())
+        t_vi = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for m in ("CP", "NCP"):
+            for L in (2, 4, 8):
+                cli.main(base + ["--inference=HMCtuning", "--method=%s" % m, "--num_leapfrog_steps=%d" % L,
+                                 "--num_chains=%d" % tune_chains, "--num_samples=300", "--num_burnin_steps=300",
+                                 "--num_adaptation_steps=200"], flags=FLAGS.copy())
+        t_tune = time.perf_counter() - t0
+        fl = FLAGS.copy()
+        res = cli.main(base + ["--inference=HMC", "--method=i", "--num_chains=%d" % chains,
+                               "--num_samples=%d" % samples, "--num_burnin_steps=%d" % burnin,
+                               "--num_adaptation_steps=%d" % adapt], flags=fl)
+        ess_norm, sem_norm, acc_cp, acc_ncp, mcmc_time = res[0], res[1], res[2], res[3], res[4]
+        with open(os.path.join(tmp, "i_tied.json")) as f:
+            saved = json.load(f)
+        num_ls = int(saved["num_leapfrog_steps"][-1])
+        LL = 2 * num_ls
+        ess = float(ess_norm) * samples * LL / 1000.0      # undo main.py:362-366's "per 1000 gradients"
+        total_steps = 1 + burnin + 2 * (samples - 1)
+        return {"flow": "VI(CP), VI(NCP) -> HMCtuning L in {2,4,8} x {CP,NCP} (%d chains) -> HMC --method=i" % tune_chains,
+                "chains": chains, "num_samples": samples, "num_burnin_steps": burnin, "num_adaptation_steps": adapt,
+                "thinning": 2, "num_ls_chosen": num_ls, "mean_min_ess_per_chain": ess,
+                "ess_min_per_1000_gradients": float(ess_norm), "sem_min_per_1000_gradients": float(sem_norm),
+                "acceptance_rate_cp": float(acc_cp), "acceptance_rate_ncp": float(acc_ncp),
+                "mcmc_time_sec": float(mcmc_time), "vi_time_sec": t_vi, "tuning_time_sec": t_tune,
+                "ess_per_sec": ess / float(mcmc_time),
+                "ess_per_sec_all_chains": ess * chains / float(mcmc_time),
+                "leapfrog_steps_per_s_end_to_end": chains * total_steps * LL / float(mcmc_time),
+                "note": "mcmc_time_sec is main.py's wall clock around sampling + ESS of BOTH candidate leapfrog counts' "
+                        "last run (the kept one): sampling, arp_ess over the [S, C, D] device trace, host summaries"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def load_profile(tag_cfg):
+    """profiles/r02_headline.json (tools/summarize_profile.py) if it was taken on this configuration."""
+    p = os.path.join(ROOT, "profiles", "r02_headline.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        prof = json.load(open(p))
+    except Exception:
+        return None
+    same = all(prof.get("config", {}).get(k) == v for k, v in tag_cfg.items())
+    prof["config_matches_this_run"] = bool(same)
+    prof["source"] = "profiles/r02_headline.json"
+    return prof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
+    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU (weak) / in total (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--method", default="i", choices=["i", "CP"])
     ap.add_argument("--leapfrog", type=int, default=8, help="leapfrog steps per sampler step (i: split CP/NCP)")
-    ap.add_argument("--transitions", type=int, default=32, help="HMC transitions per launch (= per step)")
+    ap.add_argument("--transitions", type=int, default=256, help="sampler steps per launch (= per bench step)")
+    ap.add_argument("--thin", type=int, default=2, help="a trace row every THIN-th sampler step (reference: 2)")
     ap.add_argument("--dataset", default="PA")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
-                    help="skip the secondary figures (plain_hmc, german_credit, ess): profiler runs, so that every "
-                         "launch of the headline kernel in the trace is a timed or warm-up step")
+                    help="skip the secondary figures: profiler runs, so that every launch of the headline kernel in "
+                         "the trace is a timed or warm-up step")
+    ap.add_argument("--no-ess", action="store_true", help="skip the reference-flow ESS/sec run")
     ap.add_argument("--no-trace", action="store_true", help="diagnostic: do not record trace rows")
     ap.add_argument("--stats", action="store_true", help="diagnostic: accumulate the in-kernel streaming statistics "
-                                                         "(arp_hmc_io.stats) every step instead of writing trace rows")
+                                                         "(arp_hmc_io.stats) instead of writing trace rows")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,47 +243,57 @@ def main():
         except TypeError:                                     # older torch: no device_id keyword
             dist.init_process_group("nccl")
 
-    from autoreparam_amd import models, engine, _lib
+    from autoreparam_amd import models, engine, _lib, parallel, util
     spec = models._spec_radon(args.dataset)
     eng = engine.Engine(spec, dev)
     eng.set_param(0, "CP")
     eng.set_param(1, "NCP")
-    C, L, T, D = args.chains, args.leapfrog, args.transitions, spec.D
+    L, T, D = args.leapfrog, args.transitions, spec.D
+    J = D - 3
+    if args.scaling == "strong":
+        lo, hi = parallel.shard_bounds(args.chains, rank, world)
+        C, chain_offset, C_total = hi - lo, lo, args.chains
+    else:
+        C, chain_offset, C_total = args.chains, rank * args.chains, world * args.chains
     inter = args.method == "i"
     num_ls = L // 2
+    thin = max(1, args.thin)
 
     # synthetic chain population: i.i.d. draws keyed by the global chain id
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     q0 = (0.1 * torch.randn(C, D, generator=g)).to(dev)
     eps0 = np.full(D, 0.08 / (L / 4.0) ** 2, np.float32)
     eps0[2] = 0.02 / (L / 4.0) ** 2
-    st = engine.ChainState(q0)
-    S = args.steps * T  # every timed transition appends a trace row
-    trace = torch.empty(min(S, 64), C, D, dtype=torch.float32, device=dev)  # ring of rows that gets overwritten
-
     eps_i = np.full(D, 0.08 / (max(num_ls, 1) / 4.0) ** 2, np.float32)   # interleaved: eps0/(num_ls/4)^2
     eps_i[2] = 0.02 / (max(num_ls, 1) / 4.0) ** 2
 
-    stats = torch.zeros(6, C, D, dtype=torch.float32, device=dev) if args.stats else None
-    skw = dict(stats=stats, stats_batch=8, n_samples=1 << 30) if args.stats else {}
+    def make_launcher(Tn, thin_n, chains=None, record=True, plain=False, stats=False, lanes=args.lanes):
+        """A closure that advances a fresh population by Tn sampler steps per call, with its own trace ring."""
+        qq = q0 if chains is None else q0[:chains]
+        Cn = qq.shape[0]
+        st = engine.ChainState(qq)
+        rows = (Tn + thin_n - 1) // thin_n
+        trace = torch.empty(rows, Cn, D, dtype=torch.float32, device=dev) if (record and not stats) else None
+        stats_t = torch.zeros(6, Cn, D, dtype=torch.float32, device=dev) if stats else None
+        skw = dict(stats=stats_t, stats_batch=8, n_samples=1 << 30) if stats else {}
 
-    def launch(record, plain=False):
-        # trace rows cycle through a bounded buffer so a long bench does not need S*C*D floats
-        if args.stats and not plain:
-            record = False
-        if inter and not plain:
-            eng.interleaved_run(st, eps_i, eps_i, num_ls, num_ls, T, seed=7, chain_offset=rank * C,
-                                adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=10 ** 9, adapt_target=0.75, adapt_rate=0.05,
-                                n_burnin=st.step if not args.stats else 0, thin=1, trace=trace[:T] if record else None,
-                                trace_centered=False, lanes=args.lanes, **skw)
-        else:
-            eng.hmc_run(st, eps0, L, T, seed=7, chain_offset=rank * C, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9,
-                        n_burnin=st.step, thin=1, trace=trace[:T] if record else None, trace_centered=True,
-                        lanes=args.lanes)
+        def launch():
+            # rows cycle through a bounded buffer (n_burnin = steps done: row 0 is this launch's first sample)
+            if inter and not plain:
+                eng.interleaved_run(st, eps_i, eps_i, num_ls, num_ls, Tn, seed=7, chain_offset=chain_offset,
+                                    adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=10 ** 9, adapt_target=0.75, adapt_rate=0.05,
+                                    n_burnin=st.step if not stats else 0, thin=thin_n, trace=trace,
+                                    trace_centered=False, lanes=lanes, **skw)
+            else:
+                eng.hmc_run(st, eps0, L, Tn, seed=7, chain_offset=chain_offset, adapt_kind=_lib.ADAPT_DUAL,
+                            n_adapt=10 ** 9, n_burnin=st.step if not stats else 0, thin=thin_n, trace=trace,
+                            trace_centered=True, lanes=lanes, **skw)
+        return launch, st
 
     rec = not args.no_trace
+    launch, st = make_launcher(T, thin, record=rec, stats=args.stats)
     for _ in range(args.warmup):
-        launch(rec)
+        launch()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -197,7 +302,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        launch(rec)
+        launch()
         ev[k][1].record()
     torch.cuda.synchronize()
     if dist is not None:
@@ -206,7 +311,9 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    # end-of-run statistics exchange (the only collective of the path)
+    # end-of-run statistics exchange (the only collectives of the path, parallel.py): all-gather of a per-chain
+    # statistic (here the acceptance rate; a sampling run gathers the per-chain minimum ESS the same way) and the
+    # all-reduce of the acceptance counts
     acc = st.accept_count.float() / st.step
     t_coll = 0.0
     if dist is not None:
@@ -214,35 +321,52 @@ def main():
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         elapsed = float(tm.item())
         torch.cuda.synchronize(); tc = time.perf_counter()
-        gathered = [torch.empty_like(acc) for _ in range(world)]
-        dist.all_gather(gathered, acc)
-        acc = torch.cat(gathered)
+        acc = parallel.all_gather_chains(acc, C_total, dev)
+        tot = parallel.all_reduce_sum(float(st.accept_count.sum().item()), dev)
         torch.cuda.synchronize(); t_coll = time.perf_counter() - tc
+        assert abs(float(tot.item()) - float(acc.double().sum().item()) * st.step) < 1e-3 * max(1.0, float(tot.item()))
     assert torch.isfinite(st.q).all(), "non-finite chain state"
     accept_rate = float(acc.mean().item())
 
-    # secondary figure, same run: the plain fused HMC kernel (CP, dual averaging, L leapfrogs)
-    plain = None
-    if inter and world == 1 and not args.headline_only:
-        st2, st = st, engine.ChainState(q0)
-        for _ in range(2):
-            launch(True, plain=True)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            launch(True, plain=True)
-        e1.record(); torch.cuda.synchronize()
-        pms = e0.elapsed_time(e1) / 5
-        plain = {"kernel": "hmc_kernel<RadonLane,CP>", "kernel_ms": pms,
-                 "leapfrog_steps_per_s": C * T * L / (pms * 1e-3),
-                 "achieved_GBps": C * T * algorithmic_bytes_per_transition(D) / (pms * 1e-3) / 1e9}
-        st = st2
+    LL = 2 * num_ls if inter else L
+    extras = {}
+    secondary = world == 1 and not args.headline_only
+    if secondary and inter:
+        # round 1's workload for continuity: a trace row EVERY step, 32 steps per launch
+        l32, _ = make_launcher(32, 1)
+        ms = _time_launches(l32, 20, 3)
+        extras["trace_every_step"] = {"transitions_per_launch": 32, "thin": 1, "kernel_ms": ms,
+                                      "leapfrog_steps_per_s": C * 32 * LL / (ms * 1e-3)}
+        lnt, _ = make_launcher(T, thin, record=False)
+        ms = _time_launches(lnt, 5, 2)
+        extras["no_trace"] = {"transitions_per_launch": T, "kernel_ms": ms, "leapfrog_steps_per_s": C * T * LL / (ms * 1e-3)}
+        lst, _ = make_launcher(T, thin, stats=True)
+        ms = _time_launches(lst, 5, 2)
+        extras["in_kernel_stats"] = {"transitions_per_launch": T, "thin": thin, "kernel_ms": ms,
+                                     "leapfrog_steps_per_s": C * T * LL / (ms * 1e-3)}
+        # the plain fused HMC kernel (CP, dual averaging, L leapfrogs, centred trace row every `thin`-th transition)
+        lp_, _ = make_launcher(T, thin, plain=True)
+        ms = _time_launches(lp_, 5, 2)
+        extras["plain_hmc"] = {"kernel": "radon_hmc_kernel<RadonPk,CP>", "kernel_ms": ms, "num_leapfrog_steps": L,
+                               "leapfrog_steps_per_s": C * T * L / (ms * 1e-3),
+                               "fp32_frac": C * T * L * radon_flop_per_leapfrog(J, D) / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
+        # strong-scaling shards of the 65 536-chain job on ONE GPU (what a rank of a 2 / 4 / 8 GPU job runs)
+        shards = {}
+        rate1 = C * T * LL / (kern_ms * 1e-3)
+        for n_gpu in (2, 4, 8):
+            Cs = args.chains // n_gpu
+            ls, _ = make_launcher(T, thin, chains=Cs)
+            ms = _time_launches(ls, 5, 2)
+            shards["%d" % n_gpu] = {"chains_per_gpu": Cs, "kernel_ms": ms,
+                                    "leapfrog_steps_per_s_per_gpu": Cs * T * LL / (ms * 1e-3),
+                                    "projected_speedup_vs_1gpu": n_gpu * (Cs * T * LL / (ms * 1e-3)) / rate1}
+        extras["strong_shard"] = {"total_chains": args.chains, "by_n_gpus": shards,
+                                  "note": "per-GPU throughput of a C/N-chain shard measured on this GPU; the projection "
+                                          "assumes N identical GPUs and no data-path collective (there is none)"}
 
-    # secondary figure: the one compute-bound model (BASELINE configs[2], german credit, 16 384 chains).
-    # SURVEY.md 8d prices it against the f32 peak: algorithmic flops = 2 products x 2 flop x N x F per gradient.
-    german = None
-    if world == 1 and not args.headline_only:
+    # secondary: the compute-bound model (BASELINE configs[2], german credit, 16 384 chains; SURVEY 8d prices it
+    # against the f32 peak: algorithmic flops = 2 products x 2 flop x N x F per gradient)
+    if secondary:
         gspec = models._spec_german()
         geng = engine.Engine(gspec, dev)
         geng.set_param(0, "NCP")
@@ -251,84 +375,102 @@ def main():
         stg = engine.ChainState(torch.as_tensor((0.1 * rsg.randn(Cg, gspec.D)).astype(np.float32), device=dev))
         epsg = np.full(gspec.D, 0.005, np.float32)
         kwg = dict(seed=5, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9)
-        geng.hmc_run(stg, epsg, Lg, Tg, **kwg)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            geng.hmc_run(stg, epsg, Lg, Tg, **kwg)
-        e1.record(); torch.cuda.synchronize()
-        gms = e0.elapsed_time(e1) / 3
+        gms = _time_launches(lambda: geng.hmc_run(stg, epsg, Lg, Tg, **kwg), 3, 1)
         Ng, Fg = gspec.raw["X"].shape
         gflop = 4.0 * Ng * Fg
-        german = {"kernel": "hmc_kernel<GermanLane<4,16>> (v_mfma_f32_16x16x4_f32)", "chains": Cg, "num_leapfrog_steps": Lg,
-                  "kernel_ms": gms, "leapfrog_steps_per_s": Cg * Tg * Lg / (gms * 1e-3),
-                  "roofline": {"bound": "mfma", "achieved": Cg * Tg * Lg * gflop / (gms * 1e-3) / 1e12, "peak": 157.3,
-                               "unit": "TFLOP/s", "frac": Cg * Tg * Lg * gflop / (gms * 1e-3) / 1e12 / 157.3,
-                               "algorithmic_flop_per_gradient": gflop}}
+        extras["german_credit"] = {
+            "kernel": "hmc_kernel<GermanLane<4,16>> (v_mfma_f32_16x16x4_f32)", "chains": Cg, "num_leapfrog_steps": Lg,
+            "kernel_ms": gms, "leapfrog_steps_per_s": Cg * Tg * Lg / (gms * 1e-3),
+            "roofline": {"bound": "mfma", "achieved": Cg * Tg * Lg * gflop / (gms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": Cg * Tg * Lg * gflop / (gms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                         "algorithmic_flop_per_gradient": gflop}}
+        del geng, stg
+        # election (BASELINE configs[4]: 131 072 chains): SURVEY 8d ~4.5 kflop per gradient (161 cells x ~25 incl. one exp
+        # and one log1p each + 51 x 10) + 4 D for the leapfrog update
+        espec = models._spec_election()
+        eeng = engine.Engine(espec, dev)
+        Ce, Le, Te = 131072, 4, 16
+        rse = np.random.RandomState(2)
+        eflop = 4500.0 + 4.0 * espec.D
+        el = {}
+        for name, rp in (("NCP", "NCP"), ("tied_cVIP_b1", None)):
+            if rp is None:
+                a = np.full(espec.D, 0.5, np.float32); b = np.ones(espec.D, np.float32)
+                eeng.set_param(0, (a, b))
+            else:
+                eeng.set_param(0, rp)
+            ste = engine.ChainState(torch.as_tensor((0.05 * rse.randn(Ce, espec.D)).astype(np.float32), device=dev))
+            epse = np.full(espec.D, 0.02, np.float32)
+            kwe = dict(seed=5, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9)
+            ems = _time_launches(lambda: eeng.hmc_run(ste, epse, Le, Te, **kwe), 3, 1)
+            el[name] = {"kernel_ms": ems, "leapfrog_steps_per_s": Ce * Te * Le / (ems * 1e-3),
+                        "roofline": {"bound": "valu", "achieved": Ce * Te * Le * eflop / (ems * 1e-3) / 1e12,
+                                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": Ce * Te * Le * eflop / (ems * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                     "algorithmic_flop_per_leapfrog": eflop}}
+            del ste
+        extras["election"] = {"kernel": "hmc_kernel<ElectionLane>", "chains": Ce, "num_leapfrog_steps": Le, "forms": el}
+        del eeng
 
-    # ESS/sec (second half of the BASELINE metric): a separate short run with the same kernel,
-    # S recorded samples at the reference's thinning, ESS by FFT on the device trace
+    # ESS/sec (second half of the BASELINE metric) from the reference flow at the headline size
     ess_info = None
-    if world == 1 and not args.headline_only:
-        from autoreparam_amd import util
-        S_ess, burn = 200, 200
-        Ce = C   # the headline chain count: the trace is S_ess x C x D x 4 B = 3.7 GB
-        st3 = engine.ChainState(q0[:Ce])
-        tr3 = torch.empty(S_ess, Ce, D, dtype=torch.float32, device=dev)
-        tot = 1 + burn + 2 * (S_ess - 1)
-        util.effective_sample_size(tr3[:, :64])          # first-call (module load) cost is not part of the figure
-        torch.cuda.synchronize(); te = time.perf_counter()
-        if inter:
-            eng.interleaved_run(st3, eps_i, eps_i, num_ls, num_ls, tot, seed=11, adapt_kind=_lib.ADAPT_SIMPLE,
-                                n_adapt=burn, n_burnin=burn, thin=2, trace=tr3, trace_centered=False, lanes=args.lanes)
-        else:
-            eng.hmc_run(st3, eps0, L, tot, seed=11, adapt_kind=_lib.ADAPT_DUAL, n_adapt=burn, n_burnin=burn, thin=2,
-                        trace=tr3, trace_centered=True, lanes=args.lanes)
-        torch.cuda.synchronize(); t_samp = time.perf_counter() - te
-        ess = util.effective_sample_size(tr3)
-        torch.cuda.synchronize(); t_all = time.perf_counter() - te
-        min_ess = ess.nan_to_num().min(dim=1).values
-        ess_info = {"chains": Ce, "samples": S_ess, "burnin": burn, "mean_min_ess_per_chain": float(min_ess.mean()),
-                    "sampling_s": t_samp, "sampling_plus_ess_s": t_all,
-                    "min_ess_per_sec_all_chains": float(min_ess.sum()) / t_all}
+    if secondary and inter and not args.no_ess:
+        try:
+            ess_info = reference_flow_ess(args.dataset, args.chains, local_rank)
+        except Exception as e:   # the throughput figure must not be lost to a failure of the secondary run
+            ess_info = {"error": repr(e)}
 
     if rank == 0:
-        LL = 2 * num_ls if inter else L
-        value = world * C * T * args.steps * LL / elapsed
-        # interleaved step = one transition with a trace row + one without (per transition)
-        BT = (algorithmic_bytes_per_transition(D, True) + algorithmic_bytes_per_transition(D, False)) if inter \
-            else algorithmic_bytes_per_transition(D)
-        achieved = C * T * BT / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        value = C_total * T * args.steps * LL / elapsed
+        flop_lf = radon_flop_per_leapfrog(J, D)
+        achieved_tf = C * T * LL * flop_lf / (kern_ms * 1e-3) / 1e12
+        # SURVEY 8(d) byte model: per interleaved step one transition with a trace row every `thin` steps + one without
+        n_rows = (T + thin - 1) // thin if rec else 0
+        if inter:
+            alg_bytes = C * (T * 2 * algorithmic_bytes_per_transition(D, False) + n_rows * 4 * D)
+        else:
+            alg_bytes = C * (T * algorithmic_bytes_per_transition(D, False) + n_rows * 4 * D)
+        prof = load_profile({"chains": C, "transitions": T, "thin": thin if rec else 0, "method": args.method,
+                             "leapfrog": L, "dataset": args.dataset, "lanes": args.lanes})
+        traffic = prof["hbm_bytes_per_launch"] if prof and prof.get("config_matches_this_run") else None
+        roof = {"bound": "valu", "achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tf / FP32_PEAK_TFLOPS, "traffic": traffic,
+                "kernel": "radon_interleaved_kernel<RadonPk<4,17>>" if inter else "radon_hmc_kernel<RadonPk<4,17>,CP>",
+                "kernel_ms": kern_ms, "algorithmic_flop_per_leapfrog": flop_lf,
+                "note": "FP32 vector issue binds this kernel (state in registers for the whole launch); frac = SURVEY 8(d) "
+                        "algorithmic flops / HIP-event kernel time / 157.3 TFLOP/s",
+                "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
+                        "algorithmic_GBps": alg_bytes / (kern_ms * 1e-3) / 1e9,
+                        "algorithmic_frac_of_8TBps": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "measured_bytes_per_launch": traffic,
+                        "measured_frac_of_8TBps": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                        "note": "the byte model charges every transition a state load/store the fused kernel performs "
+                                "once per launch; the measured figure is what crosses HBM"}}
+        if prof:
+            roof["profile"] = prof
         out = {
-            "metric": "leapfrog-steps/sec (all chains), radon(PA) 65536 chains per GPU",
+            "metric": "leapfrog-steps/sec (all chains) + ESS/sec, radon(%s) %d chains%s" % (
+                args.dataset, args.chains, " per GPU" if args.scaling == "weak" else " in total"),
             "value": value, "unit": "leapfrog-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("radon --dataset=%s --method=i --inference=HMC (interleaved CP/NCP), %d chains/GPU, "
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ess_per_sec": ess_info.get("ess_per_sec") if ess_info else None,
+            "config": {"workload": ("radon --dataset=%s --method=i --inference=HMC (interleaved CP/NCP), %d chains%s, "
                                     "num_ls=%d+%d leapfrog steps, %d interleaved steps per launch, simple step-size "
-                                    "adaptation on both kernels, CP trace row every step" % (args.dataset, C, num_ls,
-                                                                                            num_ls, T)) if inter else
-                                   ("radon --dataset=%s --method=CP --inference=HMC, %d chains/GPU, L=%d, "
+                                    "adaptation on both kernels, CP trace row every %s step" % (
+                                        args.dataset, args.chains, "/GPU" if args.scaling == "weak" else " total",
+                                        num_ls, num_ls, T, {1: "", 2: "2nd"}.get(thin, "%d-th" % thin))) if inter else
+                                   ("radon --dataset=%s --method=CP --inference=HMC, %d chains%s, L=%d, "
                                     "%d transitions per launch, dual-averaging adaptation, centred trace row "
-                                    "every transition" % (args.dataset, C, L, T)),
-                       "chains_per_gpu": C, "num_leapfrog_steps": LL, "transitions_per_step": T, "D": D,
-                       "lanes_per_chain": args.lanes, "parallelism": "chains sharded, %d rank(s)" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "interleaved_kernel<RadonLane,CP,NCP>" if inter else "hmc_kernel<RadonLane,CP>",
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_step_per_chain": BT,
-                         "algorithmic_bytes_per_launch": C * T * BT},
-            "accept_rate": accept_rate, "stats_allgather_s": t_coll, "plain_hmc": plain, "german_credit": german,
-            "ess": ess_info,
+                                    "every %d transition(s)" % (args.dataset, args.chains,
+                                                                 "/GPU" if args.scaling == "weak" else " total", L, T, thin)),
+                       "chains_per_gpu": C, "chains_total": C_total, "num_leapfrog_steps": LL, "transitions_per_step": T,
+                       "trace_thin": thin if rec else 0, "D": D, "lanes_per_chain": args.lanes,
+                       "parallelism": "chains sharded, %d rank(s), %s scaling" % (world, args.scaling)},
+            "roofline": roof,
+            "accept_rate": accept_rate, "rccl_ranks": world, "stats_allgather_s": t_coll, "ess": ess_info,
         }
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(spec, num_ls if inter else L, 8192, 64, eps_i if inter else eps0, 8,

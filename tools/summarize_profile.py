@@ -1,71 +1,126 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/prof (written by tools/profile_bench.sh on the GPU box) into the
-tracked evidence under profiles/: the rocprofv3 --stats kernel summary, the
-bench line of the same command and the HBM traffic of the dominant kernel.
+"""Turn gpurun_out/prof (written by tools/profile_bench.sh on the GPU box) into the tracked evidence under
+profiles/: the rocprofv3 --kernel-trace --stats summaries, the bench line of the same command, and for the dominant
+(headline) kernel the HBM traffic and SQ counters that bench.py quotes in its `roofline` block.
 
-HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and
-WRITE_SIZE are collected in separate --pmc passes, are in KiB, and on gfx950
-FETCH_SIZE under-reports wide coalesced streaming reads by 2x; this kernel's reads
-are narrow strided dwords (uncalibrated pattern), so both the raw and the
-doubled read figure are recorded and the conservative (doubled) one is used."""
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE come from separate --pmc
+passes, are in KiB, and on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x; this kernel's reads
+are narrow strided dwords (uncalibrated pattern), so the raw and the doubled read figure are both recorded and the
+conservative (doubled) one is used.  SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (x 4 = cycles).
+
+usage: tools/summarize_profile.py <tag>   (e.g. r02)"""
 import csv
 import glob
 import json
 import os
+import subprocess
 import sys
+from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 
-def one(pattern):
+def one(pattern, required=True):
     f = glob.glob(os.path.join(src, pattern))
     if not f:
-        raise SystemExit("missing " + pattern)
+        if required:
+            raise SystemExit("missing " + pattern)
+        return None
     return f[0]
 
 
-stats = list(csv.DictReader(open(one("trace/*/*_kernel_stats.csv"))))
-with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as f:
-    w = csv.DictWriter(f, fieldnames=list(stats[0].keys()))
-    w.writeheader()
-    w.writerows(stats)
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+def copy_stats(pattern, out_name):
+    rows = list(csv.DictReader(open(one(pattern))))
+    with open(os.path.join(dst, out_name), "w") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    return rows
+
+
+def counters(pattern, match=None):
+    """{kernel short name: {counter: mean value over its dispatches}}"""
+    p = one(pattern, required=False)
+    acc = defaultdict(lambda: defaultdict(list))
+    if p:
+        for r in csv.DictReader(open(p)):
+            k = short(r["Kernel_Name"])
+            if "arp::" not in k or (match and match not in k):
+                continue
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+
+
+stats = copy_stats("trace/*/*_kernel_stats.csv", "%s_kernel_stats.csv" % tag)
+copy_stats("trace_full/*/*_kernel_stats.csv", "%s_kernel_stats_full_bench.csv" % tag)
 ours = [r for r in stats if "arp::" in r["Name"]]
 dom = max(ours, key=lambda r: float(r["TotalDurationNs"]))
 kname = dom["Name"]
-short = kname.split("(")[0].replace("void ", "")
-
-
-def pmc(pattern, counter):
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(one(pattern)))
-            if r["Counter_Name"] == counter and short in r["Kernel_Name"]]
-    return vals
-
-
-fetch = pmc("pmc_fetch/*/*_counter_collection.csv", "FETCH_SIZE")
-write = pmc("pmc_write/*/*_counter_collection.csv", "WRITE_SIZE")
-vg = [r for r in csv.DictReader(open(one("trace/*/*_kernel_trace.csv"))) if short in r["Kernel_Name"]][0]
+ks = short(kname)
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-fk, wk = sum(fetch) / len(fetch), sum(write) / len(write)
+open(os.path.join(dst, "%s_bench.json" % tag), "w").write(json.dumps(bench) + "\n")
+
+vg = [r for r in csv.DictReader(open(one("trace/*/*_kernel_trace.csv"))) if ks in r["Kernel_Name"]][0]
+fetch = counters("pmc_fetch/*/*_counter_collection.csv", ks).get(ks, {}).get("FETCH_SIZE")
+write = counters("pmc_write/*/*_counter_collection.csv", ks).get(ks, {}).get("WRITE_SIZE")
+sq = {}
+for d in ("pmc_sqa", "pmc_sqb"):
+    sq.update(counters("%s/*/*_counter_collection.csv" % d, ks).get(ks, {}))
+cfg = bench["config"]
+avg_ns = float(dom["AverageNs"])
+n_simd = 256 * 4
+derived = {}
+if "GRBM_GUI_ACTIVE" in sq:
+    cyc = sq["GRBM_GUI_ACTIVE"] / 8.0          # the counter is summed over the 8 XCDs
+    derived["kernel_cycles_profiled_pass"] = cyc
+    if "SQ_ACTIVE_INST_VALU" in sq:
+        derived["valu_active_frac_of_simd_cycles"] = 4.0 * sq["SQ_ACTIVE_INST_VALU"] / (n_simd * cyc)
+    if "SQ_INSTS_VALU" in sq:
+        derived["simd_cycles_per_valu_inst"] = n_simd * cyc / sq["SQ_INSTS_VALU"]
+        derived["valu_insts_per_wave_per_sampler_step"] = sq["SQ_INSTS_VALU"] / sq.get("SQ_WAVES", 1) / cfg["transitions_per_step"]
+    derived["clock_ghz_estimate"] = cyc / avg_ns
+head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, stdout=subprocess.PIPE, text=True).stdout.strip()
 summary = {
-    "kernel": kname, "calls": int(dom["Calls"]), "avg_ns": float(dom["AverageNs"]),
+    "kernel": kname, "calls": int(dom["Calls"]), "avg_ns": avg_ns,
     "percentage_of_gpu_time": float(dom["Percentage"]),
     "vgpr": int(vg["VGPR_Count"]), "agpr": int(vg["Accum_VGPR_Count"]), "sgpr": int(vg["SGPR_Count"]),
     "lds_bytes": int(vg["LDS_Block_Size"]), "scratch_bytes": int(vg["Scratch_Size"]),
     "grid": int(vg["Grid_Size_X"]), "workgroup": int(vg["Workgroup_Size_X"]),
-    "FETCH_SIZE_KiB_per_launch": fk, "WRITE_SIZE_KiB_per_launch": wk,
-    "hbm_read_bytes_raw": fk * 1024, "hbm_read_bytes_x2_corrected": 2 * fk * 1024, "hbm_write_bytes": wk * 1024,
-    "bytes_per_launch": 2 * fk * 1024 + wk * 1024,
-    "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
-    "bench_kernel_ms": bench["roofline"]["kernel_ms"],
-    "note": "rocprofv3 --kernel-trace --stats and two --pmc passes of `bench.py --steps 10 --warmup 2`; "
-            "bench line from an un-profiled run of the same command",
+    "config": {"chains": cfg["chains_per_gpu"], "transitions": cfg["transitions_per_step"], "thin": cfg["trace_thin"],
+               "method": "i" if "interleaved" in cfg["workload"] else "CP", "leapfrog": cfg["num_leapfrog_steps"],
+               "dataset": "PA" if cfg["D"] == 71 else "?", "lanes": cfg["lanes_per_chain"]},
+    "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
+    "hbm_read_bytes_raw": fetch * 1024 if fetch is not None else None,
+    "hbm_read_bytes_x2_corrected": 2 * fetch * 1024 if fetch is not None else None,
+    "hbm_write_bytes": write * 1024 if write is not None else None,
+    "hbm_bytes_per_launch": (2 * fetch + write) * 1024 if fetch is not None and write is not None else None,
+    "sq_counters_per_launch": sq, "derived": derived,
+    "bench_kernel_ms_unprofiled": bench["roofline"]["kernel_ms"],
+    "bench_frac_unprofiled": bench["roofline"]["frac"],
+    "head": head,
+    "note": "rocprofv3 --kernel-trace --stats and separate --pmc passes of `bench.py --steps 8 --warmup 2 "
+            "--headline-only`; bench line from an un-profiled run of the same configuration (tools/profile_bench.sh)",
 }
-json.dump(summary, open(os.path.join(dst, "%s_summary.json" % tag), "w"), indent=1)
-json.dump({"bytes_per_launch": summary["bytes_per_launch"], "source": "%s_summary.json" % tag},
-          open(os.path.join(dst, "hbm_traffic.json"), "w"))
-open(os.path.join(dst, "%s_bench.json" % tag), "w").write(json.dumps(bench) + "\n")
+json.dump(summary, open(os.path.join(dst, "%s_headline.json" % tag), "w"), indent=1)
+
+# every other kernel of the full bench: duration + SQ counters
+full = {}
+for d in ("pmc_full_sqa", "pmc_full_sqb"):
+    for k, v in counters("%s/*/*_counter_collection.csv" % d).items():
+        full.setdefault(k, {}).update(v)
+with open(os.path.join(dst, "%s_sq_counters_all_kernels.txt" % tag), "w") as f:
+    f.write("# rocprofv3 --pmc (two passes) of the full bench.py run: mean per launch; SQ_*_CYCLES / SQ_WAIT_* / "
+            "SQ_ACTIVE_INST_* in quad-cycles\n")
+    for k in sorted(full):
+        f.write(k + "\n")
+        for c in sorted(full[k]):
+            f.write("    %-32s %.6g\n" % (c, full[k][c]))
 print(json.dumps(summary, indent=1))
