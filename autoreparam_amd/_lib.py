@@ -59,13 +59,14 @@ class ViConfig(C.Structure):
 
 class ViIO(C.Structure):
     _fields_ = [("lr", C.c_void_p), ("loc", C.c_void_p), ("rho", C.c_void_p), ("w", C.c_void_p),
-                ("wb", C.c_void_p), ("elbo", C.c_void_p)]
+                ("wb", C.c_void_p), ("elbo", C.c_void_p), ("prior", C.c_void_p), ("a_group", C.c_void_p),
+                ("b_group", C.c_void_p)]
 
 
 # every symbol include/autoreparam.h declares
 SYMBOLS = ["arp_version", "arp_last_error", "arp_model_create", "arp_model_destroy", "arp_model_dim",
            "arp_model_logp_const", "arp_model_set_param", "arp_logp_grad", "arp_transform",
-           "arp_hmc_run", "arp_interleaved_run", "arp_vi_run", "arp_ess"]
+           "arp_hmc_run", "arp_interleaved_run", "arp_vi_run", "arp_ess", "arp_adapt_probe"]
 
 _lib = None
 
@@ -96,6 +97,7 @@ def lib():
                                       C.POINTER(InterleavedIO), C.c_void_p]
     L.arp_vi_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(ViConfig), C.POINTER(ViIO), C.c_void_p]
     L.arp_ess.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    L.arp_adapt_probe.argtypes = [C.POINTER(HmcConfig), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

@@ -297,6 +297,22 @@ static int build_time_series(arp_model* m, const arp_dataset* d) {
   return 0;
 }
 
+namespace {
+// test hook (arp_adapt_probe): adapt_update on scripted log acceptance ratios, one row per thread
+__global__ void adapt_probe_kernel(HmcParams P, const float* __restrict__ la, int n, float* __restrict__ adapt,
+                                   float* __restrict__ kappa_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float kappa = adapt[i * 4 + 0], esum = adapt[i * 4 + 1], logavg = adapt[i * 4 + 2];
+  for (int s = 0; s < P.n_steps; ++s) {
+    adapt_update(P, P.step_base + s + 1, la[(size_t)s * n + i], kappa, esum, logavg);
+    if (kappa_out) kappa_out[(size_t)s * n + i] = kappa;
+  }
+  adapt[i * 4 + 0] = kappa; adapt[i * 4 + 1] = esum; adapt[i * 4 + 2] = logavg;
+}
+
+}  // namespace
+
 }  // namespace arp
 
 using namespace arp;
@@ -325,13 +341,24 @@ int arp_model_create(const arp_dataset* data, arp_model** out) {
       rc = 0; break;
     default: set_error("arp_model_create: unknown model id"); return 1;
   }
-  if (rc) return rc;
-  for (int w = 0; w < 2; ++w) ARP_HIP_OK(hipMalloc(&m->dev_ab[w], 2 * (size_t)m->D * sizeof(float)));
+  if (rc) { arp_model_destroy(m.release()); return rc; }
+  for (int w = 0; w < 2; ++w) {
+    if (hipMalloc(&m->dev_ab[w], 2 * (size_t)m->D * sizeof(float)) != hipSuccess) {
+      set_error("arp_model_create: hipMalloc of the parameterisation arrays failed");
+      arp_model_destroy(m.release());
+      return 1;
+    }
+  }
   // default parameterisations: 0 = CP (a=b=1), 1 = NCP (a=b=0)
   std::vector<float> ones(m->D, 1.0f), zeros(m->D, 0.0f);
+  // the handle is handed over only once it is complete: on any failure the caller gets *out == NULL and nothing to destroy
+  *out = nullptr;
+  if (arp_model_set_param(m.get(), 0, ones.data(), ones.data()) ||
+      arp_model_set_param(m.get(), 1, zeros.data(), zeros.data())) {
+    arp_model_destroy(m.release());
+    return 1;
+  }
   *out = m.release();
-  if (arp_model_set_param(*out, 0, ones.data(), ones.data())) return 1;
-  if (arp_model_set_param(*out, 1, zeros.data(), zeros.data())) return 1;
   return 0;
 }
 
@@ -478,6 +505,11 @@ int arp_interleaved_run(arp_model* m, const arp_hmc_config* cfg, int n_leapfrog_
     set_error("arp_interleaved_run: n_leapfrog_1, adapt1, accept_count1 and eps0_1 are required");
     return 1;
   }
+  if (io->k0.grad && !io->k0.logp) {
+    // kernels that carry the gradient across the change of coordinates keep BOTH between calls
+    set_error("arp_interleaved_run: k0.logp is required whenever k0.grad is given (pass both or neither)");
+    return 1;
+  }
   HmcParams P;
   if (fill_params(m, cfg, &io->k0, false, &P)) return 1;
   if (io->trace_accept1 && !P.n_samples) P.n_samples = cfg->n_samples;
@@ -522,7 +554,29 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   for (int k = 0; k < P.n_top; ++k) { P.top_idx[k] = m->top_scale[k].first; P.top_logscale[k] = (float)m->top_scale[k].second; }
   P.lr = io->lr; P.loc = io->loc; P.rho = io->rho; P.w = io->w; P.wb = cfg->learn_a ? io->wb : nullptr;
   P.elbo = io->elbo;
+  P.prior = cfg->a_prior ? io->prior : nullptr;
+  P.a_group = (cfg->learn_a && !cfg->tied_b) ? io->a_group : nullptr;
+  P.b_group = (cfg->learn_a && io->wb) ? io->b_group : nullptr;
   o->vi(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, cfg->n_lr, (hipStream_t)stream);
+  ARP_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int arp_adapt_probe(const arp_hmc_config* cfg, const float* log_accept, int n, float* adapt, float* kappa_out,
+                    void* stream) {
+  if (!cfg || !log_accept || !adapt || n <= 0 || cfg->n_steps < 0 || cfg->step_base < 0) {
+    set_error("arp_adapt_probe: bad argument");
+    return 1;
+  }
+  if (cfg->adapt_kind < ARP_ADAPT_NONE || cfg->adapt_kind > ARP_ADAPT_SIMPLE) { set_error("bad adapt_kind"); return 1; }
+  HmcParams P{};
+  P.n_steps = cfg->n_steps; P.step_base = cfg->step_base;
+  P.adapt_kind = cfg->adapt_kind; P.n_adapt = cfg->n_adapt;
+  P.adapt_target = cfg->adapt_target; P.adapt_rate = cfg->adapt_rate;
+  P.adapt_log_target = logf(cfg->adapt_target > 0.f ? cfg->adapt_target : 1e-30f);
+  P.adapt_inv_opr = 1.0f / (1.0f + cfg->adapt_rate);
+  hipLaunchKernelGGL(adapt_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, log_accept, n, adapt,
+                     kappa_out);
   ARP_HIP_OK(hipGetLastError());
   return 0;
 }

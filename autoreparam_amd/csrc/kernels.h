@@ -681,6 +681,9 @@ struct ViParams {
   float const_base;            // parameterisation independent part of the dropped constant
   int n_top; int top_idx[4]; float top_logscale[4];   // -b_i log(scale_i) of the top-level latents
   const float* lr; float* loc; float* rho; float* w; float* wb; float* elbo;
+  float* prior;                // [n_lr][n_steps] log prior density of the learnable parameters per step, or nullptr
+  const int* a_group;          // [D] leader element of every element's shared `a` (its own index when not shared), or nullptr
+  const int* b_group;          // the same for the separately learned `b`
 };
 
 template <int K>
@@ -699,13 +702,20 @@ ARP_DEV float discrete_prior_dlogp(float x) {
   return 10.0f * (l1 - l0) / (l0 + w1 + l1);
 }
 
+// log of that density (normalised: the mixture weights are softmax(0, 5, 0))
+ARP_DEV float discrete_prior_logp(float x) {
+  const float l0 = 5.0f * fast_exp(-10.0f * x), l1 = 5.0f * fast_exp(-10.0f * (1.0f - x));
+  return fast_log(l0 + 148.4131591025766f + l1) - 5.013385943110028f;   // log(2 + e^5)
+}
+
 template <class Lane>
 __global__ __launch_bounds__(kViBlock) void vi_kernel(
     typename Lane::Args A, const float* __restrict__ av, const float* __restrict__ bv, ViParams P) {
   constexpr int K = Lane::K, ND = Lane::ND, NG = Lane::NG;
   __shared__ float s_loc[kViDmax], s_sig[kViDmax], s_lsig[kViDmax], s_a[kViDmax], s_b[kViDmax];
   __shared__ float s_acc[4][kViDmax];   // sum g, sum g*eps, sum dlogp/da, sum dlogp/db
-  __shared__ float s_elbo;
+  __shared__ float s_elbo, s_prior;
+  __shared__ float s_red[2][kViDmax];   // shared (a, b) groups: per-element gradient contributions, then the leaders' values
   const int D = P.D, tid = threadIdx.x, lr_i = blockIdx.x;
   const int slot = tid % K, chain0 = tid / K;
   constexpr int chains_per_pass = kViBlock / K;
@@ -721,6 +731,20 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
     s_a[tid] = av[tid]; s_b[tid] = bv[tid];
   }
   const float base_lr = P.lr[lr_i];
+  // untied parameterisation variables that the reference creates with the shape of a SCALAR loc / scale while the
+  // random variable is a vector (program_transformations.py:486-533): one value shared by the part, owned by its
+  // first element (the leader); members are contiguous
+  int lead[2] = {tid, tid}, gsize[2] = {1, 1};
+  if (tid < D) {
+    const int* grp[2] = {P.a_group, P.wb ? P.b_group : nullptr};
+    for (int k = 0; k < 2; ++k) {
+      if (!grp[k]) continue;
+      lead[k] = grp[k][tid];
+      int n = 0;
+      for (int d = tid; d < D && grp[k][d] == tid; ++d) ++n;
+      gsize[k] = lead[k] == tid ? n : 0;
+    }
+  }
   Lane M;
   __syncthreads();
   M.init(A, s_a, s_b, slot);
@@ -742,8 +766,15 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
       }
       s_acc[0][tid] = 0.f; s_acc[1][tid] = 0.f; s_acc[2][tid] = 0.f; s_acc[3][tid] = 0.f;
     }
-    if (tid == 0) s_elbo = 0.f;
+    if (tid == 0) { s_elbo = 0.f; s_prior = 0.f; }
     __syncthreads();
+    if (P.prior && tid < D && P.learn_a) {
+      // log prior of the learnable parameters at the values this step's ELBO is evaluated with (inference.py:50-54);
+      // a shared parameter is one variable and counts once
+      float lpr = lead[0] == tid ? discrete_prior_logp(s_a[tid]) : 0.f;
+      if (P.wb && lead[1] == tid) lpr += discrete_prior_logp(s_b[tid]);
+      atomicAdd(&s_prior, lpr);
+    }
     if (P.learn_a) M.set_param(s_a, s_b);
 
     float lc[ND], sg[ND], ls[ND];
@@ -815,18 +846,31 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
     if (3 * step > 2 * P.n_steps) lr = base_lr / 20.0f; else if (3 * step > P.n_steps) lr = base_lr / 5.0f;
     b1t *= 0.9f; b2t *= 0.999f;
     const float lr_t = lr * __builtin_amdgcn_sqrtf(1.0f - b2t) / (1.0f - b1t);
+    // gradient of -(ELBO + prior) w.r.t. the unconstrained w (a = sigmoid(w)) and w_b; a shared variable sums the
+    // likelihood terms of its members (contiguous, behind the leader) and takes the prior once
+    const bool grouped = P.a_group || (P.wb && P.b_group);
+    const float inv = 1.0f / (float)P.n_mc;
+    float ga = 0.f, gb = 0.f;
     if (tid < D) {
-      const float inv = 1.0f / (float)P.n_mc;
+      ga = P.learn_a ? (s_acc[2][tid] + (P.tied_b ? s_acc[3][tid] : 0.f)) * inv : 0.f;
+      gb = P.wb ? s_acc[3][tid] * inv : 0.f;
+      if (grouped) { s_red[0][tid] = ga; s_red[1][tid] = gb; }
+    }
+    if (grouped) __syncthreads();
+    if (tid < D) {
+      if (grouped) {
+        for (int d = 1; d < gsize[0]; ++d) ga += s_red[0][tid + d];
+        for (int d = 1; d < gsize[1]; ++d) gb += s_red[1][tid + d];
+      }
       const float sgm = s_sig[tid];
+      const float a = s_a[tid], bb = s_b[tid];
+      const float pa = P.a_prior ? discrete_prior_dlogp(a) : 0.f;
+      const float pb = P.a_prior ? discrete_prior_dlogp(bb) : 0.f;
       float gr[4];
       gr[0] = -s_acc[0][tid] * inv;
       gr[1] = -(s_acc[1][tid] * inv + 1.0f / sgm) * sigmoidf_(rho);
-      float a = s_a[tid];
-      const float pa = P.a_prior ? discrete_prior_dlogp(a) : 0.f;
-      gr[2] = P.learn_a ? -((s_acc[2][tid] + (P.tied_b ? s_acc[3][tid] : 0.f)) * inv + pa) * a * (1.0f - a) : 0.f;
-      float bb = s_b[tid];
-      const float pb = P.a_prior ? discrete_prior_dlogp(bb) : 0.f;
-      gr[3] = P.wb ? -(s_acc[3][tid] * inv + pb) * bb * (1.0f - bb) : 0.f;
+      gr[2] = P.learn_a ? -(ga + pa) * a * (1.0f - a) : 0.f;
+      gr[3] = P.wb ? -(gb + pb) * bb * (1.0f - bb) : 0.f;
       float* par[4] = {&loc, &rho, &w, &wb};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -837,10 +881,17 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
         if (k < 2 || (k == 2 && P.learn_a) || (k == 3 && P.wb)) *par[k] -= lr_t * m1[k] / (__builtin_amdgcn_sqrtf(m2[k]) + 1e-8f);
       }
     }
+    if (grouped) {   // members take their leader's value
+      __syncthreads();
+      if (tid < D) { s_red[0][tid] = w; s_red[1][tid] = wb; }
+      __syncthreads();
+      if (tid < D) { w = s_red[0][lead[0]]; wb = s_red[1][lead[1]]; }
+    }
     if (tid == 0) {
       float c = P.const_base + 0.9189385332046727f * (float)D;   // + 0.5 log 2pi per latent from -log q
       for (int k = 0; k < P.n_top; ++k) c -= s_b[P.top_idx[k]] * P.top_logscale[k];
       P.elbo[(size_t)lr_i * P.n_steps + step] = s_elbo / (float)P.n_mc + c;
+      if (P.prior) P.prior[(size_t)lr_i * P.n_steps + step] = s_prior;
     }
     __syncthreads();
   }

@@ -199,11 +199,14 @@ class Engine(object):
 
 
     # -- mean-field VI ----------------------------------------------------------
-    def vi_run(self, lr, loc, rho, n_steps, n_mc, which=0, w=None, tied_b=False, wb=None, seed=0, a_prior=False):
+    def vi_run(self, lr, loc, rho, n_steps, n_mc, which=0, w=None, tied_b=False, wb=None, seed=0, a_prior=False,
+               a_group=None, b_group=None, return_prior=False):
         """Run len(lr) independent Adam optimisations of the mean-field ELBO in one launch.
 
         loc, rho (and w, the unconstrained VIP parameter, when given) are [n_lr, D]
-        device tensors updated in place; returns the ELBO timeline [n_lr, n_steps]."""
+        device tensors updated in place; returns the ELBO timeline [n_lr, n_steps] (and, with return_prior,
+        the per-step log prior of the learnable parameters).  a_group / b_group ([D] int leader indices) make
+        untied parameterisation variables shared over a part (arp_vi_io.a_group)."""
         lr_t = self._dev(np.asarray(lr, np.float32))
         n_lr = lr_t.shape[0]
         assert loc.shape == (n_lr, self.D) and rho.shape == (n_lr, self.D)
@@ -217,9 +220,29 @@ class Engine(object):
         io = _lib.ViIO()
         io.lr, io.loc, io.rho, io.w, io.elbo = _ptr(lr_t), _ptr(loc), _ptr(rho), _ptr(w), _ptr(elbo)
         io.wb = _ptr(wb)
+        prior = torch.zeros(n_lr, int(n_steps), dtype=torch.float32, device=self.device) if return_prior else None
+        io.prior = _ptr(prior)
+        ag = torch.as_tensor(np.asarray(a_group, np.int32), device=self.device) if a_group is not None else None
+        bg = torch.as_tensor(np.asarray(b_group, np.int32), device=self.device) if b_group is not None else None
+        io.a_group, io.b_group = _ptr(ag), _ptr(bg)
         with torch.cuda.device(self.device):
             _lib.check(self._L.arp_vi_run(self._h, which, C.byref(cfg), C.byref(io), _stream()))
-        return elbo
+        return (elbo, prior) if return_prior else elbo
+
+
+    def adapt_probe(self, log_accept, adapt, kind, n_adapt, step_base=0, target=0.75, rate=0.05):
+        """Test hook (arp_adapt_probe): the kernels' step-size recurrence on scripted log acceptance ratios
+        `log_accept` [n_steps, n]; `adapt` [n, 4] is updated in place; returns the multipliers [n_steps, n]."""
+        la = self._dev(log_accept)
+        n_steps, n = la.shape
+        out = torch.empty(n_steps, n, dtype=torch.float32, device=self.device)
+        cfg = _lib.HmcConfig()
+        cfg.n_steps, cfg.step_base = int(n_steps), int(step_base)
+        cfg.adapt_kind, cfg.n_adapt = int(kind), int(n_adapt)
+        cfg.adapt_target, cfg.adapt_rate = float(target), float(rate)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.arp_adapt_probe(C.byref(cfg), _ptr(la), n, _ptr(adapt), _ptr(out), _stream()))
+        return out
 
 
 def stats_summary(stats, n, batch):

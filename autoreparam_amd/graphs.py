@@ -75,14 +75,19 @@ def make_cvip_graph(model_config, parameterisation_type="exp", tied_pparams=Fals
     tied_pparams=True reproduces what the reference *executes*: `b` equals `a` only
     on the trace that creates the variable and falls back to 1 on every later trace
     (program_transformations.py:495-500, 513-514), so the target and
-    the ELBO see b = 1.  tied_pparams=False learns a separate b = sigmoid(w_b).
+    the ELBO see b = 1.  tied_pparams=False learns a separate b = sigmoid(w_b), each with the reference's
+    variable shapes.
     """
     spec = model_config.model
     init = collections.OrderedDict()
     for name, shp in zip(spec.part_names, spec.part_shapes):
-        init[name + "_a"] = np.full(shp, 0.5, np.float32)
-        if not tied_pparams:
-            init[name + "_b"] = np.full(shp, 0.5, np.float32)
+        if tied_pparams:
+            init[name + "_a"] = np.full(shp, 0.5, np.float32)      # broadcast shape of loc and scale
+        else:
+            # untied: `a` takes the shape of the variable's loc, `b` of its scale (program_transformations.py:486-533);
+            # a vector variable with a scalar loc (german beta_log_scales, election a) learns ONE shared a
+            init[name + "_a"] = np.full(spec.untied_shape(name, "a"), 0.5, np.float32)
+            init[name + "_b"] = np.full(spec.untied_shape(name, "b"), 0.5, np.float32)
     target = Target(spec, init)
     elbo = Elbo(target, flags.num_mc_samples, learn_a=True, tied=tied_pparams)
     return target, spec, elbo, _variational_parameters(spec), init

@@ -60,9 +60,20 @@ def find_best_learning_rate(elbo, variational_parameters, learnable_parameters_p
         w = torch.zeros(n_lr, D, device=dev)
         if not elbo.tied:
             wb = torch.zeros(n_lr, D, device=dev)
-    timeline = eng.vi_run(lrs, loc, rho, flags.num_optimization_steps, flags.num_mc_samples, which=0, w=w, wb=wb,
-                          seed=flags.seed, a_prior=learnable_parameters_prior is not None
-                          ).cpu().numpy().astype(np.float64)
+    a_group = b_group = None
+    if elbo.learn_a and not elbo.tied:
+        a_group, b_group = spec.untied_groups()
+    use_prior = learnable_parameters_prior is not None and elbo.learn_a
+    res = eng.vi_run(lrs, loc, rho, flags.num_optimization_steps, flags.num_mc_samples, which=0, w=w, wb=wb,
+                     seed=flags.seed, a_prior=use_prior, a_group=a_group, b_group=b_group, return_prior=use_prior)
+    if use_prior:
+        # the reference optimises, ranks the learning rates on and returns the timeline of elbo + prior, and
+        # subtracts the prior only from the final value (inference.py:50-54, 120-150)
+        pure, prior_tl = (t.cpu().numpy().astype(np.float64) for t in res)
+        timeline = pure + prior_tl
+    else:
+        timeline = res.cpu().numpy().astype(np.float64)
+        prior_tl = np.zeros_like(timeline)
     loc, rho = loc.cpu().numpy(), rho.cpu().numpy()
     scale = np.where(rho > 20, rho, np.log1p(np.exp(np.minimum(rho, 20))))
 
@@ -77,6 +88,7 @@ def find_best_learning_rate(elbo, variational_parameters, learnable_parameters_p
             best_elbo, best = this, i
     if best is None:
         raise RuntimeError("no learning rate gave a finite ELBO")
+    best_pure_elbo = best_elbo - np.mean(prior_tl[best, -32:])   # "a 'pure' ELBO for valid comparisons"  (inference.py:150)
     learned_variational_params = collections.OrderedDict()
     for k, name in enumerate(spec.part_names):
         lo, hi = spec.offsets[k], spec.offsets[k + 1]
@@ -90,10 +102,15 @@ def find_best_learning_rate(elbo, variational_parameters, learnable_parameters_p
         learned_reparam = collections.OrderedDict()
         for k, name in enumerate(spec.part_names):
             lo, hi = spec.offsets[k], spec.offsets[k + 1]
-            learned_reparam[name + "_a"] = av[lo:hi].reshape(spec.part_shapes[k]).astype(np.float32)
-            if bv is not None:
-                learned_reparam[name + "_b"] = bv[lo:hi].reshape(spec.part_shapes[k]).astype(np.float32)
-    return (np.float64(best_elbo), list(timeline[best]), lrs[best], step_size_init,
+            if bv is None:
+                learned_reparam[name + "_a"] = av[lo:hi].reshape(spec.part_shapes[k]).astype(np.float32)
+            else:   # untied: the reference's variable shapes (a shared value is a scalar)
+                sa, sb = spec.untied_shape(name, "a"), spec.untied_shape(name, "b")
+                learned_reparam[name + "_a"] = (av[lo:hi].reshape(spec.part_shapes[k]) if sa == spec.part_shapes[k]
+                                                else av[lo].reshape(())).astype(np.float32)
+                learned_reparam[name + "_b"] = (bv[lo:hi].reshape(spec.part_shapes[k]) if sb == spec.part_shapes[k]
+                                                else bv[lo].reshape(())).astype(np.float32)
+    return (np.float64(best_pure_elbo), list(timeline[best]), lrs[best], step_size_init,
             learned_variational_params, learned_reparam)
 
 
@@ -238,6 +255,7 @@ def _sample(run_segment, st, S, B, thin, C, D, dev, keep_chains, n_acc, chunk_ro
             run_segment(n, B, trace, accs)
             done += n
         ess = util.effective_sample_size(trace)
+        _sample.last_moments = None           # the whole trace is returned: moments are the caller's to take
         return trace, None, [a.cpu().numpy().astype(bool) for a in accs], ess, "autocorrelation"
     batch = max(8, min(rows, S) // 8)
     stats = torch.zeros(6, C, D, dtype=torch.float32, device=dev)
@@ -251,7 +269,10 @@ def _sample(run_segment, st, S, B, thin, C, D, dev, keep_chains, n_acc, chunk_ro
         n = min(_MAX_STEPS_PER_LAUNCH, total - done)
         run_segment(n, B, kept, [None] * n_acc, **extra)
         done += n
-    _, _, ess = _engine.stats_summary(stats, S, batch)
+    mean, var, ess = _engine.stats_summary(stats, S, batch)
+    # per-chain posterior mean / variance of every (centred) element from the in-kernel accumulators, [C, D] float64
+    # (build-specific: the reference would take them from the [S, C, D] trace this mode does not materialise)
+    _sample.last_moments = (mean, var)
     return None, kept.cpu().numpy(), [a.cpu().numpy()[np.newaxis, :] for a in racc], ess.to(torch.float32), \
         "batch_means(%d)" % batch
 
@@ -306,6 +327,7 @@ def hmc(target, model_config, step_size_init, initial_states, reparam, flags=FLA
         states_transformed = spec.unpack(kept)
         states_orig = None
     hmc.last_ess_estimator = estimator
+    hmc.last_moments = _sample.last_moments
     return states_orig, kernel_results, states_transformed, ess
 
 
@@ -345,4 +367,5 @@ def hmc_interleaved(model_config, target_cp, target_ncp, num_leapfrog_steps_cp, 
         cp_results=KernelResults(HmcInnerResults(accs[0]), st.adapt[:, 0].cpu().numpy(), st.step),
         ncp_results=KernelResults(HmcInnerResults(accs[1]), st.adapt1[:, 0].cpu().numpy(), st.step))
     hmc_interleaved.last_ess_estimator = estimator
+    hmc_interleaved.last_moments = _sample.last_moments
     return states, kr, ess

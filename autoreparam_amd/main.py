@@ -304,6 +304,10 @@ def main(argv=None, flags=FLAGS):
     """reference main.py:190-231"""
     if argv is not None:
         flags.parse(list(argv))
+    if flags.reparameterise_variational:
+        # util.make_variational_model_special (reference util.py:334-391) is outside the hot path this build covers;
+        # accepting the flag silently would write a *_reparam_variational*.json that holds ordinary mean-field results
+        raise NotImplementedError("--reparameterise_variational is not supported by this build (SURVEY.md section 2)")
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     if ws > 1:
         # launched by torch.distributed.run: one rank per GPU, RCCL for the statistics exchange
@@ -314,9 +318,13 @@ def main(argv=None, flags=FLAGS):
         torch.cuda.set_device(local)
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", device_id=torch.device(flags.device))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device(flags.device))
+            except TypeError:                                     # older torch: no device_id keyword
+                dist.init_process_group("nccl")
         if flags.inference == "VI" and dist.get_rank() != 0:
-            dist.barrier()      # VI is a single-workgroup-per-learning-rate job: rank 0 runs it
+            # VI is a single-workgroup-per-learning-rate job: rank 0 runs it and writes the JSON.  The other ranks
+            # leave without a collective -- a barrier here would sit in the RCCL watchdog for as long as the fit takes
             return None
     util.print_("Loading model {} with dataset {}.".format(flags.model, flags.dataset))
     model_config = models.get_model_by_name(flags.model, dataset=flags.dataset)
@@ -331,11 +339,7 @@ def main(argv=None, flags=FLAGS):
         ("_discrete_prior" if "VIP" in flags.method and flags.discrete_prior else ""))
     file_path = os.path.join(results_dir, filename)
     if flags.inference == "VI":
-        out = run_vi(model_config, results_dir, file_path, flags)
-        if ws > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        return out
+        return run_vi(model_config, results_dir, file_path, flags)
     elif flags.inference == "HMC":
         if flags.method == "i":
             return run_interleaved_hmc(model_config, results_dir, file_path, flags)

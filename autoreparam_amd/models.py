@@ -25,7 +25,12 @@ ModelConfig = collections.namedtuple(
 class ModelSpec(object):
     """Joint density of one model: id, latent parts in trace order, raw inputs."""
 
-    def __init__(self, name, model_id, part_names, part_shapes, raw, observed):
+    def __init__(self, name, model_id, part_names, part_shapes, raw, observed, scalar_loc=(), scalar_scale=()):
+        # vector parts whose reference random variable has a SCALAR loc / scale: with --notied_pparams the
+        # reference gives `<rv>_a` the loc's shape and `<rv>_b` the scale's (program_transformations.py:486-533),
+        # i.e. one shared value for the part
+        self.scalar_loc = set(scalar_loc)
+        self.scalar_scale = set(scalar_scale)
         self.name = name
         self.model_id = model_id
         self.part_names = list(part_names)
@@ -75,6 +80,23 @@ class ModelSpec(object):
             if name + "_b" in reparam:
                 b[lo:hi] = np.broadcast_to(np.asarray(reparam[name + "_b"], np.float32).reshape(-1), (hi - lo,))
         return a, b
+
+    def untied_groups(self):
+        """(a_group, b_group) int32 [D] for arp_vi_io: leader element of every element's untied a / b variable."""
+        ag, bg = np.arange(self.D, dtype=np.int32), np.arange(self.D, dtype=np.int32)
+        for k, name in enumerate(self.part_names):
+            lo, hi = self.offsets[k], self.offsets[k + 1]
+            if name in self.scalar_loc:
+                ag[lo:hi] = lo
+            if name in self.scalar_scale:
+                bg[lo:hi] = lo
+        return ag, bg
+
+    def untied_shape(self, name, which):
+        """shape of the reference's untied `<name>_a` (which='a') / `<name>_b` variable"""
+        k = self.part_names.index(name)
+        shared = name in (self.scalar_loc if which == "a" else self.scalar_scale)
+        return () if shared else self.part_shapes[k]
 
     def dataset(self):
         """(ctypes Dataset, keep-alive list) for arp_model_create."""
@@ -160,7 +182,8 @@ def _spec_electric():
     r = _load("electric.npz")
     P, G = int(r["n_pair"]), int(r["n_grade"])
     return ModelSpec("electric", _lib.MODEL_ELECTRIC, ["mua", "sigma_y", "a", "b"],
-                     [(int(r["n_grade_pair"]),), (G,), (P, 1), (G,)], r, {"y": r["y"]})
+                     [(int(r["n_grade_pair"]),), (G,), (P, 1), (G,)], r, {"y": r["y"]},
+                     scalar_loc=("mua", "sigma_y", "b"), scalar_scale=("a",))
 
 
 def _spec_time_series():
@@ -177,14 +200,14 @@ def _spec_german():
     F = r["X"].shape[1]
     return ModelSpec("german_credit_lognormalcentered", _lib.MODEL_GERMAN_CREDIT,
                      ["overall_log_scale", "beta_log_scales", "beta"], [(), (F,), (F,)],
-                     r, {"y": r["y"][np.newaxis, ...]})
+                     r, {"y": r["y"][np.newaxis, ...]}, scalar_loc=("beta_log_scales",))
 
 
 def _spec_election():
     r = _load("election88.npz")
     S = int(r["n_state"])
     return ModelSpec("election", _lib.MODEL_ELECTION, ["mua", "log_sigma_a", "a", "b1", "b2"],
-                     [(), (), (S,), (), ()], r, {"y": r["y"].reshape(-1, 1)})
+                     [(), (), (S,), (), ()], r, {"y": r["y"].reshape(-1, 1)}, scalar_loc=("a",))
 
 
 def get_model_by_name(model_name, dataset=None):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ARP_ABI_VERSION 1
+#define ARP_ABI_VERSION 2
 
 /* Models on the hot path (reference models.py:131-166, 809-857, 884-923, 967-1008). */
 enum {
@@ -182,6 +182,14 @@ typedef struct arp_vi_io {
   float* w;                  /* [n_lr][D] in/out unconstrained a (only if learn_a) */
   float* wb;                 /* [n_lr][D] in/out unconstrained b, learned separately (untied), or NULL */
   float* elbo;               /* [n_lr][n_steps] ELBO estimate per step (reference-valued, constants included) */
+  float* prior;              /* [n_lr][n_steps] or NULL: log density of the a_prior on the learnable parameters at each step's
+                              * values (the reference ranks learning rates on elbo + prior and reports elbo, inference.py:50-54,
+                              * 120-150) */
+  const int32_t* a_group;    /* [D] or NULL.  With untied parameters the reference gives `a` the shape of the variable's loc
+                              * (program_transformations.py:486-493, 507-510): a vector variable whose loc is a scalar (german
+                              * beta_log_scales, election a) learns ONE shared a.  a_group[d] = index of the first element of
+                              * d's group (d itself when its a is its own); groups are contiguous */
+  const int32_t* b_group;    /* the same for the separately learned b (shape of the variable's scale; only read with wb) */
 } arp_vi_io;
 int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_io* io, void* stream);
 
@@ -190,6 +198,15 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
  * (i < n_series, e.g. n_series = C*D of a [S][C][D] trace); ess[i] = S / (-1 + 2 sum_k (S-k)/S rho_k) with the
  * auto-correlations cut at the first negative one.  A constant series gives NaN (0/0), as the reference's does. */
 int arp_ess(const float* trace, int64_t n_samples, int64_t n_series, int64_t row_stride, float* ess, void* stream);
+
+/* Test hook: the step-size adaptation recurrence of the chain kernels on SCRIPTED log acceptance ratios
+ * (tfp.mcmc.DualAveragingStepSizeAdaptation / SimpleStepSizeAdaptation as wired at inference.py:224-226, 288-306;
+ * SURVEY.md 8c known answer (7)).  For each of `n` independent rows, applies the update after transitions
+ * cfg->step_base + 1 ... cfg->step_base + n_steps with log_accept[s][row]; `adapt` is [n][4] in/out as in arp_hmc_io;
+ * kappa_out ([n_steps][n] or NULL) receives the multiplier in force after each update.  Only the adapt_* fields,
+ * step_base and n_steps of cfg are read. */
+int arp_adapt_probe(const arp_hmc_config* cfg, const float* log_accept, int n, float* adapt, float* kappa_out,
+                    void* stream);
 
 #ifdef __cplusplus
 }

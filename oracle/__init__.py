@@ -182,8 +182,9 @@ _TOP = {"8schools": lambda D: [(0, 5.0), (1, 5.0)], "radon": lambda D: [], "rado
 
 
 def _vi_run(self, a, b, lr, loc, rho, w, n_steps, n_mc, learn_a=False, tied_b=False, seed=0, lanes=16, block=512,
-            wb=None, a_prior=False):
-    """find_best_learning_rate's optimisation loops: returns (elbo [n_lr, n_steps]); loc/rho/w updated in place."""
+            wb=None, a_prior=False, a_group=None, b_group=None, return_prior=False):
+    """find_best_learning_rate's optimisation loops: returns (elbo [n_lr, n_steps]); loc/rho/w updated in place.
+    a_group / b_group: int32 [D] leader indices of shared untied variables; return_prior: also the per-step log prior."""
     dtype = loc.dtype
     n_lr = len(lr)
     top = _TOP[self.spec.name](self.D)
@@ -192,14 +193,19 @@ def _vi_run(self, a, b, lr, loc, rho, w, n_steps, n_mc, learn_a=False, tied_b=Fa
     idx = np.ascontiguousarray([i for i, _ in top] + [0] * (4 - len(top)), np.int32)
     lsc = np.ascontiguousarray([np.log(s) for _, s in top] + [0.0] * (4 - len(top)), np.float64)
     elbo = np.zeros((n_lr, n_steps), dtype)
+    prior = np.zeros((n_lr, n_steps), dtype) if return_prior else None
+    ag = np.ascontiguousarray(a_group, np.int32) if a_group is not None else None
+    bg = np.ascontiguousarray(b_group, np.int32) if b_group is not None else None
     f32 = lambda v: np.ascontiguousarray(v, np.float32)
     a, b, lr = f32(a), f32(b), f32(lr)
     getattr(lib(), "orc_vi_run" + self._sfx(dtype))(
         self._h, _p(a), _p(b), n_lr, n_steps, n_mc, int(learn_a) | (int(a_prior) << 1), int(tied_b), C.c_uint64(seed), lanes, block,
         _p(lr),
         _p(loc), _p(rho), _p(w) if w is not None else C.c_void_p(0), _p(wb) if wb is not None else C.c_void_p(0),
-        _p(elbo), C.c_double(base), len(top), _p(idx), _p(lsc))
-    return elbo
+        _p(elbo), C.c_double(base), len(top), _p(idx), _p(lsc),
+        _p(ag) if ag is not None else C.c_void_p(0), _p(bg) if bg is not None else C.c_void_p(0),
+        _p(prior) if prior is not None else C.c_void_p(0))
+    return (elbo, prior) if return_prior else elbo
 
 
 def _dparam(self, x, a, b):

@@ -860,7 +860,8 @@ static REAL FN(discrete_prior_dlogp)(REAL x) {
 int FN(orc_vi_run)(const orc_model* M, const float* a_in, const float* b_in, int n_lr, int n_steps, int n_mc,
                    int learn_a_flags, int tied_b, uint64_t seed, int lanes, int block, const float* lr_in,
                    REAL* loc_io, REAL* rho_io, REAL* w_io, REAL* wb_io, REAL* elbo_out, double const_base, int n_top,
-                   const int* top_idx, const double* top_logscale) {
+                   const int* top_idx, const double* top_logscale, const int* a_group, const int* b_group,
+                   REAL* prior_out) {
   const int learn_a = learn_a_flags & 1, a_prior = (learn_a_flags >> 1) & 1;
   const int D = M->D, NG = M->n_glob, G = M->n_groups, P = M->n_local_parts;
   const int per_lane = (G + lanes - 1) / lanes, nd = NG + P * per_lane;
@@ -930,6 +931,26 @@ int FN(orc_vi_run)(const orc_model* M, const float* a_in, const float* b_in, int
       double c = const_base + 0.9189385332046727 * D;
       for (int k = 0; k < n_top; ++k) c -= (double)b[top_idx[k]] * top_logscale[k];
       elbo_out[(size_t)li * n_steps + step] = elbo / n_mc + (REAL)c;
+      /* untied parameterisation variables shared over a part (program_transformations.py:486-533: `a` has the shape of
+       * the loc, `b` of the scale): the leader (first element of the group) collects its members' likelihood terms,
+       * the prior counts once; members copy the leader's value after the update */
+      if (learn_a && (a_group || (wb && b_group))) {
+        for (int d = D - 1; d >= 0; --d) {
+          if (a_group && a_group[d] != d) { acc[2 * D + a_group[d]] += acc[2 * D + d]; }
+          if (wb && b_group && b_group[d] != d) { acc[3 * D + b_group[d]] += acc[3 * D + d]; }
+        }
+      }
+      if (prior_out) {   /* log density of the --discrete_prior mixture on every learnable variable (inference.py:50-54) */
+        double lpr = 0;
+        for (int d = 0; d < D && learn_a; ++d) {
+          const double norm = log(2.0 + exp(5.0));
+          if (!a_group || a_group[d] == d)
+            lpr += log(5.0 * exp(-10.0 * (double)a[d]) + exp(5.0) + 5.0 * exp(-10.0 * (1.0 - (double)a[d]))) - norm;
+          if (wb && (!b_group || b_group[d] == d))
+            lpr += log(5.0 * exp(-10.0 * (double)b[d]) + exp(5.0) + 5.0 * exp(-10.0 * (1.0 - (double)b[d]))) - norm;
+        }
+        prior_out[(size_t)li * n_steps + step] = (REAL)lpr;
+      }
       for (int d = 0; d < D; ++d) {
         REAL gr[4];
         gr[0] = -acc[d] / n_mc;
@@ -945,6 +966,10 @@ int FN(orc_vi_run)(const orc_model* M, const float* a_in, const float* b_in, int
           m2[k * D + d] = (REAL)0.999 * m2[k * D + d] + (REAL)0.001 * gk * gk;
           if (par[k]) *par[k] -= lr_t * m1[k * D + d] / ((REAL)sqrt((double)m2[k * D + d]) + (REAL)1e-8);
         }
+      }
+      for (int d = 0; d < D && learn_a; ++d) {
+        if (a_group && a_group[d] != d) w[d] = w[a_group[d]];
+        if (wb && b_group && b_group[d] != d) wb[d] = wb[b_group[d]];
       }
     }
     free(a); free(b); free(streams); free(m1); free(m2); free(sig); free(eps); free(z); free(g); free(da); free(db); free(acc);

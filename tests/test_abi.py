@@ -30,7 +30,7 @@ def test_header_symbols_exported(built):
     for n in names:
         assert hasattr(L, n), n
     assert sorted(names) == sorted(built.SYMBOLS)
-    assert L.arp_version() == 1
+    assert L.arp_version() == 2
 
 
 def test_struct_layout_matches_header(built):

@@ -106,3 +106,40 @@ def test_streaming_trace_mode_equals_whole_trace(gpu):
     assert np.sum(kr_a.inner_results.is_accepted) == np.sum(kr_b.inner_results.is_accepted)
     ma, mb = util.get_min_ess(ess_a)[0], util.get_min_ess(ess_b)[0]
     assert 0.4 < mb / ma < 2.5
+
+
+def test_config3_full_size_german_dvip(gpu, tmp_path):
+    """BASELINE configs[2] at its real size through the CLI flow: german_credit_lognormalcentered, cVIP fit ->
+    dVIP (thresholded parameterisation) -> HMC with dual averaging on 16 384 chains, the statistics accumulated
+    inside the kernels (the [S, C, D] trace of the full schedule would be 410 TB).  Short schedule; the pooled
+    posterior means of the centred coordinates against the long float64 oracle run (tests/golden/posterior_golden.npz)."""
+    import torch
+    from autoreparam_amd import flags as flags_mod, inference
+    d = str(tmp_path)
+    base = ["--model=german_credit_lognormalcentered", "--results_dir=" + d, "--num_chains=16384", "--seed=2"]
+    _run(base + ["--inference=VI", "--method=cVIP", "--num_optimization_steps=1500"])
+    _run(base + ["--inference=VI", "--method=dVIP", "--num_optimization_steps=1500"])
+    r = json.load(open(os.path.join(d, "dVIP_eig_tied.json")))
+    assert set(np.unique(np.concatenate([np.ravel(v) for k, v in r["learned_reparam"].items() if k.endswith("_a")]))) <= {0.0, 1.0}
+    S, burn = 400, 1500
+    hm = ["--num_samples=%d" % S, "--num_burnin_steps=%d" % burn, "--num_adaptation_steps=1200", "--num_leapfrog_steps=8",
+          "--trace_chunk_rows=64", "--num_chains_to_save=4"]
+    res = _run(base + ["--inference=HMC", "--method=dVIP"] + hm)
+    assert inference.hmc.last_ess_estimator.startswith("batch_means")
+    ess_min, sem_min, acc, mcmc_time = res
+    assert 55 < acc < 95 and ess_min > 0
+    mean_c, var_c = inference.hmc.last_moments                 # [C, D] per-chain moments from the kernels' accumulators
+    assert mean_c.shape == (16384, 125) and torch.isfinite(mean_c).all()
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "posterior_golden.npz"))
+    mean_g, sd_g, mcse_g = gold["german/mean"], gold["german/sd"], gold["german/mcse"]
+    cm = mean_c.cpu().numpy()
+    mean = cm.mean(axis=0)
+    mcse = cm.std(axis=0, ddof=1) / np.sqrt(cm.shape[0])
+    z = np.abs(mean - mean_g) / (np.sqrt(mcse ** 2 + mcse_g ** 2) + 0.02 * sd_g)
+    assert z.max() < 5.0, (int(z.argmax()), float(z.max()))
+    sd = np.sqrt(var_c.cpu().numpy().mean(axis=0) + cm.var(axis=0))
+    assert np.abs(sd / sd_g - 1).max() < 0.12
+    r = json.load(open(os.path.join(d, "dVIP_eig_tied.json")))
+    assert len(r["ess_min"]) == 1 and len(r["mcmc_time_sec"]) == 1
+    tr = np.load(os.path.join(d, "dVIP_eig_tied_traces.npz"))
+    assert tr["beta"].shape == (S, 4, 62)

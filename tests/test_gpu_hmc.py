@@ -94,7 +94,41 @@ def test_trajectories_match_oracle_b_equal_one(oracle_lib, gpu, mname):
         assert np.array_equal(st.rng.cpu().numpy().view(np.uint32)[:, :lanes], so["rng"][:, :lanes])
 
 
-@pytest.mark.parametrize("mname,kind", [("8schools", "NCP"), ("radon_MN", "NCP"), ("election", "CP")])
+def test_adaptation_recurrence_on_scripted_acceptance(oracle_lib, gpu):
+    """SURVEY 8c known answer (7): the dual-averaging and simple step-size recurrences on a SCRIPTED sequence of log
+    acceptance ratios, through the ABI (arp_adapt_probe runs the kernels' own adapt_update), against the oracle's
+    libm restatement to 1e-5 -- independent of any trajectory, so the hardware exp/log/rcp approximations are the
+    only difference.  Covers the adapting phase, the hand-over to the averaged step and a chunked continuation."""
+    from autoreparam_amd import engine
+    eng = _eng("8schools", gpu)
+    rs = np.random.RandomState(0)
+    n_steps, n, n_adapt = 60, 257, 40
+    la = np.minimum(rs.randn(n_steps, n) * 1.5 - 0.3, 5.0).astype(np.float32)
+    la[3, :7] = -np.inf                                   # a rejected divergent proposal: alpha = 0
+    la[5, 7:11] = 30.0                                    # alpha clipped at 1
+    for kind in (1, 2):
+        ad = torch.zeros(n, 4, device=gpu); ad[:, 0] = 1.0
+        k1 = eng.adapt_probe(la[:25], ad, kind, n_adapt)                       # two launches: state round-trips
+        k2 = eng.adapt_probe(la[25:], ad, kind, n_adapt, step_base=25)
+        kap = torch.cat([k1, k2]).cpu().numpy()
+        import ctypes as C
+        upd = oracle_lib.lib().orc_adapt_update_f32       # the oracle's recurrence, float32 arithmetic, libm functions
+        ref = np.zeros((n_steps, n)); st = np.zeros((n, 3), np.float32); st[:, 0] = 1.0
+        for i in range(n):
+            s3 = (C.c_float * 3)(1.0, 0.0, 0.0)
+            for t in range(n_steps):
+                upd(kind, C.c_longlong(t + 1), n_adapt, C.c_float(0.75), C.c_float(0.05), C.c_float(float(la[t, i])), s3)
+                ref[t, i] = s3[0]
+            st[i] = (s3[0], s3[1], s3[2])
+        assert np.isfinite(kap).all()
+        np.testing.assert_allclose(kap, ref, rtol=1e-5, atol=0)
+        np.testing.assert_allclose(ad.cpu().numpy()[:, :3], st, rtol=1e-5, atol=2e-6)
+        if kind == 1:   # after the adaptation steps the step is frozen at the averaged value
+            assert np.ptp(kap[n_adapt:], axis=0).max() == 0.0 and (np.abs(np.log(kap[n_adapt]) - st[:, 2]) < 1e-5).all()
+
+
+@pytest.mark.parametrize("mname,kind", [("8schools", "NCP"), ("radon_MN", "NCP"), ("election", "CP"), ("german", "NCP"),
+                                        ("radon_PA", "CP")])
 @pytest.mark.parametrize("adapt", [1, 2])
 def test_adaptation_matches_oracle(oracle_lib, gpu, mname, kind, adapt):
     """Dual-averaging / simple adaptation state after 10 adapting + 4 frozen
@@ -102,8 +136,8 @@ def test_adaptation_matches_oracle(oracle_lib, gpu, mname, kind, adapt):
     the energy error (hence the acceptance probability fed back into the step) is
     very sensitive to rounding, so states are compared on the step multiplier and
     the error sum with a 2 % tolerance rather than coordinate by coordinate."""
-    lanes = LANES[mname][-1]
-    frac = 0.002 if mname == "election" else 0.02   # keep the 10x exploration phase inside the stable region
+    lanes = LANES[mname][0] if mname in ("german", "radon_PA") else LANES[mname][-1]   # the lane counts the configs run
+    frac = 0.002 if mname in ("election", "german") else 0.02   # keep the 10x exploration phase inside the stable region
     err, terr, st, so, ta, tao = _compare(oracle_lib, gpu, mname, kind, lanes, adapt, frac, 3, 14, n_adapt=10)
     ad, ado = st.adapt.cpu().numpy()[:, :3], so["adapt"][:, :3]
     close = (np.abs(ad[:, 0] / ado[:, 0] - 1) <= 0.02) & (np.abs(ad[:, 1] - ado[:, 1]) <= 0.02)

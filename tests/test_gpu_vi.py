@@ -91,3 +91,71 @@ def test_discrete_prior_term(oracle_lib, gpu):
     fd = (p.log_prob(x + h) - p.log_prob(x - h)) / (2 * h)
     l0, l1 = 5 * np.exp(-10 * x), 5 * np.exp(-10 * (1 - x))
     np.testing.assert_allclose(10 * (l1 - l0) / (l0 + np.exp(5.0) + l1), fd, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("mname", ["election", "german"])
+def test_untied_cvip_shares_scalar_shaped_parameters(oracle_lib, gpu, mname):
+    """--notied_pparams: the reference creates `<rv>_a` with the shape of the variable's loc and `<rv>_b` with the
+    shape of its scale (program_transformations.py:486-533), so election's a[51] and german's beta_log_scales[62]
+    -- vector variables with a scalar loc -- learn ONE shared a.  Same run against the oracle; the shared elements
+    stay equal; the kernel's gradient of the shared variable is the sum over the part (checked against ed2_ref's
+    autograd with a broadcast a)."""
+    from autoreparam_amd import engine
+    sp = helpers.spec(mname)
+    eng = engine.Engine(sp, gpu)
+    orc = oracle_lib.OracleModel(sp)
+    ag, bg = sp.untied_groups()
+    part = {"election": "a", "german": "beta_log_scales"}[mname]
+    k = sp.part_names.index(part); lo_, hi_ = sp.offsets[k], sp.offsets[k + 1]
+    assert (ag[lo_:hi_] == lo_).all() and (bg == np.arange(sp.D)).all() and sp.untied_shape(part, "a") == ()
+    a = np.full(sp.D, 0.5, np.float32); b = np.full(sp.D, 0.5, np.float32)
+    eng.set_param(0, (a, b))
+    rs = np.random.RandomState(3)
+    loc0 = (1e-2 * rs.randn(1, sp.D)).astype(np.float32); rho0 = np.full((1, sp.D), -2.0, np.float32)
+    z = np.zeros((1, sp.D), np.float32)
+    loc, rho, w, wb = (torch.as_tensor(v.copy(), device=gpu) for v in (loc0, rho0, z, z))
+    n = 120
+    elbo = eng.vi_run([0.05], loc, rho, n, 256, w=w, wb=wb, seed=6, a_group=ag, b_group=bg).cpu().numpy()
+    lo, ro, wo, wbo = loc0.copy(), rho0.copy(), z.copy(), z.copy()
+    elbo_o = orc.vi_run(a, b, [0.05], lo, ro, wo, n, 256, learn_a=True, seed=6, lanes=VI_LANES[mname], wb=wbo,
+                        a_group=ag, b_group=bg)
+    np.testing.assert_allclose(elbo[:, :5], elbo_o[:, :5], rtol=2e-5, atol=2e-2)
+    np.testing.assert_allclose(elbo[:, -32:].mean(1), elbo_o[:, -32:].mean(1), rtol=2e-3, atol=0.5)
+    wg = w.cpu().numpy()[0]
+    assert np.ptp(wg[lo_:hi_]) == 0.0 and abs(wg[lo_]) > 1e-3          # one shared value, and it moved
+    assert np.ptp(wb.cpu().numpy()[0][lo_:hi_]) > 0.0                   # b keeps the scale's (vector) shape
+    np.testing.assert_allclose(wg, wo[0], rtol=0, atol=0.1 * (np.abs(wo).max() + 0.5))
+    # d logp / d(shared a) == sum over the part of the per-element derivative, against float64 autograd of the
+    # Edward2 restatement evaluated with a broadcast scalar a
+    import oracle.ed2_ref as ed2
+    x = helpers.states(sp, 1, seed=9, scale=0.2).astype(np.float64)[0]
+    av = rs.rand(sp.D).astype(np.float32).astype(np.float64); av[lo_:hi_] = av[lo_]
+    bv = rs.rand(sp.D).astype(np.float32).astype(np.float64)
+    da, _ = orc.dparam(x[None], av.astype(np.float32), bv.astype(np.float32))
+    h = 1e-4
+
+    def lj(scalar_a):      # the reference's shapes: `<part>_a` is a scalar that broadcasts over the part
+        ab = ed2.ab_dict(sp, av, bv)
+        ab[part + "_a"] = np.float64(scalar_a)
+        return ed2.log_joint(sp, ab, x)[0]
+    fd = (lj(av[lo_] + h) - lj(av[lo_] - h)) / (2 * h)
+    assert abs(da[0, lo_:hi_].sum() - fd) <= 1e-6 * (abs(fd) + 1.0)
+
+
+def test_discrete_prior_ranks_on_elbo_plus_prior(gpu, tmp_path):
+    """find_best_learning_rate with --discrete_prior: the timeline it returns and ranks the learning rates on is
+    elbo + prior, the value it reports is that minus the prior (reference inference.py:50-54, 120-150)."""
+    from autoreparam_amd import flags as flags_mod, graphs, inference, models
+    cfg = models.get_model_by_name("8schools")
+    f = flags_mod.FlagValues()
+    f.num_optimization_steps, f.learning_rates = 200, [0.05, 0.1]
+    _, _, elbo, vp, lp = graphs.make_cvip_graph(cfg, tied_pparams=True, flags=f)
+    e1, tl1, lr1, _, _, rp1 = inference.find_best_learning_rate(elbo, vp, inference.DiscretePrior(), lp, flags=f)
+    e0, tl0, lr0, _, _, rp0 = inference.find_best_learning_rate(elbo, vp, None, lp, flags=f)
+    prior = inference.DiscretePrior()
+    lp_final = sum(float(np.sum(prior.log_prob(v))) for k, v in rp1.items() if k.endswith("_a"))
+    # the reported value is the mean of (elbo + prior) over the last 32 steps minus the mean prior over them; the prior
+    # of the final parameters is within the drift of those 32 steps of it
+    assert abs((np.mean(tl1[-32:]) - e1) - lp_final) < 0.2 * abs(lp_final) + 0.05
+    assert np.mean(tl1[-32:]) < e1                       # log prior < 0 (density < 1 everywhere on (0, 1))
+    assert abs(np.mean(tl0[-32:]) - e0) < 1e-9           # no prior: the timeline is the ELBO itself

@@ -30,7 +30,7 @@ def one(pattern, required=True):
         if required:
             raise SystemExit("missing " + pattern)
         return None
-    return f[0]
+    return max(f, key=os.path.getmtime)     # gpurun merges into gpurun_out/: older runs' files may still be there
 
 
 def short(name):
