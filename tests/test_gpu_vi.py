@@ -123,7 +123,8 @@ def test_untied_cvip_shares_scalar_shaped_parameters(oracle_lib, gpu, mname):
     np.testing.assert_allclose(elbo[:, -32:].mean(1), elbo_o[:, -32:].mean(1), rtol=2e-3, atol=0.5)
     wg = w.cpu().numpy()[0]
     assert np.ptp(wg[lo_:hi_]) == 0.0 and abs(wg[lo_]) > 1e-3          # one shared value, and it moved
-    assert np.ptp(wb.cpu().numpy()[0][lo_:hi_]) > 0.0                   # b keeps the scale's (vector) shape
+    if mname == "election":    # b keeps the scale's (vector) shape; german's beta_log_scales has unit scale, so its b is inert
+        assert np.ptp(wb.cpu().numpy()[0][lo_:hi_]) > 0.0
     np.testing.assert_allclose(wg, wo[0], rtol=0, atol=0.1 * (np.abs(wo).max() + 0.5))
     # d logp / d(shared a) == sum over the part of the per-element derivative, against float64 autograd of the
     # Edward2 restatement evaluated with a broadcast scalar a
@@ -157,5 +158,6 @@ def test_discrete_prior_ranks_on_elbo_plus_prior(gpu, tmp_path):
     # the reported value is the mean of (elbo + prior) over the last 32 steps minus the mean prior over them; the prior
     # of the final parameters is within the drift of those 32 steps of it
     assert abs((np.mean(tl1[-32:]) - e1) - lp_final) < 0.2 * abs(lp_final) + 0.05
-    assert np.mean(tl1[-32:]) < e1                       # log prior < 0 (density < 1 everywhere on (0, 1))
+    assert abs(np.mean(tl1[-32:]) - e1) > 1e-3          # the prior term is in the timeline (its density is ~1.02 near
+    #                                                      the ends of (0, 1) and ~0.99 in the middle: small either way)
     assert abs(np.mean(tl0[-32:]) - e0) < 1e-9           # no prior: the timeline is the ELBO itself
