@@ -38,6 +38,20 @@ struct HmcParams {
 };
 
 
+// Lane models that keep chain-independent tables in LDS declare SMEM_FLOATS, stage_tables(Args, smem) (all threads of the
+// workgroup) and bind_tables(smem); every kernel gives them the block before Lane::init.
+template <class L, class = void> struct lane_smem { static constexpr int value = 0; };
+template <class L> struct lane_smem<L, std::void_t<decltype(L::SMEM_FLOATS)>> { static constexpr int value = L::SMEM_FLOATS; };
+template <class Lane>
+ARP_DEV void lane_tables(Lane& M, const typename Lane::Args& A, float* smem) {
+  if constexpr (lane_smem<Lane>::value > 0) {
+    Lane::stage_tables(A, smem);
+    __syncthreads();
+    M.bind_tables(smem);
+  }
+}
+#define ARP_LANE_SMEM(Lane) __shared__ __attribute__((aligned(16))) float s_lane_tab[lane_smem<Lane>::value > 0 ? lane_smem<Lane>::value : 4]
+
 // ---------------------------------------------------------------------------
 // Row I/O in the reference layout [C][D].  Lane `slot` of a chain owns the
 // replicated globals (flattened index M.gg(i)) and NL sliced elements at
@@ -241,7 +255,9 @@ __global__ __launch_bounds__(kBlock) void logp_grad_kernel(
   long long c = t / K;
   bool live = c < C;
   long long cc = live ? c : (long long)C - 1;  // dead lanes shadow the last chain (keeps DPP groups uniform)
+  ARP_LANE_SMEM(Lane);
   Lane M;
+  lane_tables(M, A, s_lane_tab);
   M.init(A, av, bv, slot);
   float q[ND], g[ND];
   load_row(M, x + cc * D, q);
@@ -261,7 +277,9 @@ __global__ __launch_bounds__(kBlock) void transform_kernel(
   long long c = t / K;
   bool live = c < C;
   long long cc = live ? c : (long long)C - 1;
+  ARP_LANE_SMEM(Lane);
   Lane M;
+  lane_tables(M, A, s_lane_tab);
   M.init(A, av, bv, slot);
   float a[ND], b[ND];
   load_row(M, in + cc * D, a);
@@ -408,7 +426,9 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
   const bool live = c < P.C;
   if (!live) c = P.C - 1;  // shadow lanes compute on the last chain but never store
   const int D = P.D;
+  ARP_LANE_SMEM(Lane);
   Lane M;
+  lane_tables(M, A, s_lane_tab);
   M.init(A, av, bv, slot);
 
   // base step sizes stay in LDS for the whole launch: re-reading them from global
@@ -534,7 +554,9 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
   const bool live = c < P.C;
   if (!live) c = P.C - 1;
   const int D = P.D;
+  ARP_LANE_SMEM(Lane);
   Lane M;
+  lane_tables(M, A, s_lane_tab);
   M.init(A, av0, bv0, slot);
 
   __shared__ float s_eps[2][kMaxD];
@@ -731,6 +753,7 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
     s_a[tid] = av[tid]; s_b[tid] = bv[tid];
   }
   const float base_lr = P.lr[lr_i];
+  ARP_LANE_SMEM(Lane);
   // untied parameterisation variables that the reference creates with the shape of a SCALAR loc / scale while the
   // random variable is a vector (program_transformations.py:486-533): one value shared by the part, owned by its
   // first element (the leader); members are contiguous
@@ -747,6 +770,7 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
   }
   Lane M;
   __syncthreads();
+  lane_tables(M, A, s_lane_tab);
   M.init(A, s_a, s_b, slot);
   Rng rng[1];
   // one stream per (learning rate, first-pass sample, slot); later passes continue it

@@ -43,10 +43,37 @@ struct ElectionLane {
   static constexpr bool HAS_VI = true;
   static constexpr bool HAS_MODE_STATE = true;    // si / cs of the top-level scalars follow b (set_mode)
   static constexpr bool HAS_MODE_B1 = true;       // MODE 3: a free, b = 1 (tied cVIP / dVIP as the reference executes them)
-  static constexpr int MINW = K_ == 4 ? 2 : 1;   // waves per SIMD the register allocator must leave room for
+  // three waves per SIMD at K = 4 (LDS: 51 KB per workgroup, three fit a CU): the 4 reciprocals + 1 exponential per state
+  // are dependent-latency bound, and a third wave buys 7 % even though the 168-register cap spills a few values
+  static constexpr int MINW = K_ == 4 ? 3 : 2;
   using Args = ElectionArgs;
 
-  float cn[NL][4], cy[NL][4], al[NL], be[NL];
+  // The cell tables (n, y of the four (female, black) cells of every state) live in LDS, not in registers: they are
+  // the same for every chain, 104 registers per lane at K = 4 -- with them in VGPRs the chain kernels spill inside
+  // the leapfrog loop.  A state's eight numbers are two 16-byte reads at an address shared by the 64/K chains of the wave.
+  static constexpr int SMEM_FLOATS = 8 * K_ * NL_;
+  const float4* tab;
+  static ARP_DEV void stage_tables(const Args& A, float* smem) {
+    for (int idx = threadIdx.x; idx < K * NL; idx += blockDim.x) {
+      const int i = idx / K, t = (idx % K) + K * i;
+      const bool cell = t <= A.S;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        smem[idx * 8 + c] = cell ? A.cell_n[t * 4 + c] : 0.0f;
+        smem[idx * 8 + 4 + c] = cell ? A.cell_y[t * 4 + c] : 0.0f;
+      }
+    }
+  }
+  ARP_DEV void bind_tables(const float* smem) { tab = reinterpret_cast<const float4*>(smem); }
+  // (n, y) of slice i.  The index is laundered so that the reads stay inside the pass that uses them: hoisted out
+  // of the leapfrog loop they would be 8 registers per state again.
+  ARP_DEV void cells(int i, float4& n4, float4& y4) const {
+    int k = (i * K + slot) * 2;
+    asm volatile("" : "+v"(k));
+    n4 = tab[k]; y4 = tab[k + 1];
+  }
+  float al[NL], be[NL];
+  float d1, d2;     // sum over the lane's cells of (y - n) that carry b1 / b2: the cell-independent part of sum y eta - n eta
   float lat_last;   // 1 if the lane's last slice is a state effect, 0 if it is the cell-only group S or padding
   // (only the last slice can be anything but a latent, see lvalid)
   ARP_DEV float lat(int i) const { return i < NL - 1 ? 1.0f : lat_last; }
@@ -73,15 +100,13 @@ struct ElectionLane {
     S = A.S;
     last_ok = slot + K * (NL - 1) < S;   // latent validity (t < S); the extra cell group t == S has no latent
     gmap[0] = 0; gmap[1] = 1; gmap[2] = 2 + S; gmap[3] = 3 + S;
+    d1 = 0.0f; d2 = 0.0f;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      int t = slot + K * i;
-      bool cell = t <= S;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        cn[i][c] = cell ? A.cell_n[t * 4 + c] : 0.0f;
-        cy[i][c] = cell ? A.cell_y[t * 4 + c] : 0.0f;
-      }
+      float4 n4, y4;
+      cells(i, n4, y4);
+      d2 += (y4.y - n4.y) + (y4.w - n4.w);     // cells with female = 1 carry b2
+      d1 += (y4.z - n4.z) + (y4.w - n4.w);     // cells with black = 1 carry b1
     }
     lat_last = slot + K * (NL - 1) < S ? 1.0f : 0.0f;
     set_param(av, bv);
@@ -142,10 +167,12 @@ struct ElectionLane {
       const float z = (qt - ai * mua) * e;
       const float as = li * fmaf(sig, z, mua);
       const float t = fast_exp(-as);
-      const float w0 = fmaf(-cn[i][0], __builtin_amdgcn_rcpf(1.0f + t), cy[i][0]);
-      const float w1 = fmaf(-cn[i][1], __builtin_amdgcn_rcpf(fmaf(t, E2, 1.0f)), cy[i][1]);
-      const float w2 = fmaf(-cn[i][2], __builtin_amdgcn_rcpf(fmaf(t, E1, 1.0f)), cy[i][2]);
-      const float w3 = fmaf(-cn[i][3], __builtin_amdgcn_rcpf(fmaf(t, E12, 1.0f)), cy[i][3]);
+      float4 n4, y4;
+      cells(i, n4, y4);
+      const float w0 = fmaf(-n4.x, __builtin_amdgcn_rcpf(1.0f + t), y4.x);
+      const float w1 = fmaf(-n4.y, __builtin_amdgcn_rcpf(fmaf(t, E2, 1.0f)), y4.y);
+      const float w2 = fmaf(-n4.z, __builtin_amdgcn_rcpf(fmaf(t, E1, 1.0f)), y4.z);
+      const float w3 = fmaf(-n4.w, __builtin_amdgcn_rcpf(fmaf(t, E12, 1.0f)), y4.w);
       const float W = (w0 + w1) + (w2 + w3);
       g_b2 += w1 + w3;
       g_b1 += w2 + w3;
@@ -172,10 +199,20 @@ struct ElectionLane {
   template <bool LOGP>
   ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const { return grad_m<LOGP, 0>(q, g); }
 
+  // Gradient (and log density when LOGP).  Two forms of the likelihood part:
+  //  * SAFE (the general form MODE 0: logp_grad_kernel, the VI kernel, arbitrary caller-supplied states): every cell
+  //    through exp(-|eta|), overflow-proof for any state;
+  //  * fast (the compile-time parameterisations, i.e. the closing gradient of every CP / NCP / b = 1 transition): the
+  //    four cells of a state share exp(-a_t) as in kick_drift, and with rc = 1 / (1 + e^-eta) = sigmoid(eta)
+  //        softplus(eta) = eta - log(rc),  so  y eta - n softplus(eta) = (y - n) eta + n log(rc):
+  //    per cell one reciprocal and one logarithm, no exponential, no |.|, no select.  e^-eta overflows only for
+  //    logits below -88, where the log density comes out -inf and the proposal is rejected (TFP's non-finite rule).
   template <bool LOGP, int MODE>
   ARP_DEV float grad_m(const float (&q)[ND], float (&g)[ND]) const {
+    constexpr bool SAFE = MODE == 0;
     const float mua = cs[0] * q[0], ls = cs[1] * q[1], b1 = cs[2] * q[2], b2 = cs[3] * q[3];
     const float sig = fast_exp(ls);
+    const float E1 = SAFE ? 0.0f : fast_exp(-b1), E2 = SAFE ? 0.0f : fast_exp(-b2), E12 = E1 * E2;
     const float eu = MODE == 2 ? 1.0f : fast_exp(-((MODE == 1 || MODE == 3) ? 1.0f : bbar) * ls);
     float g_mua = 0.0f, g_ls = 0.0f, g_b1 = 0.0f, g_b2 = 0.0f, lp = 0.0f;
 #pragma unroll
@@ -184,19 +221,38 @@ struct ElectionLane {
       const float e = MODE == 0 ? fast_exp(-be[i] * ls) : E<MODE>(i, ls, eu);
       float z = (q[NG + i] - ai * mua) * e;      // group S / padding: q = 0, a = 0 -> z = 0
       float as = li * fmaf(sig, z, mua);
-      const float eta[4] = {as, as + b2, as + b1, as + b1 + b2};
+      float4 n4, y4;
+      cells(i, n4, y4);
+      const float cn_[4] = {n4.x, n4.y, n4.z, n4.w}, cy_[4] = {y4.x, y4.y, y4.z, y4.w};
       float w[4];
+      if (SAFE) {
+        const float eta[4] = {as, as + b2, as + b1, as + b1 + b2};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        // sigmoid / softplus share exp(-|eta|)
-        float ex = fast_exp(-fabsf(eta[c]));
-        float rc = __builtin_amdgcn_rcpf(1.0f + ex);
-        float sg = eta[c] >= 0.0f ? rc : ex * rc;
-        w[c] = fmaf(-cn[i][c], sg, cy[i][c]);
-        if (LOGP) {
-          float sp = fmaxf(eta[c], 0.0f) + fast_log(1.0f + ex);
-          lp += fmaf(cy[i][c], eta[c], -cn[i][c] * sp);
+        for (int c = 0; c < 4; ++c) {
+          // sigmoid / softplus share exp(-|eta|)
+          float ex = fast_exp(-fabsf(eta[c]));
+          float rc = __builtin_amdgcn_rcpf(1.0f + ex);
+          float sg = eta[c] >= 0.0f ? rc : ex * rc;
+          w[c] = fmaf(-cn_[c], sg, cy_[c]);
+          if (LOGP) {
+            float sp = fmaxf(eta[c], 0.0f) + fast_log(1.0f + ex);
+            lp += fmaf(cy_[c], eta[c], -cn_[c] * sp);
+          }
         }
+      } else {
+        const float t = fast_exp(-as);
+        const float den[4] = {1.0f + t, fmaf(t, E2, 1.0f), fmaf(t, E1, 1.0f), fmaf(t, E12, 1.0f)};
+        float dn = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float rc = __builtin_amdgcn_rcpf(den[c]);
+          w[c] = fmaf(-cn_[c], rc, cy_[c]);
+          if (LOGP) {
+            lp = fmaf(cn_[c] * 0.6931471805599453f, __builtin_amdgcn_logf(rc), lp);    // n log(rc), v_log_f32 is log2
+            dn += cy_[c] - cn_[c];
+          }
+        }
+        if (LOGP) lp = fmaf(dn, as, lp);          // (y - n) eta, the part every cell of the state shares
       }
       float W = (w[0] + w[1]) + (w[2] + w[3]);
       g_b2 += w[1] + w[3];
@@ -207,6 +263,7 @@ struct ElectionLane {
       g_ls += fmaf(bi, fmaf(z, z, -1.0f), li * W * sig * z * (1.0f - bi));
       if (LOGP) lp += fmaf(-0.5f * z, z, -bi * ls);
     }
+    if (LOGP && !SAFE) lp = fmaf(d1, b1, fmaf(d2, b2, lp));   // (y - n) (b1 black + b2 female) over the lane's cells
     g_mua = group_sum<K>(g_mua);
     g_ls = group_sum<K>(g_ls);
     g_b1 = group_sum<K>(g_b1);

@@ -6,7 +6,7 @@ R="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$R/gpurun_out/prof"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-HL="--steps 8 --warmup 2 --no-cpu-baseline --headline-only ${BENCH_ARGS:-}"
+HL="--steps 20 --warmup 5 --no-cpu-baseline --headline-only ${BENCH_ARGS:-}"
 python3 "$R/bench.py" ${BENCH_ARGS:-} > "$OUT/bench.json" 2> "$OUT/bench.err"
 # headline kernel alone: every launch in the trace is a warm-up or timed step
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" $HL > "$OUT/trace.log" 2>&1
@@ -15,7 +15,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d "$OUT/pmc_sqa" -- python3 "$R/bench.py" $HL > "$OUT/pmc_sqa.log" 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d "$OUT/pmc_sqb" -- python3 "$R/bench.py" $HL > "$OUT/pmc_sqb.log" 2>&1
 # every kernel of the full bench (german, election, plain HMC, VI, ESS ...): kernel trace + the same SQ passes
-FULL="--steps 4 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
+FULL="--steps 20 --warmup 5 --no-cpu-baseline ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_full" -- python3 "$R/bench.py" $FULL > "$OUT/trace_full.log" 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_SALU --output-format csv -d "$OUT/pmc_full_sqa" -- python3 "$R/bench.py" $FULL --no-ess > "$OUT/pmc_full_sqa.log" 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d "$OUT/pmc_full_sqb" -- python3 "$R/bench.py" $FULL --no-ess > "$OUT/pmc_full_sqb.log" 2>&1

@@ -88,8 +88,23 @@ if "GRBM_GUI_ACTIVE" in sq:
         derived["valu_insts_per_wave_per_sampler_step"] = sq["SQ_INSTS_VALU"] / sq.get("SQ_WAVES", 1) / cfg["transitions_per_step"]
     derived["clock_ghz_estimate"] = cyc / avg_ns
 head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, stdout=subprocess.PIPE, text=True).stdout.strip()
+# the rocprofv3 average over the TIMED launches only (the last `steps` of the trace; the first launches of a process run
+# at a lower clock) next to the HIP-event figure bench.py printed in that same profiled process
+ktr = [r for r in csv.DictReader(open(one("trace/*/*_kernel_trace.csv"))) if ks in r["Kernel_Name"]]
+ktr.sort(key=lambda r: int(r["Start_Timestamp"]))
+durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ktr]
+n_timed = 20
+try:
+    line = [l for l in open(os.path.join(src, "trace.log")) if l.startswith("{")][-1]
+    prof_bench = json.loads(line)
+    n_timed = prof_bench["steps"]
+    events_ms_same_process = prof_bench["roofline"]["kernel_ms"]
+except Exception:
+    events_ms_same_process = None
+avg_timed_ns = sum(durs[-n_timed:]) / max(1, len(durs[-n_timed:]))
 summary = {
     "kernel": kname, "calls": int(dom["Calls"]), "avg_ns": avg_ns,
+    "avg_ns_timed_launches": avg_timed_ns, "hip_events_ms_same_profiled_process": events_ms_same_process,
     "percentage_of_gpu_time": float(dom["Percentage"]),
     "vgpr": int(vg["VGPR_Count"]), "agpr": int(vg["Accum_VGPR_Count"]), "sgpr": int(vg["SGPR_Count"]),
     "lds_bytes": int(vg["LDS_Block_Size"]), "scratch_bytes": int(vg["Scratch_Size"]),
@@ -106,7 +121,7 @@ summary = {
     "bench_kernel_ms_unprofiled": bench["roofline"]["kernel_ms"],
     "bench_frac_unprofiled": bench["roofline"]["frac"],
     "head": head,
-    "note": "rocprofv3 --kernel-trace --stats and separate --pmc passes of `bench.py --steps 8 --warmup 2 "
+    "note": "rocprofv3 --kernel-trace --stats and separate --pmc passes of `bench.py --steps 20 --warmup 5 "
             "--headline-only`; bench line from an un-profiled run of the same configuration (tools/profile_bench.sh)",
 }
 json.dump(summary, open(os.path.join(dst, "%s_headline.json" % tag), "w"), indent=1)
