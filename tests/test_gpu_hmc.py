@@ -346,9 +346,9 @@ def test_eight_schools_posterior_against_quadrature(gpu):
 
 
 @pytest.mark.parametrize("mname,kind,L,Cn", [("election", "CP", 8, 2048), ("german", "NCP", 8, 768), ("electric", "NCP", 8, 1024),
-                                              ("radon_sd_MN", "CP", 8, 1024)])
+                                              ("radon_sd_MN", "CP", 8, 1024), ("time_series", "CP", 64, 512)])
 def test_posterior_moments_against_long_cpu_run(gpu, mname, kind, L, Cn):
-    """election / german credit / electric / radon_stddvs have no closed-form posterior: the known answer is a long float64
+    """election / german credit / electric / radon_stddvs / time_series have no closed-form posterior: the known answer is a long float64
     oracle run committed with Monte-Carlo error bars (tests/golden/posterior_golden.npz)."""
     import os
     from autoreparam_amd import engine, _lib
@@ -362,6 +362,8 @@ def test_posterior_moments_against_long_cpu_run(gpu, mname, kind, L, Cn):
     q0 = (mode + 0.5 * sc * rs.randn(Cn, sp.D)).astype(np.float32)     # mode / scale are in `kind` coordinates
     st = engine.ChainState(torch.as_tensor(q0, device=gpu))
     burn, S = 1500, (600 if mname == "german" else 300)   # german's log-scale coordinates mix slowly
+    if mname == "time_series":                            # 123 latents chained in time: long trajectories, long burn-in
+        burn, S = 8000, 600
     tr = torch.zeros(S, Cn, sp.D, device=gpu)
     eng.hmc_run(st, (0.5 * sc).astype(np.float32), L, 1 + burn + 2 * (S - 1), seed=77, adapt_kind=_lib.ADAPT_DUAL,
                 n_adapt=burn - 200, n_burnin=burn, thin=2, trace=tr, trace_centered=True)
