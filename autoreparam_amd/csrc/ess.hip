@@ -2,8 +2,7 @@
 // semantics with its defaults (reference inference.py:240, 327; restated from the published definition):
 //   rho_k = c_k / c_0,  c_k = sum_{t < S-k} (x_t - m)(x_{t+k} - m) / (S - k),
 //   every lag from the first negative rho on is dropped,  ESS = S / (-1 + 2 sum_k (S - k)/S rho_k).
-// Chains that mix stop within a few dozen lags, so the autocovariances are formed directly, eight
-// lags per pass over the series and only until the first negative one -- no FFT, no work buffers,
+// The autocovariances are formed directly and only until the first negative one -- no FFT, no work buffers,
 // no plan creation.  One thread per series; consecutive threads read consecutive floats of a trace
 // row, so every pass streams the trace coalesced.  Sums are accumulated in double.
 #include <hip/hip_runtime.h>
@@ -12,7 +11,66 @@
 
 namespace arp {
 
-constexpr int kEssLags = 8;
+#ifndef ARP_ESS_WIN
+#define ARP_ESS_WIN 16
+#endif
+constexpr int kEssWin = ARP_ESS_WIN;      // lags 1..kEssWin come out of the first pass over the series
+
+// One sweep over a series forms kEssWin consecutive auto-covariance sums at once, lags kb+1 .. kb+16 (and c_0 when
+// kb == 0): the 16 mean-removed values y_{t-kb-1} .. y_{t-kb-16} sit in a register window that is addressed at compile
+// time (the time loop is unrolled by the window length, so nothing is ever shifted), 17 accumulators next to it.  Chains
+// that mix stop within a few dozen lags, so with the mean pass almost every series is done after two coalesced sweeps of
+// the trace; a series whose first 16 auto-correlations are all positive takes another sweep per 16 lags.
+// Loads are issued in batches of 16 independent rows (a thread's consecutive samples are a whole trace row apart: one
+// load per iteration with its wait is latency bound -- the first version of this kernel was, at 29 ms for 18.6 GB).
+// Accumulation is in float, flushed into doubles every 256 samples (v_fma_f64 issues several times slower than
+// v_fma_f32 and made the sweep compute bound); no float sum is longer than 256 products.
+template <bool FIRST>
+__device__ __forceinline__ void ess_sweep(const float* __restrict__ x, long long S, long long stride, float mean,
+                                          long long kb, double (&dacc)[kEssWin + 1]) {
+  float acc[kEssWin + 1];
+  float w[kEssWin];          // w[tt] = y at time t0 + tt - kb of the previous window (0 before the series starts)
+#pragma unroll
+  for (int j = 0; j <= kEssWin; ++j) { acc[j] = 0.0f; dacc[j] = 0.0; }
+#pragma unroll
+  for (int j = 0; j < kEssWin; ++j) w[j] = 0.0f;
+  // window t0: times t0 .. t0+15 of the leading stream; the lagged stream runs kb behind.  Start where the lagged
+  // stream starts (t0 = kb, rounded down to a window): products with times before 0 are zeros.
+  for (long long t0 = 0; t0 < S; t0 += kEssWin) {
+    float xv[kEssWin], xl[kEssWin];
+    if (t0 + kEssWin <= S) {
+#pragma unroll
+      for (int tt = 0; tt < kEssWin; ++tt) xv[tt] = x[(t0 + tt) * stride];
+    } else {   // the last, partial window: the mean past the end, i.e. y = 0, which adds nothing
+#pragma unroll
+      for (int tt = 0; tt < kEssWin; ++tt) xv[tt] = t0 + tt < S ? x[(t0 + tt) * stride] : mean;
+    }
+    if (!FIRST) {
+      if (t0 - kb >= 0 && t0 - kb + kEssWin <= S) {
+#pragma unroll
+        for (int tt = 0; tt < kEssWin; ++tt) xl[tt] = x[(t0 + tt - kb) * stride];
+      } else {
+#pragma unroll
+        for (int tt = 0; tt < kEssWin; ++tt) {
+          const long long tl = t0 + tt - kb;
+          xl[tt] = (tl >= 0 && tl < S) ? x[tl * stride] : mean;
+        }
+      }
+    }
+#pragma unroll
+    for (int tt = 0; tt < kEssWin; ++tt) {
+      const float y = xv[tt] - mean;
+      if (FIRST) acc[0] = fmaf(y, y, acc[0]);
+#pragma unroll
+      for (int j = 1; j <= kEssWin; ++j) acc[j] = fmaf(y, w[(tt - j + 2 * kEssWin) % kEssWin], acc[j]);
+      w[tt] = FIRST ? y : xl[tt] - mean;
+    }
+    if (((t0 / kEssWin) & 7) == 7 || t0 + kEssWin >= S) {
+#pragma unroll
+      for (int j = 0; j <= kEssWin; ++j) { dacc[j] += (double)acc[j]; acc[j] = 0.0f; }
+    }
+  }
+}
 
 __global__ __launch_bounds__(256) void ess_kernel(const float* __restrict__ trace, long long S, long long n,
                                                   long long stride, float* __restrict__ ess) {
@@ -20,33 +78,34 @@ __global__ __launch_bounds__(256) void ess_kernel(const float* __restrict__ trac
   if (i >= n) return;
   const float* x = trace + i;
   double m = 0.0;
-  for (long long t = 0; t < S; ++t) m += (double)x[t * stride];
+  {
+    long long t = 0;
+    for (; t + 16 <= S; t += 16) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = x[(t + j) * stride];
+      float part = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) part += v[j];
+      m += (double)part;
+    }
+    for (; t < S; ++t) m += (double)x[t * stride];
+  }
   const float mean = (float)(m / (double)S);
-  double c0 = 0.0;
-  for (long long t = 0; t < S; ++t) { const float d = x[t * stride] - mean; c0 = fma((double)d, (double)d, c0); }
-  c0 /= (double)S;
+
+  double dacc[kEssWin + 1];
+  ess_sweep<true>(x, S, stride, mean, 0, dacc);
+  const double c0 = dacc[0] / (double)S;
   if (!(c0 > 0.0)) { ess[i] = __builtin_nanf(""); return; }   // constant series: 0/0 as in the FFT form
   double total = 1.0;   // lag 0: (S - 0)/S * rho_0
   bool done = false;
-  for (long long k0 = 1; k0 < S && !done; k0 += kEssLags) {
-    // lags k0 .. k0+7 in one pass: acc[j] = sum_t y_t * y_{t - k0 - j}
-    double acc[kEssLags];
-    float w[kEssLags];   // w[j] = y_{t - k0 - j}
+  for (long long kb = 0; kb < S && !done; kb += kEssWin) {
+    if (kb > 0) ess_sweep<false>(x, S, stride, mean, kb, dacc);
 #pragma unroll
-    for (int j = 0; j < kEssLags; ++j) { acc[j] = 0.0; w[j] = 0.0f; }
-    for (long long t = k0; t < S; ++t) {
-      const float yt = x[t * stride] - mean;
-#pragma unroll
-      for (int j = kEssLags - 1; j > 0; --j) w[j] = w[j - 1];
-      w[0] = x[(t - k0) * stride] - mean;
-#pragma unroll
-      for (int j = 0; j < kEssLags; ++j) acc[j] = fma((double)yt, (double)w[j], acc[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < kEssLags; ++j) {
-      const long long k = k0 + j;
-      if (done || k >= S) break;
-      const double rho = acc[j] / (double)(S - k) / c0;
+    for (int j = 1; j <= kEssWin; ++j) {
+      const long long k = kb + j;
+      if (done || k >= S) { done = true; break; }
+      const double rho = dacc[j] / (double)(S - k) / c0;
       if (rho < 0.0) { done = true; break; }
       total += (double)(S - k) / (double)S * rho;
     }

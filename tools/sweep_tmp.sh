@@ -1,5 +1,3 @@
-R=$GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q -k "election or density or vi_" 2>&1 | tail -3
-for lib in "" $R/autoreparam_amd/libautoreparam_hip_el3.so; do
-ARP_LIB_PATH=$lib python tools/model_sweep.py election 2>&1 | tail -12
-done
+python -m pytest tests -m gpu -x -q -k "ess or cli" 2>&1 | tail -3
+python tools/ess_breakdown.py 8 | tail -1
+python tools/ess_breakdown.py 2 | tail -1
