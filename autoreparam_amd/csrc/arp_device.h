@@ -30,6 +30,11 @@ ARP_DEV float dpp_mov(float v) {
 // row mirror).
 template <int K>
 ARP_DEV float group_sum(float v) {
+  // The argument is made opaque first: with -ffp-contract=fast a multiply that feeds the first add would be fused into
+  // it, fma(x_own, y, round(x_partner y)) -- own product unrounded, partner's rounded -- and the K lanes would no
+  // longer hold the same bits (seen as a run that depended on how it was cut into launches: the replicated top-level
+  // scalars are stored from slot 0 only).
+  if (K >= 2) asm volatile("" : "+v"(v));
   if (K >= 2) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
   if (K >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
   if (K >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror

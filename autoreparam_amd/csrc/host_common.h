@@ -11,6 +11,7 @@
 #include "kernels.h"
 #include "model_radon.h"
 #include "radon_fast.h"
+#include "election_fast.h"
 #include "model_schools.h"
 #include "model_election.h"
 #include "model_german.h"
@@ -119,18 +120,38 @@ LaneOps radon_lane_ops() {
   if constexpr (K >= 4) {
     using T = RadonPk<K, NL>;
     o.hmc_cp = [](const void* args, const float*, const float*, const HmcParams& P, hipStream_t s) {
-      hipLaunchKernelGGL((radon_hmc_kernel<T, kModeCP>), dim3(Launch<RadonLane<K, NL>>::blocks(P.C)), dim3(kBlock), 0, s,
-                         *(const RadonArgs*)args, P);
+      hipLaunchKernelGGL((pk_hmc_kernel<T, kModeCP>), dim3(Launch<RadonLane<K, NL>>::blocks(P.C)), dim3(kBlock), 0, s,
+                         *(const RadonArgs*)args, nullptr, nullptr, P);
     };
     o.hmc_ncp = [](const void* args, const float*, const float*, const HmcParams& P, hipStream_t s) {
-      hipLaunchKernelGGL((radon_hmc_kernel<T, kModeNCP>), dim3(Launch<RadonLane<K, NL>>::blocks(P.C)), dim3(kBlock), 0, s,
-                         *(const RadonArgs*)args, P);
+      hipLaunchKernelGGL((pk_hmc_kernel<T, kModeNCP>), dim3(Launch<RadonLane<K, NL>>::blocks(P.C)), dim3(kBlock), 0, s,
+                         *(const RadonArgs*)args, nullptr, nullptr, P);
     };
     o.interleaved_cp_ncp = [](const void* args, const float*, const float*, const float*, const float*,
                               const HmcParams& P, hipStream_t s) {
       hipLaunchKernelGGL((radon_interleaved_kernel<T>), dim3(Launch<RadonLane<K, NL>>::blocks(P.C)), dim3(kBlock), 0, s,
                          *(const RadonArgs*)args, P);
     };
+  }
+  return o;
+}
+
+// Election: the generic lane kernels serve the general VIP form and the interleaved sampler, the packed kernels
+// (election_fast.h on pk_chain.h) the three compile-time parameterisations of a plain HMC run.
+template <int K, int NL>
+LaneOps election_lane_ops() {
+  LaneOps o = Launch<ElectionLane<K, NL>>::ops();
+  if constexpr (K >= 4) {
+    using T = ElectionPk<K, NL>;
+#define ARP_EL(MODE)                                                                                              \
+    [](const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s) {                     \
+      hipLaunchKernelGGL((pk_hmc_kernel<T, MODE>), dim3(Launch<ElectionLane<K, NL>>::blocks(P.C)), dim3(kBlock), 0, s, \
+                         *(const ElectionArgs*)args, a, b, P);                                                     \
+    }
+    o.hmc_cp = ARP_EL(kModeCP);
+    o.hmc_ncp = ARP_EL(kModeNCP);
+    o.hmc_b1 = ARP_EL(kModeB1);
+#undef ARP_EL
   }
   return o;
 }

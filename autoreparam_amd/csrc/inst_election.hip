@@ -5,8 +5,8 @@
 namespace arp {
 const std::vector<LaneOps>& election_ops() {
   static const std::vector<LaneOps> t = {
-      Launch<ElectionLane<4, 13>>::ops(), Launch<ElectionLane<8, 7>>::ops(),
-      Launch<ElectionLane<16, 4>>::ops(),
+      election_lane_ops<4, 13>(), election_lane_ops<8, 7>(),
+      election_lane_ops<16, 4>(),
   };
   return t;
 }

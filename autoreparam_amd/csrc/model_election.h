@@ -42,7 +42,8 @@ struct ElectionLane {
   static constexpr bool HAS_FUSED = true;    // kick_drift below
   static constexpr bool HAS_VI = true;
   static constexpr bool HAS_MODE_STATE = true;    // si / cs of the top-level scalars follow b (set_mode)
-  static constexpr bool HAS_MODE_B1 = true;       // MODE 3: a free, b = 1 (tied cVIP / dVIP as the reference executes them)
+  static constexpr bool HAS_MODE_B1 = true;
+  static constexpr int MOM_SPEC = 1;   // momentum stream layout 1 (kernels.h: hmc_transition, pk_chain.h)       // MODE 3: a free, b = 1 (tied cVIP / dVIP as the reference executes them)
   // three waves per SIMD at K = 4 (LDS: 51 KB per workgroup, three fit a CU): the 4 reciprocals + 1 exponential per state
   // are dependent-latency bound, and a third wave buys 7 % even though the 168-register cap spills a few values
   static constexpr int MINW = K_ == 4 ? 3 : 2;

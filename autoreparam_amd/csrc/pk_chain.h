@@ -1,0 +1,326 @@
+// Packed-f32 chain kernels: the transition, row I/O and the HMC kernel shared by the lane models that keep a chain's
+// sliced latents in register PAIRS (radon_fast.h, election_fast.h).  Same algorithm and random streams as the generic
+// kernels in kernels.h (stream layout 1); every per-slice operation of a transition is one v_pk_*_f32 on a pair.
+//
+// A packed lane model T provides
+//   K, NL, NG, ND, NP, DCAP, LBASE, MINW, Args, init(A, av, bv, slot), slot, gg(i), lbase(i), loff(i), lvalid(i), mlast,
+//   unpack / pack (flattened row <-> (top-level floats, pairs)),
+//   pass<MODE, PASS>(qg, qc, pg, pc, eg, ec, gg, gc, lp, ke)   PASS 0 interior (gradient, kick, drift), 1 closing
+//                    (gradient, logp, kinetic energy after the closing half kick), 2 bootstrap (gradient, logp),
+//   to_centered<MODE>(qg, qc, xg, xc).
+#pragma once
+#include "kernels.h"
+
+namespace arp {
+
+template <int K, int SRC>
+ARP_DEV float group_bcast_from(float v, int slot) {
+  static_assert(SRC < 4, "source slot must lie in the first quad");
+  if (K == 1) return v;
+  if (K == 4 || K == 2) return dpp_mov<SRC * 0x55>(v);            // quad_perm [SRC, SRC, SRC, SRC]
+  return group_sum<K>(slot == SRC ? v : 0.0f);
+}
+
+ARP_DEV v2f splat(float x) { return v2f{x, x}; }
+
+// Box-Muller pair as a register pair: (r cos, r sin) = one packed multiply
+ARP_DEV v2f normal_pair2(uint32_t w0, uint32_t w1) {
+  const float u = fmaf((float)w0, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+  const float rev = (float)w1 * 2.3283064365386963e-10f;
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));
+  const v2f cs = {__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)};
+  return cs * splat(r);
+}
+
+// Parked start-of-trajectory state, one region per WAVE (so that a wave's row staging block can alias its own region:
+// waves of a workgroup are not in step): pairs as 8-byte columns of 64 lanes, the 2 NG top-level floats as 4-byte columns
+// behind them (all conflict free: consecutive lanes touch consecutive 8- or 4-byte words).
+template <class T> constexpr int pk_save_wave_floats() { return (4 * T::NP + 2 * T::NG) * 64; }
+template <class T> constexpr int pk_save_floats() { return (kBlock / 64) * pk_save_wave_floats<T>(); }
+
+// One HMC transition (mcmc.HamiltonianMonteCarlo.one_step as wired at inference.py:218-222); the contract of
+// kernels.h: hmc_transition with the state in pairs.  Random stream layout 1 (DESIGN.md "Randomness"): a slot
+// draws one normal per county it owns, then one more, which is the momentum of top-level scalar `slot`
+// (slots 0..2), then the Metropolis word (slot 0's is used).
+template <int MODE, class T>
+ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const float* __restrict__ s_eps,
+                               float (&qg)[T::NG], v2f (&qc)[T::NP], float (&gg_)[T::NG], v2f (&gc)[T::NP], float& lp,
+                               bool& accepted, float* __restrict__ save) {
+  constexpr int K = T::K, NP = T::NP, NL = T::NL, NG = T::NG;
+  // step sizes: base steps from LDS (zero beyond D, so padding elements never move) times the chain's multiplier
+  float eg[NG]; v2f ec[NP];
+  {
+    const float* e = s_eps + T::LBASE + M.slot;
+    const v2f vk = splat(kappa);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) ec[k] = v2f{e[K * 2 * k], e[K * (2 * k + 1)]} * vk;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) eg[i] = s_eps[M.gg(i)] * kappa;
+  }
+  // park the start state
+  {
+    v2f* s2 = reinterpret_cast<v2f*>(save);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { s2[k * 64] = qc[k]; s2[(NP + k) * 64] = gc[k]; }
+    float* s1 = save + 4 * NP * 64 - (threadIdx.x & 63);   // float columns behind the pair columns
+#pragma unroll
+    for (int i = 0; i < NG; ++i) { s1[i * 64] = qg[i]; s1[(NG + i) * 64] = gg_[i]; }
+  }
+  // momenta
+  float pg[NG]; v2f pc[NP];
+  float extra;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
+    pc[k] = normal_pair2(w0, w1);
+  }
+  if (NL & 1) {
+    extra = pc[NP - 1][1];
+  } else {
+    const uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
+    extra = normal_pair2(w0, w1)[0];
+  }
+  pc[NP - 1] *= M.mlast;
+  float u = u01_open0(rng_next(rng));
+  u = group_bcast_from<K, 0>(u, M.slot);
+  static_assert(NG <= 4 && NG <= K, "one extra normal per slot covers the top-level scalars");
+  pg[0] = group_bcast_from<K, 0>(extra, M.slot);
+  if constexpr (NG > 1) pg[1] = group_bcast_from<K, 1>(extra, M.slot);
+  if constexpr (NG > 2) pg[2] = group_bcast_from<K, 2>(extra, M.slot);
+  if constexpr (NG > 3) pg[3] = group_bcast_from<K, 3>(extra, M.slot);
+  float ke0;
+  {
+    v2f a = pc[0] * pc[0];
+    const v2f half = splat(0.5f);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      if (k > 0) a = vfma(pc[k], pc[k], a);
+      // first half kick and first drift
+      pc[k] = vfma(half, ec[k] * gc[k], pc[k]);
+      qc[k] = vfma(ec[k], pc[k], qc[k]);
+    }
+    float kg = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      kg = fmaf(pg[i], pg[i], kg);
+      pg[i] = fmaf(0.5f * eg[i], gg_[i], pg[i]);
+      qg[i] = fmaf(eg[i], pg[i], qg[i]);
+    }
+    ke0 = 0.5f * (group_sum<K>(a[0] + a[1]) + kg);
+  }
+  float dlp, dke;
+  for (int l = 1; l < L; ++l) M.template pass<MODE, 0>(qg, qc, pg, pc, eg, ec, gg_, gc, dlp, dke);
+  float lp1, ke1;
+  M.template pass<MODE, 1>(qg, qc, pg, pc, eg, ec, gg_, gc, lp1, ke1);
+
+  // log accept ratio; any non-finite energy error rejects (TFP safe_sum semantics)
+  float la = (lp1 - lp) + (ke0 - ke1);
+  if (!(fabsf(la) <= 3.0e38f)) la = -INFINITY;
+  accepted = fast_log(u) < la;
+  if (!accepted) {
+    const v2f* s2 = reinterpret_cast<const v2f*>(save);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { qc[k] = s2[k * 64]; gc[k] = s2[(NP + k) * 64]; }
+    const float* s1 = save + 4 * NP * 64 - (threadIdx.x & 63);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) { qg[i] = s1[i * 64]; gg_[i] = s1[(NG + i) * 64]; }
+  }
+  lp = accepted ? lp1 : lp;
+  return la;
+}
+
+// the copy half of kernels.h: store_row_wave as a real call (cold path; keeps its address arithmetic out of the callers)
+__device__ __noinline__ void copy_stage_rows(const float* stage, float* gdst, int nvalid) {
+  const int lane = threadIdx.x & 63;
+  if ((reinterpret_cast<uintptr_t>(gdst) & 15) == 0) {
+    for (int k = lane * 4; k < nvalid; k += 256) {
+      const float4 t = *reinterpret_cast<const float4*>(stage + k);
+      if (k + 3 < nvalid) {
+        *reinterpret_cast<float4*>(gdst + k) = t;
+      } else {
+        gdst[k] = t.x;
+        if (k + 1 < nvalid) gdst[k + 1] = t.y;
+        if (k + 2 < nvalid) gdst[k + 2] = t.z;
+      }
+    }
+  } else {
+    for (int k = lane; k < nvalid; k += 64) gdst[k] = stage[k];
+  }
+}
+
+// A wave's rows (its 64/K consecutive chains) to a [C][D] array: store_row_wave of kernels.h with the state in pairs and,
+// when the wave is full and D is the instantiation's own dimension (the reference's PA: 68 = 4 x 17 counties), every
+// offset a compile-time constant -- the staging writes are ds_write2_b32 off one base, the copy is an unrolled run of
+// ds_read_b128 / global_store_dwordx4 off a wave-uniform base: no address arithmetic on the vector pipe.
+template <class T>
+ARP_DEV void pk_store_rows(const T& M, float* stage, float* gdst, int cl, int D, int nvalid,
+                              const float (&xg)[T::NG], const v2f (&xc)[T::NP]) {
+  constexpr int K = T::K, NL = T::NL, DC = T::DCAP, NV = (64 / K) * DC;
+  if (D == DC && nvalid == NV && (NV & 3) == 0 && (reinterpret_cast<uintptr_t>(gdst) & 15) == 0) {
+    float* row = stage + cl * DC;
+    if (M.slot == 0) {
+#pragma unroll
+      for (int i = 0; i < T::NG; ++i) row[M.gg(i)] = xg[i];
+    }
+    float* e = row + T::LBASE + M.slot;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) e[K * i] = xc[i >> 1][i & 1];      // D == DCAP: every slice is a real county
+    __builtin_amdgcn_wave_barrier();
+    // the lane's word index is formed afresh here: kept live across the sampling loop it would cost a register the
+    // chain kernels do not have
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    lane &= 63;
+    const float4* s4 = reinterpret_cast<const float4*>(stage);
+    float4* g4 = reinterpret_cast<float4*>(gdst);
+#pragma unroll
+    for (int it = 0; it < (NV / 4 + 63) / 64; ++it) {
+      const int k = lane + 64 * it;
+      if ((it + 1) * 64 <= NV / 4 || k < NV / 4) g4[k] = s4[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+  } else {   // ragged tail of the launch, or a county count that leaves padding: general offsets, out-of-line copy
+    float* row = stage + cl * D;
+    if (M.slot == 0) {
+#pragma unroll
+      for (int i = 0; i < T::NG; ++i) row[M.gg(i)] = xg[i];
+    }
+    float* e = row + T::LBASE + M.slot;
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (M.lvalid(i)) e[K * i] = xc[i >> 1][i & 1];
+    __builtin_amdgcn_wave_barrier();
+    copy_stage_rows(stage, gdst, nvalid);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// LDS of one 256-thread workgroup of the packed chain kernels
+
+template <class T>
+struct PkBlock {
+  // LDS of one 256-thread workgroup: the parked start-of-trajectory state, which also serves as the waves' row staging
+  // blocks (a row is staged only between transitions, when the parked state is dead), and the base step sizes
+  static constexpr int kSave = pk_save_floats<T>();
+  static constexpr int kStage = (kBlock / 64) * stage_floats<T>();
+  static_assert(stage_floats<T>() <= pk_save_wave_floats<T>(), "a wave's staging block aliases its own parked state");
+  static constexpr int kEps = (T::LBASE + 2 * T::K * T::NP + 4 + 3) & ~3;   // every index a lane forms, zero beyond D
+};
+
+template <class T, int MODE>
+__global__ __launch_bounds__(kBlock, T::MINW) void pk_hmc_kernel(typename T::Args A, const float* __restrict__ av,
+                                                                const float* __restrict__ bv, HmcParams P) {
+  constexpr int K = T::K, NP = T::NP, ND = T::ND, NG = T::NG;
+  // chain of this lane (a launch holds fewer than 2^31 / K chains: 32-bit lane arithmetic)
+  const unsigned t = blockIdx.x * (unsigned)kBlock + threadIdx.x;
+  const int slot = (int)(t % K);
+  int c = (int)(t / K);
+  const bool live = c < P.C;
+  if (!live) c = P.C - 1;  // shadow lanes compute on the last chain but never store
+  const int D = P.D;
+  ARP_LANE_SMEM(T);
+  T M;
+  lane_tables(M, A, s_lane_tab);
+  M.init(A, av, bv, slot);
+
+  __shared__ float s_eps[PkBlock<T>::kEps];
+  __shared__ __attribute__((aligned(16))) float s_save[PkBlock<T>::kSave];
+  // this wave's region: pair columns addressed as v2f[lane], the float columns behind them as float[lane]
+  float* wsave = s_save + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * pk_save_wave_floats<T>();
+  float* save = wsave + 2 * (threadIdx.x & 63);
+  float* stage = wsave;   // the wave's staging block aliases its own parked state (dead between transitions)
+  // first chain of this wave: wave-uniform, kept in SGPRs so that row addresses are scalar arithmetic
+  const long long cw0 = (long long)((blockIdx.x * (unsigned)kBlock + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x & ~63)) / K);
+  const int cl = (threadIdx.x & 63) / K;
+  const int nvalid = (int)(P.C - cw0 < 64 / K ? (P.C - cw0 > 0 ? P.C - cw0 : 0) : 64 / K) * D;
+  for (int d = threadIdx.x; d < PkBlock<T>::kEps; d += kBlock) s_eps[d] = d < D ? P.eps0[d] : 0.0f;
+  __syncthreads();
+
+  float qg[NG], gg_[NG]; v2f qc[NP], gc[NP];
+  float lp;
+  {
+    float v[ND];
+    load_row(M, P.q + (size_t)c * D, v);
+    T::unpack(v, qg, qc);
+    if (P.step_base == 0) {
+      float pg[NG] = {}, eg[NG] = {}; v2f pc[NP], ec[NP]; float ke;
+      M.template pass<MODE, 2>(qg, qc, pg, pc, eg, ec, gg_, gc, lp, ke);
+    } else {
+      load_row(M, P.grad + (size_t)c * D, v);
+      T::unpack(v, gg_, gc);
+      lp = P.logp[c];
+    }
+  }
+  float kappa, esum, logavg;
+  Rng rng;
+  uint32_t* rs = P.rng + ((size_t)c * kRngSlots + slot) * 4;
+  if (P.step_base == 0) {
+    kappa = 1.0f; esum = 0.0f; logavg = 0.0f;
+    rng = rng_seed(P.seed, (unsigned long long)(P.chain_offset + c), (uint32_t)slot, (uint32_t)K);
+  } else {
+    kappa = P.adapt[(size_t)c * 4 + 0]; esum = P.adapt[(size_t)c * 4 + 1]; logavg = P.adapt[(size_t)c * 4 + 2];
+    rng = Rng{rs[0], rs[1]};
+  }
+  uint32_t nacc = (P.step_base == 0) ? 0u : P.accept_count[c];
+
+  int next_rec = P.rec_step, rec_row = P.rec_row, bpos = P.stats_bpos;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing loaded is awaited inside the loop (kernels.h: hmc_kernel)
+  for (int s = 0; s < P.n_steps; ++s) {
+    bool acc;
+    const float la = pk_transition<MODE>(M, rng, P.L, kappa, s_eps, qg, qc, gg_, gc, lp, acc, save);
+    nacc += acc ? 1u : 0u;
+    const long long n = P.step_base + s + 1;
+    adapt_update(P, n, la, kappa, esum, logavg);
+
+    if (s == next_rec && rec_row < P.n_samples) {
+      const bool to_trace = P.trace && cw0 < P.trace_chains;
+      if (to_trace || P.stats) {
+        float xg[NG]; v2f xc[NP];
+        if (P.trace_centered) {
+          M.template to_centered<MODE>(qg, qc, xg, xc);
+        } else {   // the state as it is
+#pragma unroll
+          for (int i = 0; i < NG; ++i) xg[i] = qg[i];
+#pragma unroll
+          for (int k = 0; k < NP; ++k) xc[k] = qc[k];
+        }
+        if (to_trace) {
+          const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
+          pk_store_rows(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, xg, xc);
+        }
+        if (P.stats) {
+          float x[ND];
+          T::pack(xg, xc, x);
+          stats_update_wave(M, stage, P, cw0, cl, D, nvalid, x, rec_row == 0, bpos + 1 == P.stats_batch);
+          bpos = bpos + 1 == P.stats_batch ? 0 : bpos + 1;
+        }
+      }
+      if (live && slot == 0) {
+        // 32-bit lane offsets off wave-uniform bases, formed here: no per-lane pointer stays live across the sampling loop
+        unsigned ci = (unsigned)c;
+        asm volatile("" : "+v"(ci));
+        if (P.trace_accept) (P.trace_accept + (size_t)rec_row * P.C)[ci] = acc ? 1 : 0;
+        if (P.rec_accept) P.rec_accept[ci] += acc ? 1u : 0u;
+      }
+      next_rec += P.thin;
+      rec_row += 1;
+    }
+  }
+
+  size_t c2 = (size_t)c;
+  asm volatile("" : "+v"(c2));
+  const long long cw2 = cw0;
+  pk_store_rows(M, stage, P.q + cw2 * D, cl, D, nvalid, qg, qc);
+  pk_store_rows(M, stage, P.grad + cw2 * D, cl, D, nvalid, gg_, gc);
+  if (live) {
+    uint32_t* rs2 = P.rng + ((size_t)c2 * kRngSlots + slot) * 4;
+    rs2[0] = rng.x; rs2[1] = rng.c; rs2[2] = 0u; rs2[3] = 0u;
+    if (slot == 0) {
+      P.logp[c2] = lp;
+      P.adapt[c2 * 4 + 0] = kappa; P.adapt[c2 * 4 + 1] = esum; P.adapt[c2 * 4 + 2] = logavg;
+      P.accept_count[c2] = nacc;
+    }
+  }
+}
+
+}  // namespace arp

@@ -208,7 +208,7 @@ orc_model* orc_election_create(int N, int S, const int32_t* state, const float* 
                                const float* black, const float* y) {
   orc_model* M = (orc_model*)calloc(1, sizeof(orc_model));
   M->model = 3; M->S = S; M->N = N; M->D = S + 4;
-  M->n_glob = 4; M->n_groups = S + 1; M->n_local_parts = 1;
+  M->n_glob = 4; M->n_groups = S + 1; M->n_local_parts = 1; M->mom_spec = 1;
   M->glob_idx[0] = 0; M->glob_idx[1] = 1; M->glob_idx[2] = 2 + S; M->glob_idx[3] = 3 + S;
   M->group_idx = (int*)malloc(sizeof(int) * (S + 1));
   for (int t = 0; t < S; ++t) M->group_idx[t] = 2 + t;

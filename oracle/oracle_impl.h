@@ -135,8 +135,11 @@ static REAL FN(election_logp_grad)(const orc_model* M, const float* a, const flo
   const REAL c0 = 100 / s0, c1 = 10 / s1, cb1 = 100 / sb1, cb2 = 100 / sb2;
   const REAL mua = c0 * x[0], ls = c1 * x[1], b1 = cb1 * x[iB1], b2 = cb2 * x[iB2];
   const REAL sig = (REAL)exp((double)ls);
-  REAL lp = -(REAL)0.5 * ((x[0] / s0) * (x[0] / s0) + (x[1] / s1) * (x[1] / s1) +
-                          (x[iB1] / sb1) * (x[iB1] / sb1) + (x[iB2] / sb2) * (x[iB2] / sb2));
+  /* the log density is a sum of ~260 terms of size 10 .. 10^4 whose DIFFERENCES between states decide the Metropolis
+   * test: the terms are formed in REAL, the running sum is kept in double (a float running sum of a value ~10^4 .. 10^5
+   * is off by 5e-3 .. 7e-2, several times the device path's error, which sums per lane and per state pair) */
+  double lp = -0.5 * (double)((x[0] / s0) * (x[0] / s0) + (x[1] / s1) * (x[1] / s1) +
+                              (x[iB1] / sb1) * (x[iB1] / sb1) + (x[iB2] / sb2) * (x[iB2] / sb2));
   REAL g_mua = 0, g_ls = 0, g_b1 = 0, g_b2 = 0;
   for (int t = 0; t <= S; ++t) {               /* t == S: observations without a state effect */
     REAL as = 0, z = 0, e = 0, at = 0, bt = 0;
@@ -154,12 +157,12 @@ static REAL FN(election_logp_grad)(const orc_model* M, const float* a, const flo
       const REAL eta = as + f * b2 + k * b1;
       const REAL sp = (eta > 0 ? eta : 0) + (REAL)log1p(exp(-fabs((double)eta)));
       const REAL sgm = (REAL)(1.0 / (1.0 + exp(-(double)eta)));
-      lp += y * eta - n * sp;
+      lp += (double)(y * eta - n * sp);
       const REAL w = y - n * sgm;
       W += w; g_b2 += f * w; g_b1 += k * w;
     }
     if (t < S) {
-      lp += -(REAL)0.5 * z * z - bt * ls;
+      lp += (double)(-(REAL)0.5 * z * z - bt * ls);
       const REAL gt = e * (sig * W - z);
       g[2 + t] = gt;
       g_mua += W - at * gt;
@@ -170,7 +173,7 @@ static REAL FN(election_logp_grad)(const orc_model* M, const float* a, const flo
   g[1] = -x[1] / (s1 * s1) + c1 * g_ls;
   g[iB1] = -x[iB1] / (sb1 * sb1) + cb1 * g_b1;
   g[iB2] = -x[iB2] / (sb2 * sb2) + cb2 * g_b2;
-  return lp;
+  return (REAL)lp;
 }
 static void FN(election_convert)(const orc_model* M, const float* a, const float* b, const REAL* x,
                                  REAL* out, int to_centered) {

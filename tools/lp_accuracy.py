@@ -1,0 +1,23 @@
+"""How accurate are the chain kernels' cached log densities?  HIP (float32) and the float32 oracle against the float64 oracle."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import helpers, oracle
+from autoreparam_amd import engine
+oracle.build()
+for mname, kinds in (("election", ("CP", "NCP", "B1")), ("radon_PA", ("CP", "NCP")), ("german", ("NCP",))):
+    sp = helpers.spec(mname); orc = oracle.OracleModel(sp); eng = engine.Engine(sp, "cuda:0")
+    for kind in kinds:
+        a, b = helpers.params(sp, kind)
+        eng.set_param(0, (a, b))
+        q0 = helpers.states(sp, 512, seed=2, scale=0.1)
+        st = engine.ChainState(torch.as_tensor(q0, device="cuda:0"))
+        eng.hmc_run(st, np.zeros(sp.D, np.float32), 2, 1, seed=1, lanes=4)      # zero step: the state does not move
+        lp_hip = st.logp.cpu().numpy().astype(np.float64)
+        lp64, _ = orc.logp_grad(q0.astype(np.float64), a, b)
+        lp32, _ = orc.logp_grad(q0, a, b, dtype=np.float32)
+        lp_dens, _ = eng.logp_grad(q0)                                            # the general (SAFE) form
+        print("%-9s %-3s |logp| %.0f  hip-chain %.2e  hip-density-kernel %.2e  oracle-f32 %.2e  (max abs error vs float64)" % (
+            mname, kind, np.abs(lp64).max(), np.abs(lp_hip - lp64).max(), np.abs(lp_dens.cpu().numpy() - lp64).max(),
+            np.abs(lp32.astype(np.float64) - lp64).max()))
