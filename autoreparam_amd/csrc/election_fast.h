@@ -23,6 +23,7 @@ struct ElectionPk {
   static constexpr int LBASE = 2;
   static_assert(K_ >= 4, "the packed kernels deal the top-level momenta out over the first slots of a chain");
   static_assert(NL_ >= 3, "at least two state pairs per lane");
+  // three waves per SIMD (measured at K = 4: four waves cap the lane at 128 registers, spill 26 values and run 4 % slower)
   static constexpr int MINW = NL_ <= 13 ? 3 : 2;
   using Args = ElectionArgs;
 
