@@ -113,11 +113,13 @@ ARP_DEV float u01_open0(uint32_t w) { return (float)((w >> 8) + 1u) * 5.96046447
 
 // Two standard normals from two 32-bit words (Box-Muller on the hardware
 // transcendental units: v_log_f32 is log2, v_sin/v_cos take revolutions).
-// u = (float)w0 * 2^-32 + 2^-33 lies in (0, 1] after rounding, the angle (float)w1 * 2^-32 in [0, 1]
-// revolutions (1 == 0 for sin/cos): one conversion and one multiply-add each, no shifts.
+// u = (float)w0 * 2^-32 + 2^-33 lies in (0, 1] after rounding (one conversion and one multiply-add, no shifts); the
+// angle is the float in [1, 2) whose mantissa is the low 23 bits of w1, in revolutions (sin/cos are periodic, so the
+// leading 1 is free): one v_and_or_b32 instead of a conversion (half rate on gfx950) and a multiply.
+ARP_DEV float angle_rev(uint32_t w1) { return __uint_as_float(0x3f800000u | (w1 & 0x007fffffu)); }
 ARP_DEV void normal_pair(uint32_t w0, uint32_t w1, float& z0, float& z1) {
   float u = fmaf((float)w0, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-  float rev = (float)w1 * 2.3283064365386963e-10f;
+  float rev = angle_rev(w1);
   // r = sqrt(-2 ln u) = sqrt(-2 ln2 * log2 u)
   float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));
   z0 = r * __builtin_amdgcn_cosf(rev);

@@ -395,6 +395,10 @@ ARP_DEV void adapt_update(const HmcParams& P, long long n, float la,
   const int kind = P.adapt_kind, n_adapt = P.n_adapt;
   const float target = P.adapt_target, rate = P.adapt_rate;
   if (kind == ARP_ADAPT_NONE) return;
+  if (kind == ARP_ADAPT_SIMPLE) {   // log(target) < 0, so comparing la itself equals comparing min(la, 0)
+    if (n <= n_adapt) kappa *= la > P.adapt_log_target ? 1.0f + rate : P.adapt_inv_opr;
+    return;
+  }
   float lacc = fminf(la, 0.0f);
   if (kind == ARP_ADAPT_DUAL) {
     if (n <= n_adapt) {

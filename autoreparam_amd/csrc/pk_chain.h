@@ -26,7 +26,7 @@ ARP_DEV v2f splat(float x) { return v2f{x, x}; }
 // Box-Muller pair as a register pair: (r cos, r sin) = one packed multiply
 ARP_DEV v2f normal_pair2(uint32_t w0, uint32_t w1) {
   const float u = fmaf((float)w0, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-  const float rev = (float)w1 * 2.3283064365386963e-10f;
+  const float rev = angle_rev(w1);
   const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));
   const v2f cs = {__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)};
   return cs * splat(r);

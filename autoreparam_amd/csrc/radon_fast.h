@@ -88,7 +88,7 @@ struct RadonPk {
     const float mua = qg[0], b1 = qg[1], b2 = qg[2];
     const v2f vb1 = splat(b1), vnb2 = splat(-b2), vmua = splat(mua);
     const v2f vmua_last = vmua * mlast;     // padding: mu = 0 there (its u is 0), so r = m = 0
-    v2f ah[2], auh[2], ams[2];      // two accumulator sets (even / odd pairs), seeded by their first terms
+    v2f ah[1], auh[1], ams[1];      // accumulators, seeded by the first pair's terms
     v2f alp = splat(0.0f), ake = splat(0.0f);
     const v2f half = splat(0.5f);
 #pragma unroll
@@ -101,12 +101,12 @@ struct RadonPk {
       const v2f l = vfma(-n2[k], m, t);
       const v2f gm = l - r;
       const v2f h = (MODE == kModeCP) ? r : l;
-      if (k < 2) {
-        ah[k & 1] = h; auh[k & 1] = u2[k] * h; ams[k & 1] = m * sx2[k];
+      if (k == 0) {
+        ah[0] = h; auh[0] = u2[k] * h; ams[0] = m * sx2[k];
       } else {
-        ah[k & 1] += h;
-        auh[k & 1] = vfma(u2[k], h, auh[k & 1]);
-        ams[k & 1] = vfma(m, sx2[k], ams[k & 1]);
+        ah[0] += h;
+        auh[0] = vfma(u2[k], h, auh[0]);
+        ams[0] = vfma(m, sx2[k], ams[0]);
       }
       if (PASS == 0) {
         const v2f pn = vfma(ec[k], gm, pc[k]);
@@ -121,7 +121,7 @@ struct RadonPk {
         }
       }
     }
-    const v2f th = ah[0] + ah[1], tuh = auh[0] + auh[1], tms = ams[0] + ams[1];
+    const v2f th = ah[0], tuh = auh[0], tms = ams[0];
     const float s_h = group_sum<K>(th[0] + th[1]);
     const float s_uh = group_sum<K>(tuh[0] + tuh[1]);
     const float s_ms = group_sum<K>(tms[0] + tms[1]);

@@ -98,11 +98,12 @@ static orc_rng orc_rng_seed(uint64_t seed, uint64_t chain, uint32_t slot, uint32
   return r;
 }
 
-/* Box-Muller: u = (float)w0 2^-32 + 2^-33 in (0,1], angle (float)w1 2^-32 revolutions
- * (uint32 -> float conversions round to nearest even, as v_cvt_f32_u32 does) */
+/* Box-Muller: u = (float)w0 2^-32 + 2^-33 in (0,1] (uint32 -> float conversions round to nearest even, as
+ * v_cvt_f32_u32 does); angle = the low 23 bits of w1 as the fraction of a revolution (the device builds the float
+ * 1.fraction and lets sin/cos drop the leading 1) */
 static void orc_normal_pair(uint32_t w0, uint32_t w1, float* z0, float* z1) {
   float u = fmaf((float)w0, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-  float rev = (float)w1 * 2.3283064365386963e-10f;
+  float rev = (float)(w1 & 0x007fffffu) * 1.1920928955078125e-07f;   /* exact: 23 bits x 2^-23 */
   float r = sqrtf(-1.3862943611198906f * log2f(u));
   float ang = 6.283185307179586f * rev;
   *z0 = r * cosf(ang);

@@ -3,6 +3,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from autoreparam_amd import flags as flags_mod
@@ -133,3 +134,39 @@ def test_analyze_reports(tmp_path):
     lines = analyze.report_ess(res, normalize_times=True)
     assert len(lines) == 2 and "8 leapfrog steps" in lines[0]
     analyze.main(["--results_dir", str(tmp_path), "--elbos", "--ess", "--reparams"])
+
+
+def test_untied_parameter_shapes_follow_the_reference():
+    """--notied_pparams: `<rv>_a` has the shape of the variable's loc, `<rv>_b` of its scale
+    (program_transformations.py:486-533): vector variables with a scalar loc / scale share one value."""
+    import helpers
+    from autoreparam_amd import flags as flags_mod, graphs, models
+    sp = helpers.spec("election")
+    ag, bg = sp.untied_groups()
+    k = sp.part_names.index("a"); lo, hi = sp.offsets[k], sp.offsets[k + 1]
+    assert (ag[lo:hi] == lo).all() and (ag[:lo] == np.arange(lo)).all() and (bg == np.arange(sp.D)).all()
+    assert sp.untied_shape("a", "a") == () and sp.untied_shape("a", "b") == (51,)
+    sp = helpers.spec("electric")
+    ag, bg = sp.untied_groups()
+    for name in ("mua", "sigma_y", "b"):
+        k = sp.part_names.index(name); assert (ag[sp.offsets[k]:sp.offsets[k + 1]] == sp.offsets[k]).all()
+    k = sp.part_names.index("a"); assert (bg[sp.offsets[k]:sp.offsets[k + 1]] == sp.offsets[k]).all()
+    sp = helpers.spec("radon_MN")
+    ag, bg = sp.untied_groups()
+    assert (ag == np.arange(sp.D)).all() and (bg == np.arange(sp.D)).all()      # m: loc and scale are both [J]
+    # the cVIP graph carries those shapes; the tied graph the broadcast (per element) ones
+    cfg = models.get_model_by_name("german_credit_lognormalcentered")
+    f = flags_mod.FlagValues()
+    _, _, _, _, init = graphs.make_cvip_graph(cfg, tied_pparams=False, flags=f)
+    assert np.shape(init["beta_log_scales_a"]) == () and np.shape(init["beta_log_scales_b"]) == (62,)
+    _, _, _, _, init = graphs.make_cvip_graph(cfg, tied_pparams=True, flags=f)
+    assert np.shape(init["beta_log_scales_a"]) == (62,) and "beta_log_scales_b" not in init
+    # a scalar entry broadcasts over its part when the parameterisation is applied
+    a, b = cfg.model.ab_from_reparam({"overall_log_scale_a": 0.3, "beta_log_scales_a": np.float32(0.25), "beta_a": np.full(62, 0.5)})
+    assert (a[1:63] == 0.25).all() and (b == 1).all()
+
+
+def test_unsupported_flag_fails_loudly():
+    from autoreparam_amd import flags as flags_mod, main as cli
+    with pytest.raises(NotImplementedError):
+        cli.main(["--model=8schools", "--reparameterise_variational"], flags=flags_mod.FlagValues())
