@@ -207,13 +207,33 @@ static int build_german(arp_model* m, const arp_dataset* d) {
     return 1;
   }
   m->D = 1 + 2 * F; m->n_groups = F;
-  m->host_tables.assign((size_t)N * kGermanCols + N, 0.0f);
+  // [N][64] rows + outcomes (the 8- and 16-lane likelihoods), then the image the matrix-core likelihood copies
+  // into LDS with LDS-DMA (model_german.h, "tile image"): per 128 observations 32 pieces of 4 rows x 64 columns,
+  // each [feature block k][row][chunk ^ piece][4], and one piece of outcomes
+  const size_t plain = ((size_t)N * kGermanCols + N + 255) & ~(size_t)255;
+  const int nt = (N + kGermanTileRows - 1) / kGermanTileRows;
+  m->host_tables.assign(plain + (size_t)nt * kGermanImgTile, 0.0f);
   for (int n = 0; n < N; ++n)
     for (int f = 0; f < F; ++f) m->host_tables[(size_t)n * kGermanCols + f] = d->X_host[(size_t)n * F + f];
   for (int n = 0; n < N; ++n) m->host_tables[(size_t)N * kGermanCols + n] = d->y_host[n];
+  for (int t = 0; t < nt; ++t) {
+    float* img = m->host_tables.data() + plain + (size_t)t * kGermanImgTile;
+    for (int r = 0; r < kGermanTileRows; ++r) {
+      const int n = t * kGermanTileRows + r;
+      if (n >= N) break;
+      const int blk = r >> 4, p = (r >> 2) & 3, rho = r & 3;
+      float* piece = img + (blk * 4 + p) * 256;
+      for (int f = 0; f < F; ++f) {
+        const int k = f >> 4, c = (f >> 2) & 3, w = f & 3;
+        piece[k * 64 + rho * 16 + ((c ^ p) << 2) + w] = d->X_host[(size_t)n * F + f];
+      }
+      img[32 * 256 + r] = d->y_host[n];
+    }
+  }
   if (upload_tables(m)) return 1;
   m->german.X = m->dev_tables;
   m->german.y = m->dev_tables + (size_t)N * kGermanCols;
+  m->german.Xt = m->dev_tables + plain;
   m->german.N = N; m->german.F = F;
   m->const_base = -(1.0 + 2.0 * F) * kHalfLog2Pi;
   m->top_scale = {{0, log(10.0)}};

@@ -89,6 +89,23 @@ ARP_DEV void store_row(const Lane& M, float* __restrict__ row, const float (&v)[
 // ---------------------------------------------------------------------------
 template <class Lane>
 constexpr int stage_floats() { return (((64 / Lane::K) * Lane::DCAP) + 3) & ~3; }
+// The chain kernels' per-wave row-staging blocks.  A lane model whose gradient owns a large LDS work area that is idle
+// between gradients (German credit's tile buffers) lends it instead: STAGE_ALIAS = true, stage_mem() (at least
+// kStageCap floats), and its grad() must open with a workgroup barrier before it writes the area.
+template <class L, class = void> struct lane_stage_alias { static constexpr bool value = false; };
+template <class L> struct lane_stage_alias<L, std::void_t<decltype(L::STAGE_ALIAS)>> { static constexpr bool value = L::STAGE_ALIAS; };
+template <class Lane>
+ARP_DEV float* lane_stage(float* own) {
+  if constexpr (lane_stage_alias<Lane>::value) {
+    static_assert((kBlock / 64) * stage_floats<Lane>() <= Lane::kStageCap, "the lent area holds every wave's staging block");
+    return Lane::stage_mem();
+  } else {
+    return own;
+  }
+}
+#define ARP_STAGE_SMEM(Lane)                                                                                              \
+  __shared__ __attribute__((aligned(16))) float s_stage_own[lane_stage_alias<Lane>::value ? 4 : (kBlock / 64) * stage_floats<Lane>()]; \
+  float* const s_stage = lane_stage<Lane>(s_stage_own)
 
 template <class Lane>
 ARP_DEV void store_row_wave(const Lane& M, float* stage, float* gdst, int cl, int D, int nvalid,
@@ -439,7 +456,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
   // memory every transition would queue behind the trace stores (vmcnt is in order)
   __shared__ float s_eps[kMaxD];
   __shared__ float s_save[2 * ND * kBlock];   // parked start-of-trajectory state, one column per lane
-  __shared__ __attribute__((aligned(16))) float s_stage[(kBlock / 64) * stage_floats<Lane>()];
+  ARP_STAGE_SMEM(Lane);
   float* save = s_save + threadIdx.x;
   float* stage = s_stage + (threadIdx.x >> 6) * stage_floats<Lane>();
   // first chain of this wave, this lane's chain within the wave, floats of the wave's live chains
@@ -565,7 +582,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
 
   __shared__ float s_eps[2][kMaxD];
   __shared__ float s_save[2 * ND * kBlock];
-  __shared__ __attribute__((aligned(16))) float s_stage[(kBlock / 64) * stage_floats<Lane>()];
+  ARP_STAGE_SMEM(Lane);
   float* save = s_save + threadIdx.x;
   float* stage = s_stage + (threadIdx.x >> 6) * stage_floats<Lane>();
   const long long cw0 = ((long long)blockIdx.x * kBlock + (threadIdx.x & ~63)) / K;

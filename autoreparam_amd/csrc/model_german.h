@@ -21,10 +21,21 @@
 namespace arp {
 
 constexpr int kGermanCols = 64;   // padded row length of the device design matrix
+// Tile image of the matrix-core likelihood (built by arp_api.hip: build_german): the design matrix in tiles of 128
+// observations, each stored as the exact byte image of its LDS copy so that LDS-DMA (global_load_lds_dwordx4: 64 lanes
+// x 16 contiguous bytes per instruction, no registers, no VALU) moves it.  A tile is 32 pieces of 1 KiB -- piece
+// (block b = row / 16, p = row / 4 % 4) holds 4 rows as [feature block k = col / 16][row % 4][chunk c ^ p][4 floats],
+// c = col / 4 % 4 -- followed by one piece with the 128 outcomes.  In LDS the pieces of a block sit 1088 bytes apart
+// (64 bytes of padding each): with the chunk XOR this makes both operand reads of the matrix-core products bank
+// conflict free (16 rows x one 16-byte chunk as ds_read_b128; 4 rows x 16 consecutive columns per lane group as
+// ds_read2st64_b32), checked lane by lane against the gfx950 bank rules.
+constexpr int kGermanTileRows = 128;
+constexpr int kGermanImgTile = 33 * 256;   // floats per tile of the image
 
 struct GermanArgs {
   const float* X;   // [N][64] row-major, columns >= F are zero
   const float* y;   // [N]
+  const float* Xt;  // tile image, ceil(N / 128) x kGermanImgTile floats
   int N, F;
 };
 
@@ -48,7 +59,7 @@ struct GermanLane {
 
   float a[NLS], b[NLS];     // a of bls_d, b of beta_d (the only ones that matter)
   float s0i, c0;            // 1/10^b0, 10^(1-b0)
-  const float* X; const float* y;
+  const float* X; const float* y; const float* Xt;
   int N, F, slot, nown;
 
   static ARP_DEV int gg(int) { return 0; }
@@ -59,7 +70,7 @@ struct GermanLane {
 
   ARP_DEV void init(const Args& A, const float* av, const float* bv, int slot_) {
     slot = slot_;
-    X = A.X; y = A.y; N = A.N; F = A.F;
+    X = A.X; y = A.y; Xt = A.Xt; N = A.N; F = A.F;
     nown = F - slot * NLS;
     nown = nown < 0 ? 0 : (nown > NLS ? NLS : nown);
     set_param(av, bv);
@@ -75,17 +86,25 @@ struct GermanLane {
     }
   }
 
-  // LDS row stride of the design-matrix tile.  The matrix-core path (K = 4) pads rows to 68 floats:
-  // both of its operand reads (16 consecutive rows x one float4, and 4 rows x 16 consecutive
-  // columns per lane group) then fall on distinct banks.
-  static constexpr int kStride = K_ == 4 ? kGermanCols + 4 : kGermanCols;
-  // rows per LDS tile: the matrix-core path amortises its two workgroup barriers and the tile hand-over
-  // over 128 rows; the others keep 64 so that two workgroups fit a CU
-  static constexpr int kRows = K_ == 4 ? 128 : 64;
+  // K = 8, 16: [rows][64] tile of 64 observations + outcomes, filled through registers (fill_tile).
+  // K = 4 (matrix cores): two buffers of the tile image (8 blocks of 16 rows, 4352 bytes each), two of outcomes, and a
+  // per-wave exchange area.
+  static constexpr int kStride = kGermanCols;
+  static constexpr int kRows = K_ == 4 ? kGermanTileRows : 64;
+  static constexpr int kBlkB = 4 * 1088;              // bytes of a 16-row block in LDS
+  static constexpr int kXBufB = (kGermanTileRows / 16) * kBlkB;
+  static constexpr int kYBufB = 1024;
+  static constexpr int kXchStride = kGermanCols + 4;  // exchange rows padded: conflict-free float4 access both ways
   static constexpr int kXchWaves = W_;                // waves per workgroup the exchange area covers
   static constexpr bool HAS_VI = W_ == kViBlock / 64;   // the VI kernel is built from the lanes sized for its 8 waves
-  static constexpr int kXch = 16 * kStride + 64;      // per wave: [16 chains][row] + 64 log-density partials
-  static constexpr int kTileFloats = kRows * kStride + kRows + (K_ == 4 ? kXchWaves * kXch : 0);
+  static constexpr int kXch = 16 * kXchStride + 64;   // per wave: [16 chains][row] + 64 log-density partials
+  static constexpr int kXchBase = (2 * kXBufB + 2 * kYBufB) / 4;
+  static constexpr int kTileFloats = K_ == 4 ? kXchBase + kXchWaves * kXch : kRows * kStride + kRows;
+  // The chain kernels' row-staging block (kernels.h: ARP_STAGE_SMEM) aliases tile buffer 0: it is used between
+  // gradients only, and grad() opens with a workgroup barrier before anything is copied into that buffer.
+  static constexpr bool STAGE_ALIAS = K_ == 4;
+  static ARP_DEV float* stage_mem() { return tile_mem(); }
+  static constexpr int kStageCap = kXBufB / 4;
   // The [rows x 64] design-matrix tile and its outcomes, shared by the workgroup (one copy per
   // kernel: both instantiations of grad<> go through this function).
   static ARP_DEV float* tile_mem() {
@@ -257,64 +276,68 @@ struct GermanLane {
   // Likelihood pass for K = 4 on the matrix cores.  A wave holds 16 chains; logits = X beta is
   // a [obs x 64] x [64 x 16 chains] product and v = X^T (y - sigmoid(logits)) a
   // [64 x obs] x [obs x 16 chains] one, both with f32 inputs and f32 accumulation
-  // (v_mfma_f32_16x16x4_f32: exact f32 FMAs at the vector FMA rate, but X is read from LDS once
-  // per 16 chains instead of once per chain, every (observation, chain) sigmoid is evaluated
-  // exactly once, and the VALU is left to the sigmoids).
+  // (v_mfma_f32_16x16x4_f32: exact f32 FMAs at the vector FMA rate -- and on the vector FMA datapath: vector
+  // instructions of ANY wave on the SIMD wait while an f32 MFMA runs, tools/mfma_overlap.hip -- but X is read from
+  // LDS once per 16 chains instead of once per chain and every (observation, chain) sigmoid is evaluated exactly once).
   //   state layout : lane 4c+t   holds beta[16t .. 16t+15] of chain c
   //   MFMA layout  : lane 16g+j  supplies B[k = g][col = chain j]; a 16 x 16 result has
   //                  col = chain j on the lane and rows 4g .. 4g+3 in its 4 registers
-  // beta moves to the MFMA layout (and v back) through a per-wave LDS area, once per gradient.
+  // beta moves to the MFMA layout (and v back) through a per-wave LDS area, once per gradient; it is scaled by
+  // -log2(e) on the way, so the forward product delivers the argument of v_exp_f32 directly.
   // Forward, per 16 rows: 16 steps of k = 4, step s taking column 16g+s from lane group g (the
   // order of a sum is free as long as A and B agree).  The residuals come out with rows 4g+r in
   // register r, which is exactly the B operand of the backward product if its step s takes
   // row 4g+s from lane group g: no movement between the two products.
-  // one tile in flight between global memory and LDS (kTileF4 float4 per thread)
-  static constexpr int kTileF4 = kRows * (kGermanCols / 4) / (64 * W_);
-  struct TileRegs {
-    float4 x[kTileF4];
-    float y;
-  };
-  ARP_DEV void fetch_tile(int n0, TileRegs& T) const {
-    const int rows = min(kRows, N - n0);
-    const float4* src = reinterpret_cast<const float4*>(X + (size_t)n0 * kGermanCols);
-    const int nthreads = blockDim.x;
-#pragma unroll
-    for (int k = 0; k < kTileF4; ++k) {
-      const int t = threadIdx.x + k * nthreads;
-      T.x[k] = t < rows * (kGermanCols / 4) ? src[t] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    T.y = (int)threadIdx.x < rows ? y[n0 + threadIdx.x] : 0.0f;
+  //
+  // Tiles of 128 observations travel global memory -> LDS by LDS-DMA (see "tile image" above) into two buffers: while
+  // tile n is multiplied, tile n+1 lands; one workgroup barrier per tile (everybody has finished tile n-1 and
+  // everybody's pieces of tile n have landed).  Tile n uses buffer (n + tiles) & 1, so the last tile of a gradient is
+  // always in buffer 1 and buffer 0 is free for the kernels' row staging between gradients.
+  static ARP_DEV void glds16(const float* sbase, uint32_t voff, uint32_t lds_dst) {
+    unsigned keep;   // M0 = LDS destination of the wave's 1 KiB; compiler-reserved, so saved and restored in the statement
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
   }
-  ARP_DEV void store_tile(float* tile, const TileRegs& T) const {
-    float4* dst = reinterpret_cast<float4*>(tile);
-    const int nthreads = blockDim.x;
+  // this wave's share of tile n into buffer `buf`: 32 / W pieces of the design matrix, wave 0 also the outcomes
+  ARP_DEV void issue_tile(int n, int buf, uint32_t tile_off, int wv, int lane) const {
+    constexpr int PW = 32 / W_;
+    const float* src = Xt + (size_t)n * kGermanImgTile;
+    const uint32_t xb0 = tile_off + (uint32_t)buf * kXBufB;
+    const uint32_t voff = (uint32_t)lane * 16u;
 #pragma unroll
-    for (int k = 0; k < kTileF4; ++k) {
-      const int t = threadIdx.x + k * nthreads;
-      if (t < kRows * (kGermanCols / 4)) dst[(t >> 4) * (kStride / 4) + (t & 15)] = T.x[k];
+    for (int p = 0; p < PW; ++p) {
+      const int P = wv * PW + p;   // piece: block P / 4, rows 4 (P % 4) ..
+      glds16(src + P * 256, voff, xb0 + (uint32_t)((P >> 2) * kBlkB + (P & 3) * 1088));
     }
-    if ((int)threadIdx.x < kRows) tile[kRows * kStride + threadIdx.x] = T.y;
+    if (wv == 0) glds16(src + 32 * 256, voff, tile_off + 2u * kXBufB + (uint32_t)buf * kYBufB);
   }
   // LDS reads of the matrix-core path, pinned with inline asm a block ahead of their use (see the
   // note at Rows4: left to the scheduler they sink to the first use and the single wave per SIMD
   // waits out every LDS round trip with the matrix pipe idle).
-  // A operand of the forward product for rows r0 .. r0+15: lane (g, j) takes row r0+j, columns 16g .. 16g+15.
-  static ARP_DEV void issue_a(uint32_t a_off, v4f (&xa)[4]) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(xa[0]) : "v"(a_off));
-    asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(xa[1]) : "v"(a_off));
-    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(xa[2]) : "v"(a_off));
-    asm volatile("ds_read_b128 %0, %1 offset:48" : "=v"(xa[3]) : "v"(a_off));
+  // A operand of the forward product for rows r0 .. r0+15 of block BLK: lane (g, j) takes row r0+j, columns
+  // 16g .. 16g+15 (feature block g), chunk i from a_off[i] (the chunk XOR differs from lane to lane).
+  template <int BLK>
+  static ARP_DEV void issue_a(const uint32_t (&a_off)[4], v4f (&xa)[4]) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[0]) : "v"(a_off[0]), "n"(BLK * kBlkB));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[1]) : "v"(a_off[1]), "n"(BLK * kBlkB));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[2]) : "v"(a_off[2]), "n"(BLK * kBlkB));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[3]) : "v"(a_off[3]), "n"(BLK * kBlkB));
   }
-  // A operand of the backward product for rows r0 .. r0+15: lane (g, j) takes rows r0+4g+s (s < 4),
-  // columns j+16k (k < 4): xb[2s + k/2][k%2]; plus the four outcomes of its rows.
-  static ARP_DEV void issue_y(uint32_t y_off, v4f& y4) { asm volatile("ds_read_b128 %0, %1" : "=v"(y4) : "v"(y_off)); }
-  static ARP_DEV void issue_b(uint32_t b_off, v2f (&xb)[8]) {
-    static_assert(3 * kStride + 48 <= 255, "ds_read2_b32 offsets are 8 bits of dwords");
-#define ARP_RD2(i, o0, o1) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(xb[i]) : "v"(b_off), "n"(o0), "n"(o1))
-    ARP_RD2(0, 0, 16); ARP_RD2(1, 32, 48);
-    ARP_RD2(2, kStride, kStride + 16); ARP_RD2(3, kStride + 32, kStride + 48);
-    ARP_RD2(4, 2 * kStride, 2 * kStride + 16); ARP_RD2(5, 2 * kStride + 32, 2 * kStride + 48);
-    ARP_RD2(6, 3 * kStride, 3 * kStride + 16); ARP_RD2(7, 3 * kStride + 32, 3 * kStride + 48);
+  template <int BLK>
+  static ARP_DEV void issue_y(uint32_t y_off, v4f& y4) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(y4) : "v"(y_off), "n"(BLK * 64));
+  }
+  // A operand of the backward product for block BLK: lane (g, j) takes rows r0+4g+s (s < 4) from b_off[s],
+  // columns j+16k (k < 4): xb[2s + k/2][k%2].  Feature blocks are 256 bytes apart and a block is 17 x 256 bytes,
+  // so ds_read2st64_b32 (offsets in units of 256 bytes) reaches every block from one address.
+  template <int BLK>
+  static ARP_DEV void issue_b(const uint32_t (&b_off)[4], v2f (&xb)[8]) {
+    static_assert(kBlkB == 17 * 256 && 17 * (kGermanTileRows / 16 - 1) + 3 <= 255, "ds_read2st64_b32 offsets are 8 bits");
+#define ARP_RD2(i, s_, o0) asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(xb[i]) : "v"(b_off[s_]), "n"(o0), "n"((o0) + 1))
+    ARP_RD2(0, 0, 17 * BLK); ARP_RD2(1, 0, 17 * BLK + 2);
+    ARP_RD2(2, 1, 17 * BLK); ARP_RD2(3, 1, 17 * BLK + 2);
+    ARP_RD2(4, 2, 17 * BLK); ARP_RD2(5, 2, 17 * BLK + 2);
+    ARP_RD2(6, 3, 17 * BLK); ARP_RD2(7, 3, 17 * BLK + 2);
 #undef ARP_RD2
   }
   // the reads of (y4, xa) / xb have landed once at most NEWER younger LDS reads are outstanding
@@ -342,18 +365,19 @@ struct GermanLane {
       e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(s_ + 1) >> 2][(s_ + 1) & 3], bB[s_ + 1], e1, 0, 0, 0);
     }
   }
-  // y - sigmoid(eta) of one row (and its log density term)
+  // y - sigmoid(eta) of one row (and its log density term); z = -eta log2(e) comes out of the forward product
   template <bool LOGP>
-  static ARP_DEV float residual(float eta, float yv, bool valid, float& lp) {
+  static ARP_DEV float residual(float z, float yv, bool valid, float& lp) {
     if (LOGP) {
-      const float ex = fast_exp(-fabsf(eta));
+      const float eta = -0.6931471805599453f * z;
+      const float ex = __builtin_amdgcn_exp2f(-fabsf(z));
       const float rc = __builtin_amdgcn_rcpf(1.0f + ex);
       const float tt = fmaf(yv, eta, -(fmaxf(eta, 0.0f) + fast_log(1.0f + ex)));
       lp += valid ? tt : 0.0f;
-      return yv - (eta >= 0.0f ? rc : ex * rc);
+      return yv - (z <= 0.0f ? rc : ex * rc);
     }
     // 1 / (1 + e^-eta): e^-eta = inf gives 0, no NaN
-    return yv - __builtin_amdgcn_rcpf(1.0f + fast_exp(-eta));
+    return yv - __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
   }
   // step s of the backward product: four feature blocks, independent accumulators
   static ARP_DEV void backward_step(const v2f (&xb)[8], int s_, float w, v4f (&acc)[4]) {
@@ -365,19 +389,17 @@ struct GermanLane {
   // Block I (rows 16 I .. 16 I + 15) of a tile, see likelihood_mfma.  Program order:
   //   issue  B(I) (backward operands), Y(I+1) (outcomes), A(I+2) (forward operands)
   //   R1     forward MFMAs of block I+1 with the four residuals of block I spread between them
-  //          (one wave per SIMD: a VALU run longer than the ~24 spare issue cycles of an MFMA
-  //          leaves the matrix pipe idle, so the scheduler is told to alternate 1 MFMA : 2 VALU)
   //   R2     backward MFMAs of block I
   template <bool LOGP, int I>
-  static ARP_DEV void mfma_block(uint32_t a_off, uint32_t b_off, uint32_t y_off, int gk, int rows,
+  static ARP_DEV void mfma_block(const uint32_t (&a_off)[4], const uint32_t (&b_off)[4], uint32_t y_off, int gk, int rows,
                                  const float (&bB)[16], v4f (&xa)[2][4], v2f (&xb)[8], v4f (&y4)[2],
                                  v4f (&e0)[2], v4f (&e1)[2], v4f (&acc)[4], float& lp) {
     constexpr int r0 = 16 * I, cur = I & 1, nxt = (I + 1) & 1;
     constexpr bool F1 = I + 1 < kRows / 16, F2 = I + 2 < kRows / 16;
     const int row = r0 + 4 * gk;   // rows of a lane's four residuals: row + r
-    issue_b(b_off + r0 * kStride * 4, xb);
-    if (F1) issue_y(y_off + (r0 + 16) * 4, y4[nxt]);
-    if (F2) issue_a(a_off + (r0 + 32) * kStride * 4, xa[cur]);
+    issue_b<I>(b_off, xb);
+    if (F1) issue_y<I + 1>(y_off, y4[nxt]);
+    if (F2) issue_a<F2 ? I + 2 : 0>(a_off, xa[cur]);
     if (F1) wait_a<8 + 1 + (F2 ? 4 : 0)>(xa[nxt], y4[cur]);
     else wait_y<8>(y4[cur]);
     __builtin_amdgcn_sched_barrier(0);
@@ -405,7 +427,7 @@ struct GermanLane {
 
   // blocks I, I+1, ... of a tile
   template <bool LOGP, int I>
-  static ARP_DEV void mfma_blocks(uint32_t a_off, uint32_t b_off, uint32_t y_off, int gk, int rows,
+  static ARP_DEV void mfma_blocks(const uint32_t (&a_off)[4], const uint32_t (&b_off)[4], uint32_t y_off, int gk, int rows,
                                   const float (&bB)[16], v4f (&xa)[2][4], v2f (&xb)[8], v4f (&y4)[2],
                                   v4f (&e0)[2], v4f (&e1)[2], v4f (&acc)[4], float& lp) {
     if constexpr (I < kRows / 16) {
@@ -419,18 +441,25 @@ struct GermanLane {
     static_assert(NLS == 16, "K = 4 owns 16 features per lane");
     float* tile = tile_mem();
     const int lane = threadIdx.x & 63;
-    float* xch = tile + kRows * kStride + kRows + (threadIdx.x >> 6) * kXch;
-    float* lpx = xch + 16 * kStride;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* xch = tile + kXchBase + wv * kXch;
+    float* lpx = xch + 16 * kXchStride;
     const int c = lane >> 2, t = lane & 3;    // state layout (t == slot)
     const int gk = lane >> 4, j = lane & 15;  // MFMA layout
     const uint32_t tile_off = lds_offset(tile);
-    const uint32_t a_off = tile_off + (uint32_t)(j * kStride + 16 * gk) * 4u;      // row j, columns 16g..
-    const uint32_t b_off = tile_off + (uint32_t)(4 * gk * kStride + j) * 4u;       // rows 4g.., column j
-    const uint32_t y_off = tile_off + (uint32_t)(kRows * kStride + 4 * gk) * 4u;
-    float4* own = reinterpret_cast<float4*>(xch + c * kStride + 16 * t);
-    const float4* mine = reinterpret_cast<const float4*>(xch + j * kStride + 16 * gk);
+    const int nt = (N + kRows - 1) / kRows;
+    int buf = nt & 1;
+    // the staging block (buffer 0) and the previous gradient's tiles are no longer in use by any wave
+    __syncthreads();
+    issue_tile(0, buf, tile_off, wv, lane);
+
+    float4* own = reinterpret_cast<float4*>(xch + c * kXchStride + 16 * t);
+    const float4* mine = reinterpret_cast<const float4*>(xch + j * kXchStride + 16 * gk);
+    constexpr float kNegLog2e = -1.4426950408889634f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) own[i] = make_float4(beta[4 * i], beta[4 * i + 1], beta[4 * i + 2], beta[4 * i + 3]);
+    for (int i = 0; i < 4; ++i)
+      own[i] = make_float4(kNegLog2e * beta[4 * i], kNegLog2e * beta[4 * i + 1], kNegLog2e * beta[4 * i + 2],
+                           kNegLog2e * beta[4 * i + 3]);
     __builtin_amdgcn_wave_barrier();
     float bB[16];
 #pragma unroll
@@ -439,37 +468,52 @@ struct GermanLane {
       bB[4 * i] = f.x; bB[4 * i + 1] = f.y; bB[4 * i + 2] = f.z; bB[4 * i + 3] = f.w;
     }
     __builtin_amdgcn_wave_barrier();
+    // operand addresses in the current buffer (see "tile image"): row j of a block is in piece j / 4
+    uint32_t a_off[4], b_off[4], y_off;
+    {
+      const uint32_t xb0 = tile_off + (uint32_t)buf * kXBufB;
+      const uint32_t pj = (uint32_t)j >> 2;
+      const uint32_t abase = xb0 + pj * 1088u + (uint32_t)gk * 256u + ((uint32_t)j & 3u) * 64u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_off[i] = abase + (((uint32_t)i ^ pj) << 4);
+      const uint32_t bbase = xb0 + (uint32_t)gk * 1088u + ((pj ^ (uint32_t)gk) << 4) + ((uint32_t)j & 3u) * 4u;
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) b_off[s_] = bbase + (uint32_t)s_ * 64u;
+      y_off = tile_off + 2u * kXBufB + (uint32_t)buf * kYBufB + (uint32_t)gk * 16u;
+    }
     v4f acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
     float lp = 0.0f;
-    // one wave per SIMD here: nothing else hides the global-memory latency of a tile, so the
-    // next tile travels through registers while the current one is multiplied
-    TileRegs T;
-    fetch_tile(0, T);
-    for (int n0 = 0; n0 < N; n0 += kRows) {
-      __syncthreads();   // previous tile fully consumed
-      store_tile(tile, T);
-      if (n0 + kRows < N) fetch_tile(n0 + kRows, T);
+    for (int n = 0; n < nt; ++n) {
+      // this wave's pieces of tile n have landed; after the barrier everybody's have, and nobody reads tile n-1 any more
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      const int rows = min(kRows, N - n0);
+      if (n + 1 < nt) issue_tile(n + 1, buf ^ 1, tile_off, wv, lane);
+      const int rows = min(kRows, N - n * kRows);
       // The tile is zero filled up to its last row: always kRows / 16 blocks of 16 rows, software
       // pipelined (mfma_block).
       v4f xa[2][4], y4[2];
       v2f xb[8];
       v4f e0[2], e1[2];
-      issue_y(y_off, y4[0]);
-      issue_a(a_off, xa[0]);
-      issue_a(a_off + 16 * kStride * 4, xa[1]);
+      issue_y<0>(y_off, y4[0]);
+      issue_a<0>(a_off, xa[0]);
+      issue_a<1>(a_off, xa[1]);
       wait_a<4>(xa[0], y4[0]);
       e0[0] = e1[0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
       forward_steps<0, 16>(xa[0], bB, e0[0], e1[0]);
       mfma_blocks<LOGP, 0>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, e0, e1, acc, lp);
+      // the other buffer
+      const uint32_t dx = buf ? (uint32_t)-kXBufB : (uint32_t)kXBufB, dy = buf ? (uint32_t)-kYBufB : (uint32_t)kYBufB;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a_off[i] += dx; b_off[i] += dx; }
+      y_off += dy;
+      buf ^= 1;
     }
     // v back to the state layout: lane (g, j) holds v[16k + 4g + r] of chain j in acc[k][r]
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      *reinterpret_cast<float4*>(xch + j * kStride + 16 * k + 4 * gk) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+      *reinterpret_cast<float4*>(xch + j * kXchStride + 16 * k + 4 * gk) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
     if (LOGP) lpx[lane] = lp;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
