@@ -208,8 +208,8 @@ static int build_german(arp_model* m, const arp_dataset* d) {
   }
   m->D = 1 + 2 * F; m->n_groups = F;
   // [N][64] rows + outcomes (the 8- and 16-lane likelihoods), then the image the matrix-core likelihood copies
-  // into LDS with LDS-DMA (model_german.h, "tile image"): per 128 observations 32 pieces of 4 rows x 64 columns,
-  // each [feature block k][row][chunk ^ piece][4], and one piece of outcomes
+  // into LDS with LDS-DMA (model_german.h, "tile image"): per 128 observations the rows with their 16-byte chunks
+  // XOR-permuted, and one piece of outcomes
   const size_t plain = ((size_t)N * kGermanCols + N + 255) & ~(size_t)255;
   const int nt = (N + kGermanTileRows - 1) / kGermanTileRows;
   m->host_tables.assign(plain + (size_t)nt * kGermanImgTile, 0.0f);
@@ -221,12 +221,8 @@ static int build_german(arp_model* m, const arp_dataset* d) {
     for (int r = 0; r < kGermanTileRows; ++r) {
       const int n = t * kGermanTileRows + r;
       if (n >= N) break;
-      const int blk = r >> 4, p = (r >> 2) & 3, rho = r & 3;
-      float* piece = img + (blk * 4 + p) * 256;
-      for (int f = 0; f < F; ++f) {
-        const int k = f >> 4, c = (f >> 2) & 3, w = f & 3;
-        piece[k * 64 + rho * 16 + ((c ^ p) << 2) + w] = d->X_host[(size_t)n * F + f];
-      }
+      float* rowp = img + r * kGermanCols;   // chunk c of row r at chunk position c ^ (r & 11)
+      for (int f = 0; f < F; ++f) rowp[((((f >> 2) ^ (r & 11)) & 15) << 2) + (f & 3)] = d->X_host[(size_t)n * F + f];
       img[32 * 256 + r] = d->y_host[n];
     }
   }

@@ -23,12 +23,11 @@ namespace arp {
 constexpr int kGermanCols = 64;   // padded row length of the device design matrix
 // Tile image of the matrix-core likelihood (built by arp_api.hip: build_german): the design matrix in tiles of 128
 // observations, each stored as the exact byte image of its LDS copy so that LDS-DMA (global_load_lds_dwordx4: 64 lanes
-// x 16 contiguous bytes per instruction, no registers, no VALU) moves it.  A tile is 32 pieces of 1 KiB -- piece
-// (block b = row / 16, p = row / 4 % 4) holds 4 rows as [feature block k = col / 16][row % 4][chunk c ^ p][4 floats],
-// c = col / 4 % 4 -- followed by one piece with the 128 outcomes.  In LDS the pieces of a block sit 1088 bytes apart
-// (64 bytes of padding each): with the chunk XOR this makes both operand reads of the matrix-core products bank
-// conflict free (16 rows x one 16-byte chunk as ds_read_b128; 4 rows x 16 consecutive columns per lane group as
-// ds_read2st64_b32), checked lane by lane against the gfx950 bank rules.
+// x 16 contiguous bytes per instruction, no registers, no VALU) moves it.  A tile is 32 pieces of 1 KiB = 4 rows of 64
+// floats; the 16-byte chunk c of row r is stored at chunk position c ^ (r & 11), followed by one piece with the 128
+// outcomes.  With that XOR both operand reads of the matrix-core products are bank-conflict free as ds_read_b128
+// (forward: 16 rows x one chunk of a 64-byte feature block; backward: 4 rows x 16 consecutive chunks per lane group),
+// checked lane by lane against the gfx950 bank rules (4 groups of 16 lanes, bank = dword address mod 64).
 constexpr int kGermanTileRows = 128;
 constexpr int kGermanImgTile = 33 * 256;   // floats per tile of the image
 
@@ -87,24 +86,25 @@ struct GermanLane {
   }
 
   // K = 8, 16: [rows][64] tile of 64 observations + outcomes, filled through registers (fill_tile).
-  // K = 4 (matrix cores): two buffers of the tile image (8 blocks of 16 rows, 4352 bytes each), two of outcomes, and a
-  // per-wave exchange area.
+  // K = 4 (matrix cores): [X buffer 0][outcomes 0][outcomes 1][X buffer 1] of the tile image, then a per-wave exchange area.
   static constexpr int kStride = kGermanCols;
   static constexpr int kRows = K_ == 4 ? kGermanTileRows : 64;
-  static constexpr int kBlkB = 4 * 1088;              // bytes of a 16-row block in LDS
-  static constexpr int kXBufB = (kGermanTileRows / 16) * kBlkB;
+  static constexpr int kBlkB = 16 * kGermanCols * 4;   // bytes of a 16-row block
+  static constexpr int kXBufB = kGermanTileRows * kGermanCols * 4;
   static constexpr int kYBufB = 1024;
+  static constexpr int kBufStep = kXBufB + 2 * kYBufB;   // X buffer 0 -> X buffer 1
+  static constexpr int kYBase = kXBufB;                  // outcomes of buffer 0
   static constexpr int kXchStride = kGermanCols + 4;  // exchange rows padded: conflict-free float4 access both ways
   static constexpr int kXchWaves = W_;                // waves per workgroup the exchange area covers
   static constexpr bool HAS_VI = W_ == kViBlock / 64;   // the VI kernel is built from the lanes sized for its 8 waves
   static constexpr int kXch = 16 * kXchStride + 64;   // per wave: [16 chains][row] + 64 log-density partials
   static constexpr int kXchBase = (2 * kXBufB + 2 * kYBufB) / 4;
   static constexpr int kTileFloats = K_ == 4 ? kXchBase + kXchWaves * kXch : kRows * kStride + kRows;
-  // The chain kernels' row-staging block (kernels.h: ARP_STAGE_SMEM) aliases tile buffer 0: it is used between
-  // gradients only, and grad() opens with a workgroup barrier before anything is copied into that buffer.
+  // The chain kernels' row-staging block (kernels.h: ARP_STAGE_SMEM) aliases tile buffer 0 (X and outcomes): it is used
+  // between gradients only, and grad() opens with a workgroup barrier before anything is copied into that buffer.
   static constexpr bool STAGE_ALIAS = K_ == 4;
   static ARP_DEV float* stage_mem() { return tile_mem(); }
-  static constexpr int kStageCap = kXBufB / 4;
+  static constexpr int kStageCap = (kXBufB + kYBufB) / 4;
   // The [rows x 64] design-matrix tile and its outcomes, shared by the workgroup (one copy per
   // kernel: both instantiations of grad<> go through this function).
   static ARP_DEV float* tile_mem() {
@@ -302,20 +302,20 @@ struct GermanLane {
   ARP_DEV void issue_tile(int n, int buf, uint32_t tile_off, int wv, int lane) const {
     constexpr int PW = 32 / W_;
     const float* src = Xt + (size_t)n * kGermanImgTile;
-    const uint32_t xb0 = tile_off + (uint32_t)buf * kXBufB;
+    const uint32_t xb0 = tile_off + (uint32_t)buf * kBufStep;
     const uint32_t voff = (uint32_t)lane * 16u;
 #pragma unroll
     for (int p = 0; p < PW; ++p) {
-      const int P = wv * PW + p;   // piece: block P / 4, rows 4 (P % 4) ..
-      glds16(src + P * 256, voff, xb0 + (uint32_t)((P >> 2) * kBlkB + (P & 3) * 1088));
+      const int P = wv * PW + p;   // rows 4 P .. 4 P + 3
+      glds16(src + P * 256, voff, xb0 + (uint32_t)P * 1024u);
     }
-    if (wv == 0) glds16(src + 32 * 256, voff, tile_off + 2u * kXBufB + (uint32_t)buf * kYBufB);
+    if (wv == 0) glds16(src + 32 * 256, voff, tile_off + kYBase + (uint32_t)buf * kYBufB);
   }
   // LDS reads of the matrix-core path, pinned with inline asm a block ahead of their use (see the
   // note at Rows4: left to the scheduler they sink to the first use and the single wave per SIMD
   // waits out every LDS round trip with the matrix pipe idle).
-  // A operand of the forward product for rows r0 .. r0+15 of block BLK: lane (g, j) takes row r0+j, columns
-  // 16g .. 16g+15 (feature block g), chunk i from a_off[i] (the chunk XOR differs from lane to lane).
+  // A operand of the forward product for block BLK (rows 16 BLK ..): lane (g, j) takes row j, columns 16g .. 16g+15
+  // (feature block g), chunk i from a_off[i] (the chunk XOR differs from lane to lane).
   template <int BLK>
   static ARP_DEV void issue_a(const uint32_t (&a_off)[4], v4f (&xa)[4]) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[0]) : "v"(a_off[0]), "n"(BLK * kBlkB));
@@ -327,118 +327,142 @@ struct GermanLane {
   static ARP_DEV void issue_y(uint32_t y_off, v4f& y4) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(y4) : "v"(y_off), "n"(BLK * 64));
   }
-  // A operand of the backward product for block BLK: lane (g, j) takes rows r0+4g+s (s < 4) from b_off[s],
-  // columns j+16k (k < 4): xb[2s + k/2][k%2].  Feature blocks are 256 bytes apart and a block is 17 x 256 bytes,
-  // so ds_read2st64_b32 (offsets in units of 256 bytes) reaches every block from one address.
+  // A operand of the backward product for block BLK: lane (g, j) takes rows 4g+s (s < 4) from b_off[s], columns
+  // 4j .. 4j+3: accumulator k of the product gets feature 4j+k on output row j, so a lane (g', chain) ends up with
+  // features 16g' + 4r + k in acc[k][r].
   template <int BLK>
-  static ARP_DEV void issue_b(const uint32_t (&b_off)[4], v2f (&xb)[8]) {
-    static_assert(kBlkB == 17 * 256 && 17 * (kGermanTileRows / 16 - 1) + 3 <= 255, "ds_read2st64_b32 offsets are 8 bits");
-#define ARP_RD2(i, s_, o0) asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(xb[i]) : "v"(b_off[s_]), "n"(o0), "n"((o0) + 1))
-    ARP_RD2(0, 0, 17 * BLK); ARP_RD2(1, 0, 17 * BLK + 2);
-    ARP_RD2(2, 1, 17 * BLK); ARP_RD2(3, 1, 17 * BLK + 2);
-    ARP_RD2(4, 2, 17 * BLK); ARP_RD2(5, 2, 17 * BLK + 2);
-    ARP_RD2(6, 3, 17 * BLK); ARP_RD2(7, 3, 17 * BLK + 2);
-#undef ARP_RD2
+  static ARP_DEV void issue_b(const uint32_t (&b_off)[4], v4f (&xb)[4]) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xb[0]) : "v"(b_off[0]), "n"(BLK * kBlkB));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xb[1]) : "v"(b_off[1]), "n"(BLK * kBlkB));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xb[2]) : "v"(b_off[2]), "n"(BLK * kBlkB));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xb[3]) : "v"(b_off[3]), "n"(BLK * kBlkB));
   }
-  // the reads of (y4, xa) / xb have landed once at most NEWER younger LDS reads are outstanding
-  // (LDS reads return in order; y4 is always issued before xa)
+  // every LDS read older than the NEWER youngest has landed (LDS reads return in order); the operands are tied to the
+  // statement so that no use of them moves above it
   template <int NEWER>
-  static ARP_DEV void wait_a(v4f (&xa)[4], v4f& y4) {
-    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(y4) : "n"(NEWER));
-  }
-  template <int NEWER>
-  static ARP_DEV void wait_y(v4f& y4) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(y4) : "n"(NEWER)); }
-  template <int NEWER>
-  static ARP_DEV void wait_b(v2f (&xb)[8]) {
-    asm volatile("s_waitcnt lgkmcnt(%8)"
-                 : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]), "+v"(xb[4]), "+v"(xb[5]), "+v"(xb[6]),
-                   "+v"(xb[7])
+  static ARP_DEV void wait_ops(v4f (&xa)[4], v4f (&xb)[4], v4f& y4) {
+    asm volatile("s_waitcnt lgkmcnt(%9)"
+                 : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]),
+                   "+v"(y4)
                  : "n"(NEWER));
   }
-  // steps [S0, S1) of the 16 k-steps of a forward product, alternating two accumulation chains
-  // (a dependent MFMA waits 40 cycles, independent ones issue every 32)
-  template <int S0, int S1>
-  static ARP_DEV void forward_steps(const v4f (&xa)[4], const float (&bB)[16], v4f& e0, v4f& e1) {
-#pragma unroll
-    for (int s_ = S0; s_ < S1; s_ += 2) {
-      e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s_ >> 2][s_ & 3], bB[s_], e0, 0, 0, 0);
-      e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(s_ + 1) >> 2][(s_ + 1) & 3], bB[s_ + 1], e1, 0, 0, 0);
-    }
-  }
-  // y - sigmoid(eta) of one row (and its log density term); z = -eta log2(e) comes out of the forward product
+  // y - sigmoid(eta) of a lane's four rows (and their log density terms); z = -eta log2(e) comes out of the forward
+  // product.  Written stage by stage over the four rows: a transcendental's result needs a wait state before its
+  // first use, four independent ones in a row need none.
   template <bool LOGP>
-  static ARP_DEV float residual(float z, float yv, bool valid, float& lp) {
+  static ARP_DEV void residuals(const v4f& z, const v4f& yv, int row, int rows, float (&w)[4], float& lp) {
+    float ex[4], rc[4];
     if (LOGP) {
-      const float eta = -0.6931471805599453f * z;
-      const float ex = __builtin_amdgcn_exp2f(-fabsf(z));
-      const float rc = __builtin_amdgcn_rcpf(1.0f + ex);
-      const float tt = fmaf(yv, eta, -(fmaxf(eta, 0.0f) + fast_log(1.0f + ex)));
-      lp += valid ? tt : 0.0f;
-      return yv - (z <= 0.0f ? rc : ex * rc);
-    }
-    // 1 / (1 + e^-eta): e^-eta = inf gives 0, no NaN
-    return yv - __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
-  }
-  // step s of the backward product: four feature blocks, independent accumulators
-  static ARP_DEV void backward_step(const v2f (&xb)[8], int s_, float w, v4f (&acc)[4]) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[2 * s_ + (k >> 1)][k & 1], w, acc[k], 0, 0, 0);
-  }
-
-  // Block I (rows 16 I .. 16 I + 15) of a tile, see likelihood_mfma.  Program order:
-  //   issue  B(I) (backward operands), Y(I+1) (outcomes), A(I+2) (forward operands)
-  //   R1     forward MFMAs of block I+1 with the four residuals of block I spread between them
-  //   R2     backward MFMAs of block I
-  template <bool LOGP, int I>
-  static ARP_DEV void mfma_block(const uint32_t (&a_off)[4], const uint32_t (&b_off)[4], uint32_t y_off, int gk, int rows,
-                                 const float (&bB)[16], v4f (&xa)[2][4], v2f (&xb)[8], v4f (&y4)[2],
-                                 v4f (&e0)[2], v4f (&e1)[2], v4f (&acc)[4], float& lp) {
-    constexpr int r0 = 16 * I, cur = I & 1, nxt = (I + 1) & 1;
-    constexpr bool F1 = I + 1 < kRows / 16, F2 = I + 2 < kRows / 16;
-    const int row = r0 + 4 * gk;   // rows of a lane's four residuals: row + r
-    issue_b<I>(b_off, xb);
-    if (F1) issue_y<I + 1>(y_off, y4[nxt]);
-    if (F2) issue_a<F2 ? I + 2 : 0>(a_off, xa[cur]);
-    if (F1) wait_a<8 + 1 + (F2 ? 4 : 0)>(xa[nxt], y4[cur]);
-    else wait_y<8>(y4[cur]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (F1) {
-      e0[nxt] = e1[nxt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-      forward_steps<0, 16>(xa[nxt], bB, e0[nxt], e1[nxt]);
-    }
-    float w[4];
+      for (int r_ = 0; r_ < 4; ++r_) ex[r_] = __builtin_amdgcn_exp2f(-fabsf(z[r_]));
 #pragma unroll
-    for (int r_ = 0; r_ < 4; ++r_)
-      w[r_] = residual<LOGP>(e0[cur][r_] + e1[cur][r_], y4[cur][r_], row + r_ < rows, lp);
-    if (F1) {
+      for (int r_ = 0; r_ < 4; ++r_) rc[r_] = __builtin_amdgcn_rcpf(1.0f + ex[r_]);
+      float lg[4];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU
+      for (int r_ = 0; r_ < 4; ++r_) lg[r_] = __builtin_amdgcn_logf(rc[r_]);   // log2(1 / (1 + ex)) = -log2(1 + ex)
+#pragma unroll
+      for (int r_ = 0; r_ < 4; ++r_) {
+        // y eta - max(eta, 0) - log(1 + ex), eta = -ln2 z:  ln2 (log2 rc - y z + min(z, 0))
+        const float tt = 0.6931471805599453f * (lg[r_] + fmaf(-yv[r_], z[r_], fminf(z[r_], 0.0f)));
+        lp += row + r_ < rows ? tt : 0.0f;
+        w[r_] = yv[r_] - (z[r_] <= 0.0f ? rc[r_] : ex[r_] * rc[r_]);
       }
+    } else {
+      // 1 / (1 + e^-eta): e^-eta = inf gives 0, no NaN
+#pragma unroll
+      for (int r_ = 0; r_ < 4; ++r_) ex[r_] = __builtin_amdgcn_exp2f(z[r_]);
+#pragma unroll
+      for (int r_ = 0; r_ < 4; ++r_) rc[r_] = __builtin_amdgcn_rcpf(1.0f + ex[r_]);
+#pragma unroll
+      for (int r_ = 0; r_ < 4; ++r_) w[r_] = yv[r_] - rc[r_];
+    }
+  }
+  static constexpr int kNB = kGermanTileRows / 16;   // 16-row blocks per tile
+
+  // The software pipeline over the blocks of a tile.  Operands of block m live in xa[m & 1] (forward), xb[m & 1]
+  // (backward), y4[m & 1] (outcomes).  Phase I multiplies FORWARD block I+1 (one accumulation chain) interleaved 1:1
+  // with BACKWARD block I (four chains): a dependent MFMA would wait 40 cycles for its predecessor, with an
+  // independent one in between both issue every 32.  Vector instructions cannot hide under f32 MFMAs (same datapath,
+  // tools/mfma_overlap.hip), so everything else is kept minimal and placed after the MFMAs: the LDS reads of the
+  // operands two phases ahead (into the registers the MFMAs just consumed; their issue also covers the MFMA result
+  // latency), the four residuals of block I+1, then the outcome read.
+  //   reads issued at the end of phase I: A(I+3), B(I+2) | residuals | Y(I+3)      (9 instructions when all exist)
+  template <bool LOGP, int I>
+  static ARP_DEV void phase(const uint32_t (&a_off)[4], const uint32_t (&b_off)[4], uint32_t y_off, int gk, int rows,
+                            const float (&bB)[16], v4f (&xa)[2][4], v4f (&xb)[2][4], v4f (&y4)[2], float (&w)[4],
+                            v4f (&acc)[4], float& lp) {
+    constexpr int fa = (I + 1) & 1, bb = I & 1;
+    // younger reads at this point: those issued at the end of phase I-1
+    constexpr int newer = (I + 2 < kNB ? 5 : 0) + (I + 1 < kNB ? 4 : 0);
+    wait_ops<newer>(xa[fa], xb[bb], y4[fa]);
+    __builtin_amdgcn_sched_barrier(0);
+    v4f e = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {
+      e = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[fa][s_ >> 2][s_ & 3], bB[s_], e, 0, 0, 0);
+      acc[s_ & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[bb][s_ >> 2][s_ & 3], w[s_ >> 2], acc[s_ & 3], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    wait_b<(F1 ? 1 : 0) + (F2 ? 4 : 0)>(xb);
-#pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_) backward_step(xb, s_, w[s_], acc);
+    if constexpr (I + 3 < kNB) issue_a<I + 3>(a_off, xa[fa]);
+    if constexpr (I + 2 < kNB) issue_b<I + 2>(b_off, xb[bb]);
+    __builtin_amdgcn_sched_barrier(0);
+    residuals<LOGP>(e, y4[fa], 16 * (I + 1) + 4 * gk, rows, w, lp);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (I + 3 < kNB) issue_y<I + 3>(y_off, y4[fa]);
     __builtin_amdgcn_sched_barrier(0);
   }
-
-  // blocks I, I+1, ... of a tile
   template <bool LOGP, int I>
-  static ARP_DEV void mfma_blocks(const uint32_t (&a_off)[4], const uint32_t (&b_off)[4], uint32_t y_off, int gk, int rows,
-                                  const float (&bB)[16], v4f (&xa)[2][4], v2f (&xb)[8], v4f (&y4)[2],
-                                  v4f (&e0)[2], v4f (&e1)[2], v4f (&acc)[4], float& lp) {
-    if constexpr (I < kRows / 16) {
-      mfma_block<LOGP, I>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, e0, e1, acc, lp);
-      mfma_blocks<LOGP, I + 1>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, e0, e1, acc, lp);
+  static ARP_DEV void phases(const uint32_t (&a_off)[4], const uint32_t (&b_off)[4], uint32_t y_off, int gk, int rows,
+                             const float (&bB)[16], v4f (&xa)[2][4], v4f (&xb)[2][4], v4f (&y4)[2], float (&w)[4],
+                             v4f (&acc)[4], float& lp) {
+    if constexpr (I + 1 < kNB) {
+      phase<LOGP, I>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, acc, lp);
+      phases<LOGP, I + 1>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, acc, lp);
     }
+  }
+  // the first reads of a tile: A(0), Y(0), A(1), Y(1), B(0)
+  static ARP_DEV void first_reads(const uint32_t (&a_off)[4], const uint32_t (&b_off)[4], uint32_t y_off,
+                                  v4f (&xa)[2][4], v4f (&xb)[2][4], v4f (&y4)[2]) {
+    issue_a<0>(a_off, xa[0]);
+    issue_y<0>(y_off, y4[0]);
+    issue_a<1>(a_off, xa[1]);
+    issue_y<1>(y_off, y4[1]);
+    issue_b<0>(b_off, xb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // forward block 0 on its own (two chains: nothing to interleave with), then as the end of a phase
+  template <bool LOGP>
+  static ARP_DEV void head(const uint32_t (&a_off)[4], const uint32_t (&b_off)[4], uint32_t y_off, int gk, int rows,
+                           const float (&bB)[16], v4f (&xa)[2][4], v4f (&xb)[2][4], v4f (&y4)[2], float (&w)[4], float& lp) {
+    asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[0][2]), "+v"(xa[0][3]), "+v"(y4[0]));
+    __builtin_amdgcn_sched_barrier(0);
+    v4f e0 = v4f{0.0f, 0.0f, 0.0f, 0.0f}, e1 = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s_ = 0; s_ < 16; s_ += 2) {
+      e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][s_ >> 2][s_ & 3], bB[s_], e0, 0, 0, 0);
+      e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][(s_ + 1) >> 2][(s_ + 1) & 3], bB[s_ + 1], e1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    issue_a<2>(a_off, xa[0]);
+    issue_b<1>(b_off, xb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    residuals<LOGP>(e0 + e1, y4[0], 4 * gk, rows, w, lp);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_y<2>(y_off, y4[0]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // backward block kNB-1: the last MFMAs of a tile
+  static ARP_DEV void tail(const v4f (&xbl)[4], const float (&w)[4], v4f (&acc)[4]) {
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_)
+      acc[s_ & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xbl[s_ >> 2][s_ & 3], w[s_ >> 2], acc[s_ & 3], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   template <bool LOGP>
   ARP_DEV float likelihood_mfma(const float (&beta)[NLS], float (&v)[NLS]) const {
     static_assert(NLS == 16, "K = 4 owns 16 features per lane");
+    static_assert(kNB >= 4 && (kNB & 1) == 0, "the pipeline's register parities assume an even number of blocks");
     float* tile = tile_mem();
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -468,52 +492,58 @@ struct GermanLane {
       bB[4 * i] = f.x; bB[4 * i + 1] = f.y; bB[4 * i + 2] = f.z; bB[4 * i + 3] = f.w;
     }
     __builtin_amdgcn_wave_barrier();
-    // operand addresses in the current buffer (see "tile image"): row j of a block is in piece j / 4
+    // operand addresses in the current buffer (see "tile image"): chunk c of row r sits at chunk c ^ (r & 11)
     uint32_t a_off[4], b_off[4], y_off;
     {
-      const uint32_t xb0 = tile_off + (uint32_t)buf * kXBufB;
-      const uint32_t pj = (uint32_t)j >> 2;
-      const uint32_t abase = xb0 + pj * 1088u + (uint32_t)gk * 256u + ((uint32_t)j & 3u) * 64u;
+      const uint32_t xb0 = tile_off + (uint32_t)buf * kBufStep;
+      const uint32_t uj = (uint32_t)j, ug = (uint32_t)gk;
+      // forward: row j, chunks 4g + i
+      const uint32_t abase = xb0 + uj * 256u + (((ug << 2) ^ (uj & 8u)) << 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a_off[i] = abase + (((uint32_t)i ^ pj) << 4);
-      const uint32_t bbase = xb0 + (uint32_t)gk * 1088u + ((pj ^ (uint32_t)gk) << 4) + ((uint32_t)j & 3u) * 4u;
+      for (int i = 0; i < 4; ++i) a_off[i] = abase + ((((uint32_t)i) ^ (uj & 3u)) << 4);
+      // backward: rows 4g + s, chunk j;  (4g + s) & 11 = s | (g & 2) << 2
+      const uint32_t bbase = xb0 + ug * 1024u;
 #pragma unroll
-      for (int s_ = 0; s_ < 4; ++s_) b_off[s_] = bbase + (uint32_t)s_ * 64u;
-      y_off = tile_off + 2u * kXBufB + (uint32_t)buf * kYBufB + (uint32_t)gk * 16u;
+      for (int s_ = 0; s_ < 4; ++s_) b_off[s_] = bbase + (uint32_t)s_ * 256u + ((uj ^ (uint32_t)s_ ^ ((ug & 2u) << 2)) << 4);
+      y_off = tile_off + kYBase + (uint32_t)buf * kYBufB + ug * 16u;
     }
     v4f acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
     float lp = 0.0f;
+    v4f xa[2][4], y4[2];
+    v4f xb[2][4];
+    float w[4];
+    // tile 0 has landed everywhere; tile 1 into the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nt > 1) issue_tile(1, buf ^ 1, tile_off, wv, lane);
+    first_reads(a_off, b_off, y_off, xa, xb, y4);
     for (int n = 0; n < nt; ++n) {
-      // this wave's pieces of tile n have landed; after the barrier everybody's have, and nobody reads tile n-1 any more
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (n + 1 < nt) issue_tile(n + 1, buf ^ 1, tile_off, wv, lane);
-      const int rows = min(kRows, N - n * kRows);
-      // The tile is zero filled up to its last row: always kRows / 16 blocks of 16 rows, software
-      // pipelined (mfma_block).
-      v4f xa[2][4], y4[2];
-      v2f xb[8];
-      v4f e0[2], e1[2];
-      issue_y<0>(y_off, y4[0]);
-      issue_a<0>(a_off, xa[0]);
-      issue_a<1>(a_off, xa[1]);
-      wait_a<4>(xa[0], y4[0]);
-      e0[0] = e1[0] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-      forward_steps<0, 16>(xa[0], bB, e0[0], e1[0]);
-      mfma_blocks<LOGP, 0>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, e0, e1, acc, lp);
-      // the other buffer
-      const uint32_t dx = buf ? (uint32_t)-kXBufB : (uint32_t)kXBufB, dy = buf ? (uint32_t)-kYBufB : (uint32_t)kYBufB;
+      const int rows = min(kRows, N - n * kRows);   // the image is zero filled up to the tile's last row
+      head<LOGP>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, lp);
+      phases<LOGP, 0>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, acc, lp);
+      // every LDS read of this tile has landed (the operands of the last backward block among them)
+      wait_ops<0>(xa[0], xb[(kNB - 1) & 1], y4[0]);
+      if (n + 1 < nt) {
+        // tile n+1 is in LDS for every wave and nobody reads tile n any more: its buffer takes tile n+2, and the first
+        // reads of tile n+1 travel under the last MFMAs of tile n
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (n + 2 < nt) issue_tile(n + 2, buf, tile_off, wv, lane);
+        const uint32_t dx = buf ? (uint32_t)-kBufStep : (uint32_t)kBufStep, dy = buf ? (uint32_t)-kYBufB : (uint32_t)kYBufB;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { a_off[i] += dx; b_off[i] += dx; }
-      y_off += dy;
-      buf ^= 1;
+        for (int i = 0; i < 4; ++i) { a_off[i] += dx; b_off[i] += dx; }
+        y_off += dy;
+        buf ^= 1;
+        first_reads(a_off, b_off, y_off, xa, xb, y4);
+      }
+      tail(xb[(kNB - 1) & 1], w, acc);
     }
-    // v back to the state layout: lane (g, j) holds v[16k + 4g + r] of chain j in acc[k][r]
+    // v back to the state layout: lane (g, j) holds v[16g + 4r + k] of chain j in acc[k][r]
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      *reinterpret_cast<float4*>(xch + j * kXchStride + 16 * k + 4 * gk) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+    for (int r_ = 0; r_ < 4; ++r_)
+      *reinterpret_cast<float4*>(xch + j * kXchStride + 16 * gk + 4 * r_) = make_float4(acc[0][r_], acc[1][r_], acc[2][r_], acc[3][r_]);
     if (LOGP) lpx[lane] = lp;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
