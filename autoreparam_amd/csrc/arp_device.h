@@ -141,4 +141,15 @@ ARP_DEV float softplusf_(float x) {
   return fmaxf(x, 0.0f) + fast_log(1.0f + e);
 }
 
+
+#ifdef ARP_EXP_TIMING
+// timing experiments only: per-workgroup segment timers (core-clock cycles), printed by block 0 at kernel end
+ARP_DEV unsigned long long* exp_t() { __shared__ unsigned long long t[16]; return t; }
+ARP_DEV unsigned long long exp_now() { return __builtin_readcyclecounter(); }
+#define ARP_T(k, t0) do { unsigned long long n_ = arp::exp_now(); if (threadIdx.x == 0) arp::exp_t()[k] += n_ - t0; t0 = n_; } while (0)
+#define ARP_T0(t0) unsigned long long t0 = arp::exp_now()
+#else
+#define ARP_T(k, t0) do {} while (0)
+#define ARP_T0(t0) do {} while (0)
+#endif
 }  // namespace arp

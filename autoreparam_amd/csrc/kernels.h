@@ -493,6 +493,10 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
   // everything loaded so far has landed: no load result is awaited inside the loop, so the
   // in-order vmcnt never makes a wave wait for its own trace stores
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#ifdef ARP_EXP_TIMING
+  if (threadIdx.x == 0) for (int k = 0; k < 16; ++k) exp_t()[k] = 0;
+  ARP_T0(tk);
+#endif
   for (int s = 0; s < P.n_steps; ++s) {
     load_row(M, s_eps, eps);
 #pragma unroll
@@ -534,6 +538,13 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
     }
   }
 
+#ifdef ARP_EXP_TIMING
+  ARP_T(8, tk);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned long long* t = exp_t();
+    printf("TIMING total %llu | pre %llu bar %llu start %llu tiles %llu vx %llu post %llu | lik %llu\n", t[8], t[0], t[1], t[2], t[3], t[4], t[5], t[7]);
+  }
+#endif
   // recompute the per-lane row addresses here instead of keeping 64-bit pointers alive (in VGPR
   // pairs) across the whole sampling loop
   long long c2 = c;

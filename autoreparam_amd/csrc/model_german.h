@@ -298,18 +298,25 @@ struct GermanLane {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
   }
+  // four consecutive pieces: the instruction offset moves the global and the LDS address alike
+  static ARP_DEV void glds16x4(const float* sbase, uint32_t voff, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  }
   // this wave's share of tile n into buffer `buf`: 32 / W pieces of the design matrix, wave 0 also the outcomes
   ARP_DEV void issue_tile(int n, int buf, uint32_t tile_off, int wv, int lane) const {
     constexpr int PW = 32 / W_;
-    const float* src = Xt + (size_t)n * kGermanImgTile;
-    const uint32_t xb0 = tile_off + (uint32_t)buf * kBufStep;
+    static_assert(PW % 4 == 0, "pieces go out four at a time");
+    const float* src = Xt + (size_t)n * kGermanImgTile + wv * (PW * 256);
+    const uint32_t dst = tile_off + (uint32_t)buf * kBufStep + (uint32_t)wv * (PW * 1024u);
     const uint32_t voff = (uint32_t)lane * 16u;
 #pragma unroll
-    for (int p = 0; p < PW; ++p) {
-      const int P = wv * PW + p;   // rows 4 P .. 4 P + 3
-      glds16(src + P * 256, voff, xb0 + (uint32_t)P * 1024u);
-    }
-    if (wv == 0) glds16(src + 32 * 256, voff, tile_off + kYBase + (uint32_t)buf * kYBufB);
+    for (int p = 0; p < PW; p += 4) glds16x4(src + p * 256, voff, dst + (uint32_t)p * 1024u);
+    if (wv == 0) glds16(Xt + (size_t)n * kGermanImgTile + 32 * 256, voff, tile_off + kYBase + (uint32_t)buf * kYBufB);
   }
   // LDS reads of the matrix-core path, pinned with inline asm a block ahead of their use (see the
   // note at Rows4: left to the scheduler they sink to the first use and the single wave per SIMD
@@ -337,6 +344,8 @@ struct GermanLane {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xb[2]) : "v"(b_off[2]), "n"(BLK * kBlkB));
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xb[3]) : "v"(b_off[3]), "n"(BLK * kBlkB));
   }
+  template <int IMM>
+  static ARP_DEV void rd128(v4f& dst, uint32_t addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM)); }
   // every LDS read older than the NEWER youngest has landed (LDS reads return in order); the operands are tied to the
   // statement so that no use of them moves above it
   template <int NEWER>
@@ -397,15 +406,31 @@ struct GermanLane {
     wait_ops<newer>(xa[fa], xb[bb], y4[fa]);
     __builtin_amdgcn_sched_barrier(0);
     v4f e = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    // Quarter q = k-steps 4q .. 4q+3: forward chunk q and backward row q.  Once its MFMAs are issued those two registers
+    // are free, and the reads that refill them (a single wave can issue one instruction of any kind every 4 cycles, so
+    // they go into the 32-cycle shadow of an MFMA instead of behind the whole block).
 #pragma unroll
-    for (int s_ = 0; s_ < 16; ++s_) {
-      e = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[fa][s_ >> 2][s_ & 3], bB[s_], e, 0, 0, 0);
-      acc[s_ & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[bb][s_ >> 2][s_ & 3], w[s_ >> 2], acc[s_ & 3], 0, 0, 0);
+    for (int q_ = 0; q_ < 4; ++q_) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        e = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[fa][q_][k], bB[4 * q_ + k], e, 0, 0, 0);
+        acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[bb][q_][k], w[q_], acc[k], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (I + 3 < kNB) {
+        if (q_ == 0) rd128<(I + 3) * kBlkB>(xa[fa][0], a_off[0]);
+        if (q_ == 1) rd128<(I + 3) * kBlkB>(xa[fa][1], a_off[1]);
+        if (q_ == 2) rd128<(I + 3) * kBlkB>(xa[fa][2], a_off[2]);
+        if (q_ == 3) rd128<(I + 3) * kBlkB>(xa[fa][3], a_off[3]);
+      }
+      if constexpr (I + 2 < kNB) {
+        if (q_ == 0) rd128<(I + 2) * kBlkB>(xb[bb][0], b_off[0]);
+        if (q_ == 1) rd128<(I + 2) * kBlkB>(xb[bb][1], b_off[1]);
+        if (q_ == 2) rd128<(I + 2) * kBlkB>(xb[bb][2], b_off[2]);
+        if (q_ == 3) rd128<(I + 2) * kBlkB>(xb[bb][3], b_off[3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (I + 3 < kNB) issue_a<I + 3>(a_off, xa[fa]);
-    if constexpr (I + 2 < kNB) issue_b<I + 2>(b_off, xb[bb]);
-    __builtin_amdgcn_sched_barrier(0);
     residuals<LOGP>(e, y4[fa], 16 * (I + 1) + 4 * gk, rows, w, lp);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (I + 3 < kNB) issue_y<I + 3>(y_off, y4[fa]);
@@ -438,24 +463,27 @@ struct GermanLane {
     __builtin_amdgcn_sched_barrier(0);
     v4f e0 = v4f{0.0f, 0.0f, 0.0f, 0.0f}, e1 = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int s_ = 0; s_ < 16; s_ += 2) {
-      e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][s_ >> 2][s_ & 3], bB[s_], e0, 0, 0, 0);
-      e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][(s_ + 1) >> 2][(s_ + 1) & 3], bB[s_ + 1], e1, 0, 0, 0);
+    for (int q_ = 0; q_ < 4; ++q_) {
+      e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][q_][0], bB[4 * q_], e0, 0, 0, 0);
+      e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][q_][1], bB[4 * q_ + 1], e1, 0, 0, 0);
+      e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][q_][2], bB[4 * q_ + 2], e0, 0, 0, 0);
+      e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0][q_][3], bB[4 * q_ + 3], e1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q_ == 0) { rd128<2 * kBlkB>(xa[0][0], a_off[0]); rd128<kBlkB>(xb[1][0], b_off[0]); }
+      if (q_ == 1) { rd128<2 * kBlkB>(xa[0][1], a_off[1]); rd128<kBlkB>(xb[1][1], b_off[1]); }
+      if (q_ == 2) { rd128<2 * kBlkB>(xa[0][2], a_off[2]); rd128<kBlkB>(xb[1][2], b_off[2]); }
+      if (q_ == 3) { rd128<2 * kBlkB>(xa[0][3], a_off[3]); rd128<kBlkB>(xb[1][3], b_off[3]); }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    issue_a<2>(a_off, xa[0]);
-    issue_b<1>(b_off, xb[1]);
-    __builtin_amdgcn_sched_barrier(0);
     residuals<LOGP>(e0 + e1, y4[0], 4 * gk, rows, w, lp);
     __builtin_amdgcn_sched_barrier(0);
     issue_y<2>(y_off, y4[0]);
     __builtin_amdgcn_sched_barrier(0);
   }
-  // backward block kNB-1: the last MFMAs of a tile
-  static ARP_DEV void tail(const v4f (&xbl)[4], const float (&w)[4], v4f (&acc)[4]) {
+  // backward block kNB-1, the last MFMAs of a tile, one quarter (row q of the block) at a time
+  static ARP_DEV void tail_quarter(const v4f& xrow, float wq, v4f (&acc)[4]) {
 #pragma unroll
-    for (int s_ = 0; s_ < 16; ++s_)
-      acc[s_ & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xbl[s_ >> 2][s_ & 3], w[s_ >> 2], acc[s_ & 3], 0, 0, 0);
+    for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xrow[k], wq, acc[k], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -473,8 +501,10 @@ struct GermanLane {
     const uint32_t tile_off = lds_offset(tile);
     const int nt = (N + kRows - 1) / kRows;
     int buf = nt & 1;
+    ARP_T0(tt);
     // the staging block (buffer 0) and the previous gradient's tiles are no longer in use by any wave
     __syncthreads();
+    ARP_T(1, tt);
     issue_tile(0, buf, tile_off, wv, lane);
 
     float4* own = reinterpret_cast<float4*>(xch + c * kXchStride + 16 * t);
@@ -518,28 +548,48 @@ struct GermanLane {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (nt > 1) issue_tile(1, buf ^ 1, tile_off, wv, lane);
+    ARP_T(2, tt);
     first_reads(a_off, b_off, y_off, xa, xb, y4);
     for (int n = 0; n < nt; ++n) {
       const int rows = min(kRows, N - n * kRows);   // the image is zero filled up to the tile's last row
       head<LOGP>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, lp);
       phases<LOGP, 0>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, acc, lp);
       // every LDS read of this tile has landed (the operands of the last backward block among them)
-      wait_ops<0>(xa[0], xb[(kNB - 1) & 1], y4[0]);
+      constexpr int lb = (kNB - 1) & 1;
+      wait_ops<0>(xa[0], xb[lb], y4[0]);
       if (n + 1 < nt) {
         // tile n+1 is in LDS for every wave and nobody reads tile n any more: its buffer takes tile n+2, and the first
-        // reads of tile n+1 travel under the last MFMAs of tile n
+        // reads of tile n+1 go out in the shadow of the last MFMAs of tile n
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        tail_quarter(xb[lb][0], w[0], acc);
         if (n + 2 < nt) issue_tile(n + 2, buf, tile_off, wv, lane);
         const uint32_t dx = buf ? (uint32_t)-kBufStep : (uint32_t)kBufStep, dy = buf ? (uint32_t)-kYBufB : (uint32_t)kYBufB;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { a_off[i] += dx; b_off[i] += dx; }
-        y_off += dy;
         buf ^= 1;
-        first_reads(a_off, b_off, y_off, xa, xb, y4);
+        __builtin_amdgcn_sched_barrier(0);
+        tail_quarter(xb[lb][1], w[1], acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_off[i] += dx;
+        y_off += dy;
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a<0>(a_off, xa[0]);
+        issue_y<0>(y_off, y4[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        tail_quarter(xb[lb][2], w[2], acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b_off[i] += dx;
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a<1>(a_off, xa[1]);
+        issue_y<1>(y_off, y4[1]);
+        issue_b<0>(b_off, xb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        tail_quarter(xb[lb][3], w[3], acc);
+      } else {
+#pragma unroll
+        for (int q_ = 0; q_ < 4; ++q_) tail_quarter(xb[lb][q_], w[q_], acc);
       }
-      tail(xb[(kNB - 1) & 1], w, acc);
     }
+    ARP_T(3, tt);
     // v back to the state layout: lane (g, j) holds v[16g + 4r + k] of chain j in acc[k][r]
 #pragma unroll
     for (int r_ = 0; r_ < 4; ++r_)
@@ -553,11 +603,13 @@ struct GermanLane {
     }
     if (LOGP) lp = (lpx[c] + lpx[16 + c]) + (lpx[32 + c] + lpx[48 + c]);
     __builtin_amdgcn_wave_barrier();
+    ARP_T(4, tt);
     return lp;
   }
 
   template <bool LOGP>
   ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const {
+    ARP_T0(tg);
     const float ols = c0 * q[0];
     float beta[NLS], v[NLS], bls[NLS], r[NLS];
 #pragma unroll
@@ -568,9 +620,11 @@ struct GermanLane {
       v[i] = 0.0f;
     }
     float lp;
+    ARP_T(0, tg);
     if constexpr (K == 8) lp = likelihood_k8<LOGP>(beta, v);
     else if constexpr (K == 4) lp = likelihood_mfma<LOGP>(beta, v);
     else lp = likelihood_generic<LOGP>(beta, v);
+    ARP_T(7, tg);
     float lq = 0.0f, g_ols = 0.0f;
 #pragma unroll
     for (int i = 0; i < NLS; ++i) {
@@ -587,6 +641,7 @@ struct GermanLane {
     const float u0 = q[0] * s0i;
     g[0] = fmaf(c0, g_ols, -u0 * s0i);
     if (LOGP) lp += group_sum<K>(lq) - 0.5f * u0 * u0;
+    ARP_T(5, tg);
     return lp;
   }
 
