@@ -91,3 +91,28 @@ def test_missing_param_and_bad_lanes_fail(engines):
         eng.logp_grad(x, lanes=3)
     with pytest.raises(RuntimeError):
         eng.logp_grad(x, lanes=1)  # no 1-lane instantiation for radon
+
+
+@pytest.mark.parametrize("n_obs", [1, 17, 128, 129, 300, 513, 1000])
+def test_german_observation_tiles(oracle_lib, gpu, n_obs):
+    """German credit's matrix-core likelihood (4 lanes per chain) streams the design matrix in 128-row tiles through two
+    LDS buffers: one tile, an odd and an even number of tiles, tiles that end inside a 16-row block -- log density and
+    gradient against the float64 oracle on the truncated data set, and the 8- and 16-lane paths beside it."""
+    import copy
+    from autoreparam_amd import engine
+    full = helpers.spec("german")
+    sp = copy.copy(full)
+    sp.raw = dict(full.raw); sp.raw["X"] = full.raw["X"][:n_obs]; sp.raw["y"] = full.raw["y"][:n_obs]
+    sp.observed = {"y": sp.raw["y"][None]}
+    eng = engine.Engine(sp, gpu)
+    orc = oracle_lib.OracleModel(sp)
+    for kind in ("NCP", "VIP"):
+        a, b = helpers.params(sp, kind)
+        eng.set_param(0, (a, b))
+        x = helpers.states(sp, 37, seed=n_obs)
+        lp_o, g_o = orc.logp_grad(x, a, b, dtype=np.float64)
+        for lanes in (4, 8, 16):
+            lp, g = eng.logp_grad(x, which=0, lanes=lanes)
+            lp, g = lp.cpu().numpy(), g.cpu().numpy()
+            assert np.abs(lp - lp_o).max() <= 2e-6 * max(1.0, np.abs(lp_o).max()) + 1e-3, (lanes, kind)
+            assert np.abs(g - g_o).max() <= _tol(g_o), (lanes, kind)

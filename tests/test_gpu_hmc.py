@@ -29,12 +29,15 @@ def _eps0(oracle_lib, sp, a, b, x, frac):
     return (frac / np.sqrt(np.abs(diag) + 1.0)).astype(np.float32)
 
 
-def _compare(oracle_lib, gpu, mname, kind, lanes, adapt_kind, frac, L, n, n_adapt=0):
+def _compare(oracle_lib, gpu, mname, kind, lanes, adapt_kind, frac, L, n, n_adapt=0, sp=None):
     """Run the HIP kernel and the float32 oracle on the same seeds; return per-chain
     max |q_hip - q_oracle| (relative to the state scale) and the two final states."""
     from autoreparam_amd import engine
-    sp = helpers.spec(mname)
-    eng = _eng(mname, gpu)
+    if sp is None:
+        sp = helpers.spec(mname)
+        eng = _eng(mname, gpu)
+    else:
+        eng = engine.Engine(sp, gpu)
     orc = oracle_lib.OracleModel(sp)
     a, b = helpers.params(sp, kind)
     eng.set_param(0, (a, b))
@@ -79,6 +82,24 @@ def test_trajectories_match_oracle_fixed_step(oracle_lib, gpu, mname, kind):
         assert np.abs(st.logp.cpu().numpy()[ok] - so["logp"][ok]).max() <= lp_tol * np.abs(so["logp"]).max() + 2e-3
         # the streams are part of the specification: states must be bitwise equal
         assert np.array_equal(st.rng.cpu().numpy().view(np.uint32)[:, :lanes], so["rng"][:, :lanes])
+
+
+@pytest.mark.parametrize("n_obs", [100, 300, 640])
+def test_german_trajectories_on_one_three_and_five_tiles(oracle_lib, gpu, n_obs):
+    """German credit on the matrix cores with the data set cut to 1, 3 and 5 tiles of 128 observations: an odd number of
+    tiles flips the buffer the first tile of a gradient lands in, and the trace rows are staged in the LDS area that the
+    next gradient's first tile overwrites -- trajectories, acceptance and trace rows against the float32 oracle."""
+    import copy
+    full = helpers.spec("german")
+    sp = copy.copy(full)
+    sp.raw = dict(full.raw); sp.raw["X"] = full.raw["X"][:n_obs]; sp.raw["y"] = full.raw["y"][:n_obs]
+    sp.observed = {"y": sp.raw["y"][None]}
+    err, terr, st, so, ta, tao = _compare(oracle_lib, gpu, "german", "NCP", 4, 0, 0.05, 4, 12, sp=sp)
+    ok = err <= 1e-4
+    assert ok.mean() >= 0.95, (ok.mean(), np.sort(err)[-5:])
+    assert (terr[ok] <= 1e-4).mean() >= 0.98 and (terr[ok] <= 1e-2).all()
+    assert np.array_equal(st.accept_count.cpu().numpy()[ok], so["accept_count"][ok])
+    assert np.array_equal(ta[:, ok], tao[:, ok])
 
 
 @pytest.mark.parametrize("mname", ["election", "radon_PA", "german"])
