@@ -207,6 +207,12 @@ def run_interleaved_hmc_with_leapfrog_steps(model_config, results_dir, num_leapf
     acc_ncp = float(parallel.all_reduce_sum(float(np.sum(is_accepted_ncp)), dev).item()) * 100.0 / float(
         flags.num_samples * flags.num_chains)
     util.print_("ESS: {} +/- {}".format(ess_min, sem_min))
+    # Only `[:, :num_chains_to_save]` of the samples is ever read again (save_ess).  Taking that slice to the host now
+    # releases the [S, C, D] device trace before the next candidate leapfrog count allocates its own (two 18.6 GB traces
+    # alive at once at the headline size, and a fresh device allocation of that size can cost half a second).
+    k = max(0, int(flags.num_chains_to_save))
+    states = [np.asarray(s[:, :k]) for s in states] if k > 0 else [np.zeros((flags.num_samples, 0), np.float32) for _ in states]
+    del kernel_results, is_accepted_cp, is_accepted_ncp
     return (ess_min, sem_min, acc_cp, acc_ncp, mcmc_time, states, normalized_ess_final)
 
 
