@@ -5,6 +5,10 @@
 // The autocovariances are formed directly and only until the first negative one -- no FFT, no work buffers,
 // no plan creation.  One thread per series; consecutive threads read consecutive floats of a trace
 // row, so every pass streams the trace coalesced.  Sums are accumulated in double.
+// The first 16 lags come out of ONE pass over the series, without a mean pass in front of it: with y_t = x_t - r
+// (r = the mean of the first 16 samples, so that y is small) and m' = mean(y),
+//   sum_{t>=k} (y_t - m')(y_{t-k} - m') = sum_{t>=k} y_t y_{t-k} - m' (2 T - head_k - tail_k) + (S - k) m'^2,
+// T = sum_t y_t, head_k / tail_k = the sums of the first / last k values (two 16-sample loops).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "host_common.h"
@@ -27,8 +31,10 @@ constexpr int kEssWin = ARP_ESS_WIN;      // lags 1..kEssWin come out of the fir
 // v_fma_f32 and made the sweep compute bound); no float sum is longer than 256 products.
 template <bool FIRST>
 __device__ __forceinline__ void ess_sweep(const float* __restrict__ x, long long S, long long stride, float mean,
-                                          long long kb, double (&dacc)[kEssWin + 1]) {
+                                          long long kb, double (&dacc)[kEssWin + 1], double& dtot) {
   float acc[kEssWin + 1];
+  float tot = 0.0f;
+  dtot = 0.0;
   float w[kEssWin];          // w[tt] = y at time t0 + tt - kb of the previous window (0 before the series starts)
 #pragma unroll
   for (int j = 0; j <= kEssWin; ++j) { acc[j] = 0.0f; dacc[j] = 0.0; }
@@ -60,7 +66,7 @@ __device__ __forceinline__ void ess_sweep(const float* __restrict__ x, long long
 #pragma unroll
     for (int tt = 0; tt < kEssWin; ++tt) {
       const float y = xv[tt] - mean;
-      if (FIRST) acc[0] = fmaf(y, y, acc[0]);
+      if (FIRST) { acc[0] = fmaf(y, y, acc[0]); tot += y; }
 #pragma unroll
       for (int j = 1; j <= kEssWin; ++j) acc[j] = fmaf(y, w[(tt - j + 2 * kEssWin) % kEssWin], acc[j]);
       w[tt] = FIRST ? y : xl[tt] - mean;
@@ -68,6 +74,7 @@ __device__ __forceinline__ void ess_sweep(const float* __restrict__ x, long long
     if (((t0 / kEssWin) & 7) == 7 || t0 + kEssWin >= S) {
 #pragma unroll
       for (int j = 0; j <= kEssWin; ++j) { dacc[j] += (double)acc[j]; acc[j] = 0.0f; }
+      if (FIRST) { dtot += (double)tot; tot = 0.0f; }
     }
   }
 }
@@ -77,30 +84,36 @@ __global__ __launch_bounds__(256) void ess_kernel(const float* __restrict__ trac
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* x = trace + i;
-  double m = 0.0;
-  {
-    long long t = 0;
-    for (; t + 16 <= S; t += 16) {
-      float v[16];
+  // reference level r and the sums of the first / last k values (k <= 16)
+  const int nh = S < kEssWin ? (int)S : kEssWin;
+  float fh[kEssWin], ft[kEssWin];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = x[(t + j) * stride];
-      float part = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) part += v[j];
-      m += (double)part;
-    }
-    for (; t < S; ++t) m += (double)x[t * stride];
+  for (int j = 0; j < kEssWin; ++j) {
+    fh[j] = j < nh ? x[(long long)j * stride] : 0.0f;
+    ft[j] = j < nh ? x[(S - 1 - j) * stride] : 0.0f;     // ft[j] = x_{S-1-j}
   }
-  const float mean = (float)(m / (double)S);
+  float r = 0.0f;   // x_0 + mean(x_j - x_0): exactly x_0 for a constant series
+#pragma unroll
+  for (int j = 1; j < kEssWin; ++j) r += j < nh ? fh[j] - fh[0] : 0.0f;
+  r = fh[0] + r / (float)nh;
 
-  double dacc[kEssWin + 1];
-  ess_sweep<true>(x, S, stride, mean, 0, dacc);
-  const double c0 = dacc[0] / (double)S;
+  double dacc[kEssWin + 1], T;
+  ess_sweep<true>(x, S, stride, r, 0, dacc, T);
+  const double mp = T / (double)S;          // mean of y
+  const float mean = r + (float)mp;         // mean of x, for the sweeps past lag 16
+  // centred sums: lag 0 first
+  double head = 0.0, tail = 0.0;            // sums of the first / last k values of y
+  const double c0 = (dacc[0] - (double)S * mp * mp) / (double)S;
+#pragma unroll
+  for (int j = 1; j <= kEssWin; ++j) {
+    head += (double)(fh[j - 1] - r); tail += (double)(ft[j - 1] - r);
+    dacc[j] = dacc[j] - mp * (2.0 * T - head - tail) + (double)(S - j) * mp * mp;
+  }
   if (!(c0 > 0.0)) { ess[i] = __builtin_nanf(""); return; }   // constant series: 0/0 as in the FFT form
   double total = 1.0;   // lag 0: (S - 0)/S * rho_0
   bool done = false;
   for (long long kb = 0; kb < S && !done; kb += kEssWin) {
-    if (kb > 0) ess_sweep<false>(x, S, stride, mean, kb, dacc);
+    if (kb > 0) { double unused; ess_sweep<false>(x, S, stride, mean, kb, dacc, unused); }
 #pragma unroll
     for (int j = 1; j <= kEssWin; ++j) {
       const long long k = kb + j;
