@@ -13,6 +13,10 @@ OBJ = os.path.join(HERE, "build" + TAG)
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fno-slp-vectorize", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("ARP_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DNAME for a timing variant)
+# per-file flags.  German credit's matrix-core likelihood: let the MFMAs write VGPRs (the forward product's result is
+# consumed by VALU instructions at once; from AGPRs every element costs a v_accvgpr_read first: 601 -> 460 instructions
+# per 128-row tile)
+FILE_FLAGS = {"inst_german.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _sources():
@@ -38,7 +42,7 @@ def build(force=False, verbose=False):
         o = os.path.join(OBJ, src[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + FILE_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
