@@ -377,13 +377,15 @@ struct GermanLane {
         w[r_] = yv[r_] - (z[r_] <= 0.0f ? rc[r_] : ex[r_] * rc[r_]);
       }
     } else {
-      // 1 / (1 + e^-eta): e^-eta = inf gives 0, no NaN
+      // 1 / (1 + e^-eta): e^-eta = inf gives 0, no NaN.  The adds and subtractions go two rows at a time (v_pk_add_f32).
 #pragma unroll
       for (int r_ = 0; r_ < 4; ++r_) ex[r_] = __builtin_amdgcn_exp2f(z[r_]);
-#pragma unroll
-      for (int r_ = 0; r_ < 4; ++r_) rc[r_] = __builtin_amdgcn_rcpf(1.0f + ex[r_]);
-#pragma unroll
-      for (int r_ = 0; r_ < 4; ++r_) w[r_] = yv[r_] - rc[r_];
+      const v2f one = v2f{1.0f, 1.0f};
+      const v2f d01 = v2f{ex[0], ex[1]} + one, d23 = v2f{ex[2], ex[3]} + one;
+      rc[0] = __builtin_amdgcn_rcpf(d01[0]); rc[1] = __builtin_amdgcn_rcpf(d01[1]);
+      rc[2] = __builtin_amdgcn_rcpf(d23[0]); rc[3] = __builtin_amdgcn_rcpf(d23[1]);
+      const v2f w01 = v2f{yv[0], yv[1]} - v2f{rc[0], rc[1]}, w23 = v2f{yv[2], yv[3]} - v2f{rc[2], rc[3]};
+      w[0] = w01[0]; w[1] = w01[1]; w[2] = w23[0]; w[3] = w23[1];
     }
   }
   static constexpr int kNB = kGermanTileRows / 16;   // 16-row blocks per tile
