@@ -146,44 +146,63 @@ ARP_DEV void store_row_wave(const Lane& M, float* stage, float* gdst, int cl, in
 __device__ __noinline__ void stats_update_staged(const float* stage, float* g, size_t comp, int nvalid, bool first,
                                                  bool batch_end, float invb) {
   const int lane = threadIdx.x & 63;
-  // per sample only ref (read), s1 and s2 (read-modify-write) are touched; `cur` holds s1 as it was when the
-  // current batch began and is visited at batch ends only: batch sum = s1 - cur
-  auto upd = [&](float x, float& ref, float& s1, float& s2, float& cur, float& sb1, float& sb2) {
+  // per sample only ref (read), s1 and s2 (read-modify-write) are touched
+  auto upd = [&](float x, float& ref, float& s1, float& s2) {
     ref = first ? x : ref;
     const float dx = x - ref;
     s1 += dx; s2 = fmaf(dx, dx, s2);
-    if (batch_end) { const float bm = (s1 - cur) * invb; sb1 += bm; sb2 = fmaf(bm, bm, sb2); cur = s1; }
   };
   const bool aligned = ((reinterpret_cast<uintptr_t>(g) | (comp * sizeof(float))) & 15) == 0;
-  for (int k = lane * 4; k < nvalid; k += 256) {
-    if (aligned && k + 3 < nvalid) {
-      const float4 x = *reinterpret_cast<const float4*>(stage + k);
-      float4 ref = *reinterpret_cast<float4*>(g + k), s1 = *reinterpret_cast<float4*>(g + comp + k);
-      float4 s2 = *reinterpret_cast<float4*>(g + 2 * comp + k);
-      float4 cur = make_float4(0, 0, 0, 0), sb1 = cur, sb2 = cur;
-      if (batch_end) {
-        cur = *reinterpret_cast<float4*>(g + 3 * comp + k);
-        sb1 = *reinterpret_cast<float4*>(g + 4 * comp + k); sb2 = *reinterpret_cast<float4*>(g + 5 * comp + k);
+  // One 16-byte slice of the planes: loads (`ld`), then arithmetic + stores (`st`).  Slices go two at a time with the
+  // plane loads of both issued before the first use: the planes come from the Infinity Cache / HBM, and one round trip
+  // per slice (five per sample at D = 71, each also waiting out the previous slice's stores: vmcnt is in order) was
+  // most of what the statistics cost.
+  struct Slice { float4 x, ref, s1, s2; };
+  auto ld = [&](int k, Slice& S) {
+    S.x = *reinterpret_cast<const float4*>(stage + k);
+    S.ref = *reinterpret_cast<float4*>(g + k); S.s1 = *reinterpret_cast<float4*>(g + comp + k);
+    S.s2 = *reinterpret_cast<float4*>(g + 2 * comp + k);
+  };
+  auto st = [&](int k, Slice& S) {
+    upd(S.x.x, S.ref.x, S.s1.x, S.s2.x);
+    upd(S.x.y, S.ref.y, S.s1.y, S.s2.y);
+    upd(S.x.z, S.ref.z, S.s1.z, S.s2.z);
+    upd(S.x.w, S.ref.w, S.s1.w, S.s2.w);
+    if (first) *reinterpret_cast<float4*>(g + k) = S.ref;
+    *reinterpret_cast<float4*>(g + comp + k) = S.s1; *reinterpret_cast<float4*>(g + 2 * comp + k) = S.s2;
+  };
+  // unaligned planes or the ragged tail of the wave's block: element by element, nothing past it is touched
+  auto tail = [&](int k) {
+    for (int j = k; j < nvalid && j < k + 4; ++j) {
+      float ref = g[j], s1 = g[comp + j], s2 = g[2 * comp + j];
+      upd(stage[j], ref, s1, s2);
+      if (first) g[j] = ref;
+      g[comp + j] = s1; g[2 * comp + j] = s2;
+    }
+  };
+  for (int k = lane * 4; k < nvalid; k += 512) {
+    const int k2 = k + 256;
+    if (aligned && k2 + 3 < nvalid) {          // both slices whole
+      Slice A, B;
+      ld(k, A); ld(k2, B);
+      st(k, A); st(k2, B);
+    } else {
+      if (aligned && k + 3 < nvalid) { Slice A; ld(k, A); st(k, A); } else tail(k);
+      if (k2 < nvalid) {
+        if (aligned && k2 + 3 < nvalid) { Slice B; ld(k2, B); st(k2, B); } else tail(k2);
       }
-      upd(x.x, ref.x, s1.x, s2.x, cur.x, sb1.x, sb2.x);
-      upd(x.y, ref.y, s1.y, s2.y, cur.y, sb1.y, sb2.y);
-      upd(x.z, ref.z, s1.z, s2.z, cur.z, sb1.z, sb2.z);
-      upd(x.w, ref.w, s1.w, s2.w, cur.w, sb1.w, sb2.w);
-      if (first) *reinterpret_cast<float4*>(g + k) = ref;
-      *reinterpret_cast<float4*>(g + comp + k) = s1; *reinterpret_cast<float4*>(g + 2 * comp + k) = s2;
-      if (batch_end) {
-        *reinterpret_cast<float4*>(g + 3 * comp + k) = cur;
-        *reinterpret_cast<float4*>(g + 4 * comp + k) = sb1; *reinterpret_cast<float4*>(g + 5 * comp + k) = sb2;
-      }
-    } else {   // unaligned planes or the ragged tail of the wave's block: element by element, nothing past it is touched
+    }
+  }
+  // batch ends only (one sample in `stats_batch`): `cur` holds s1 as it was when the batch began, batch sum = s1 - cur.
+  // This lane reads back the s1 it has just written (same addresses, same lane).
+  if (batch_end) {
+    for (int k = lane * 4; k < nvalid; k += 256) {
       for (int j = k; j < nvalid && j < k + 4; ++j) {
-        float ref = g[j], s1 = g[comp + j], s2 = g[2 * comp + j];
-        float cur = batch_end ? g[3 * comp + j] : 0.0f, sb1 = batch_end ? g[4 * comp + j] : 0.0f;
-        float sb2 = batch_end ? g[5 * comp + j] : 0.0f;
-        upd(stage[j], ref, s1, s2, cur, sb1, sb2);
-        if (first) g[j] = ref;
-        g[comp + j] = s1; g[2 * comp + j] = s2;
-        if (batch_end) { g[3 * comp + j] = cur; g[4 * comp + j] = sb1; g[5 * comp + j] = sb2; }
+        const float s1 = g[comp + j], cur = g[3 * comp + j];
+        const float bm = (s1 - cur) * invb;
+        g[4 * comp + j] += bm;
+        g[5 * comp + j] = fmaf(bm, bm, g[5 * comp + j]);
+        g[3 * comp + j] = s1;
       }
     }
   }
