@@ -356,31 +356,48 @@ struct GermanLane {
                  : "n"(NEWER));
   }
   // y - sigmoid(eta) of a lane's four rows (and their log density terms); z = -eta log2(e) comes out of the forward
-  // product.  Written stage by stage over the four rows: a transcendental's result needs a wait state before its
-  // first use, four independent ones in a row need none.
-  template <bool LOGP>
-  static ARP_DEV void residuals(const v4f& z, const v4f& yv, int row, int rows, float (&w)[4], float& lp) {
+  // product.  Written stage by stage over the four rows (a transcendental's result needs a wait state before its first
+  // use, four independent ones in a row need none), additions two rows at a time (v_pk_add_f32 / v_pk_fma_f32).
+  // LOGP: with ex = 2^-|z| and rc = 1 / (1 + ex) in [1/2, 1],
+  //   sigmoid(eta) = 1/2 + copysign(rc - 1/2, eta)           (= rc for eta >= 0, 1 - rc otherwise)
+  //   log2 of the Bernoulli term  y eta - softplus(eta)  =  log2(rc) - y z + min(z, 0)
+  // accumulated in log2 units in two packed accumulators (lp2; scaled by ln 2 once per gradient).  MASK: the tile ends
+  // inside the block range (last tile of the data set), rows >= `rows` are padding and must not count.
+  template <bool LOGP, bool MASK>
+  static ARP_DEV void residuals(const v4f& z, const v4f& yv, int row, int rows, float (&w)[4], v2f (&lp2)[2]) {
     float ex[4], rc[4];
+    const v2f one = v2f{1.0f, 1.0f};
     if (LOGP) {
 #pragma unroll
       for (int r_ = 0; r_ < 4; ++r_) ex[r_] = __builtin_amdgcn_exp2f(-fabsf(z[r_]));
-#pragma unroll
-      for (int r_ = 0; r_ < 4; ++r_) rc[r_] = __builtin_amdgcn_rcpf(1.0f + ex[r_]);
-      float lg[4];
+      const v2f d01 = v2f{ex[0], ex[1]} + one, d23 = v2f{ex[2], ex[3]} + one;
+      rc[0] = __builtin_amdgcn_rcpf(d01[0]); rc[1] = __builtin_amdgcn_rcpf(d01[1]);
+      rc[2] = __builtin_amdgcn_rcpf(d23[0]); rc[3] = __builtin_amdgcn_rcpf(d23[1]);
+      float lg[4], mz[4];
 #pragma unroll
       for (int r_ = 0; r_ < 4; ++r_) lg[r_] = __builtin_amdgcn_logf(rc[r_]);   // log2(1 / (1 + ex)) = -log2(1 + ex)
 #pragma unroll
-      for (int r_ = 0; r_ < 4; ++r_) {
-        // y eta - max(eta, 0) - log(1 + ex), eta = -ln2 z:  ln2 (log2 rc - y z + min(z, 0))
-        const float tt = 0.6931471805599453f * (lg[r_] + fmaf(-yv[r_], z[r_], fminf(z[r_], 0.0f)));
-        lp += row + r_ < rows ? tt : 0.0f;
-        w[r_] = yv[r_] - (z[r_] <= 0.0f ? rc[r_] : ex[r_] * rc[r_]);
+      for (int r_ = 0; r_ < 4; ++r_)   // min(z, 0); fminf() would add a v_max to quiet NaNs first
+        asm("v_min_f32 %0, 0, %1" : "=v"(mz[r_]) : "v"(z[r_]));
+      const v2f y01 = v2f{yv[0], yv[1]}, y23 = v2f{yv[2], yv[3]};
+      v2f t01 = vfma(-y01, v2f{z[0], z[1]}, v2f{mz[0], mz[1]}) + v2f{lg[0], lg[1]};
+      v2f t23 = vfma(-y23, v2f{z[2], z[3]}, v2f{mz[2], mz[3]}) + v2f{lg[2], lg[3]};
+      if (MASK) {
+        t01 = v2f{row + 0 < rows ? t01[0] : 0.0f, row + 1 < rows ? t01[1] : 0.0f};
+        t23 = v2f{row + 2 < rows ? t23[0] : 0.0f, row + 3 < rows ? t23[1] : 0.0f};
       }
+      lp2[0] += t01; lp2[1] += t23;
+      const v2f half = v2f{0.5f, 0.5f};
+      const v2f h01 = v2f{rc[0], rc[1]} - half, h23 = v2f{rc[2], rc[3]} - half;   // |sigmoid - 1/2|
+      // sign(eta) = -sign(z): magnitude from h, sign bit from z, subtracted instead of added
+      const v2f c01 = v2f{__builtin_copysignf(h01[0], z[0]), __builtin_copysignf(h01[1], z[1])};
+      const v2f c23 = v2f{__builtin_copysignf(h23[0], z[2]), __builtin_copysignf(h23[1], z[3])};
+      const v2f w01 = (y01 - half) + c01, w23 = (y23 - half) + c23;
+      w[0] = w01[0]; w[1] = w01[1]; w[2] = w23[0]; w[3] = w23[1];
     } else {
-      // 1 / (1 + e^-eta): e^-eta = inf gives 0, no NaN.  The adds and subtractions go two rows at a time (v_pk_add_f32).
+      // 1 / (1 + e^-eta): e^-eta = inf gives 0, no NaN
 #pragma unroll
       for (int r_ = 0; r_ < 4; ++r_) ex[r_] = __builtin_amdgcn_exp2f(z[r_]);
-      const v2f one = v2f{1.0f, 1.0f};
       const v2f d01 = v2f{ex[0], ex[1]} + one, d23 = v2f{ex[2], ex[3]} + one;
       rc[0] = __builtin_amdgcn_rcpf(d01[0]); rc[1] = __builtin_amdgcn_rcpf(d01[1]);
       rc[2] = __builtin_amdgcn_rcpf(d23[0]); rc[3] = __builtin_amdgcn_rcpf(d23[1]);
@@ -398,10 +415,10 @@ struct GermanLane {
   // operands two phases ahead (into the registers the MFMAs just consumed; their issue also covers the MFMA result
   // latency), the four residuals of block I+1, then the outcome read.
   //   reads issued at the end of phase I: A(I+3), B(I+2) | residuals | Y(I+3)      (9 instructions when all exist)
-  template <bool LOGP, int I>
+  template <bool LOGP, bool MASK, int I>
   static ARP_DEV void phase(const uint32_t (&a_off)[4], const uint32_t (&b_off)[4], uint32_t y_off, int gk, int rows,
                             const float (&bB)[16], v4f (&xa)[2][4], v4f (&xb)[2][4], v4f (&y4)[2], float (&w)[4],
-                            v4f (&acc)[4], float& lp) {
+                            v4f (&acc)[4], v2f (&lp)[2]) {
     constexpr int fa = (I + 1) & 1, bb = I & 1;
     // younger reads at this point: those issued at the end of phase I-1
     constexpr int newer = (I + 2 < kNB ? 5 : 0) + (I + 1 < kNB ? 4 : 0);
@@ -433,18 +450,18 @@ struct GermanLane {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    residuals<LOGP>(e, y4[fa], 16 * (I + 1) + 4 * gk, rows, w, lp);
+    residuals<LOGP, MASK>(e, y4[fa], 16 * (I + 1) + 4 * gk, rows, w, lp);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (I + 3 < kNB) issue_y<I + 3>(y_off, y4[fa]);
     __builtin_amdgcn_sched_barrier(0);
   }
-  template <bool LOGP, int I>
+  template <bool LOGP, bool MASK, int I>
   static ARP_DEV void phases(const uint32_t (&a_off)[4], const uint32_t (&b_off)[4], uint32_t y_off, int gk, int rows,
                              const float (&bB)[16], v4f (&xa)[2][4], v4f (&xb)[2][4], v4f (&y4)[2], float (&w)[4],
-                             v4f (&acc)[4], float& lp) {
+                             v4f (&acc)[4], v2f (&lp)[2]) {
     if constexpr (I + 1 < kNB) {
-      phase<LOGP, I>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, acc, lp);
-      phases<LOGP, I + 1>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, acc, lp);
+      phase<LOGP, MASK, I>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, acc, lp);
+      phases<LOGP, MASK, I + 1>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, acc, lp);
     }
   }
   // the first reads of a tile: A(0), Y(0), A(1), Y(1), B(0)
@@ -458,9 +475,9 @@ struct GermanLane {
     __builtin_amdgcn_sched_barrier(0);
   }
   // forward block 0 on its own (two chains: nothing to interleave with), then as the end of a phase
-  template <bool LOGP>
+  template <bool LOGP, bool MASK>
   static ARP_DEV void head(const uint32_t (&a_off)[4], const uint32_t (&b_off)[4], uint32_t y_off, int gk, int rows,
-                           const float (&bB)[16], v4f (&xa)[2][4], v4f (&xb)[2][4], v4f (&y4)[2], float (&w)[4], float& lp) {
+                           const float (&bB)[16], v4f (&xa)[2][4], v4f (&xb)[2][4], v4f (&y4)[2], float (&w)[4], v2f (&lp)[2]) {
     asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[0][2]), "+v"(xa[0][3]), "+v"(y4[0]));
     __builtin_amdgcn_sched_barrier(0);
     v4f e0 = v4f{0.0f, 0.0f, 0.0f, 0.0f}, e1 = v4f{0.0f, 0.0f, 0.0f, 0.0f};
@@ -477,7 +494,7 @@ struct GermanLane {
       if (q_ == 3) { rd128<2 * kBlkB>(xa[0][3], a_off[3]); rd128<kBlkB>(xb[1][3], b_off[3]); }
       __builtin_amdgcn_sched_barrier(0);
     }
-    residuals<LOGP>(e0 + e1, y4[0], 4 * gk, rows, w, lp);
+    residuals<LOGP, MASK>(e0 + e1, y4[0], 4 * gk, rows, w, lp);
     __builtin_amdgcn_sched_barrier(0);
     issue_y<2>(y_off, y4[0]);
     __builtin_amdgcn_sched_barrier(0);
@@ -542,7 +559,7 @@ struct GermanLane {
     v4f acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    float lp = 0.0f;
+    v2f lp2[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};   // log density of the lane's rows, log2 units
     v4f xa[2][4], y4[2];
     v4f xb[2][4];
     float w[4];
@@ -554,8 +571,13 @@ struct GermanLane {
     first_reads(a_off, b_off, y_off, xa, xb, y4);
     for (int n = 0; n < nt; ++n) {
       const int rows = min(kRows, N - n * kRows);   // the image is zero filled up to the tile's last row
-      head<LOGP>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, lp);
-      phases<LOGP, 0>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, acc, lp);
+      if (!LOGP || rows == kRows) {     // only the log density cares about padding rows, and only the last tile has any
+        head<LOGP, false>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, lp2);
+        phases<LOGP, false, 0>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, acc, lp2);
+      } else {
+        head<LOGP, true>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, lp2);
+        phases<LOGP, true, 0>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, acc, lp2);
+      }
       // every LDS read of this tile has landed (the operands of the last backward block among them)
       constexpr int lb = (kNB - 1) & 1;
       wait_ops<0>(xa[0], xb[lb], y4[0]);
@@ -596,7 +618,8 @@ struct GermanLane {
 #pragma unroll
     for (int r_ = 0; r_ < 4; ++r_)
       *reinterpret_cast<float4*>(xch + j * kXchStride + 16 * gk + 4 * r_) = make_float4(acc[0][r_], acc[1][r_], acc[2][r_], acc[3][r_]);
-    if (LOGP) lpx[lane] = lp;
+    float lp = 0.0f;
+    if (LOGP) lpx[lane] = 0.6931471805599453f * ((lp2[0][0] + lp2[0][1]) + (lp2[1][0] + lp2[1][1]));
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
