@@ -506,6 +506,15 @@ struct GermanLane {
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  // Start of a gradient on the matrix-core path: the staging block (buffer 0) and the previous gradient's tiles are no
+  // longer in use by any wave after the barrier; tile 0 then travels while the prior part of the gradient is computed.
+  ARP_DEV void first_tile() const {
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nt = (N + kRows - 1) / kRows;
+    __syncthreads();
+    issue_tile(0, nt & 1, lds_offset(tile_mem()), wv, threadIdx.x & 63);
+  }
+
   template <bool LOGP>
   ARP_DEV float likelihood_mfma(const float (&beta)[NLS], float (&v)[NLS]) const {
     static_assert(NLS == 16, "K = 4 owns 16 features per lane");
@@ -520,11 +529,7 @@ struct GermanLane {
     const uint32_t tile_off = lds_offset(tile);
     const int nt = (N + kRows - 1) / kRows;
     int buf = nt & 1;
-    ARP_T0(tt);
-    // the staging block (buffer 0) and the previous gradient's tiles are no longer in use by any wave
-    __syncthreads();
-    ARP_T(1, tt);
-    issue_tile(0, buf, tile_off, wv, lane);
+    ARP_T0(tt);   // tile 0 is on its way (first_tile)
 
     float4* own = reinterpret_cast<float4*>(xch + c * kXchStride + 16 * t);
     const float4* mine = reinterpret_cast<const float4*>(xch + j * kXchStride + 16 * gk);
@@ -635,6 +640,7 @@ struct GermanLane {
   template <bool LOGP>
   ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const {
     ARP_T0(tg);
+    if constexpr (K == 4) first_tile();
     const float ols = c0 * q[0];
     float beta[NLS], v[NLS], bls[NLS], r[NLS];
 #pragma unroll
