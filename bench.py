@@ -361,7 +361,7 @@ def main():
         # the plain fused HMC kernel (CP, dual averaging, L leapfrogs, centred trace row every `thin`-th transition)
         lp_, _ = make_launcher(T, thin, plain=True)
         ms = _time_launches(lp_, 5, 2)
-        extras["plain_hmc"] = {"kernel": "radon_hmc_kernel<RadonPk,CP>", "kernel_ms": ms, "num_leapfrog_steps": L,
+        extras["plain_hmc"] = {"kernel": "pk_hmc_kernel<RadonPk<4,17>,CP>", "kernel_ms": ms, "num_leapfrog_steps": L,
                                "leapfrog_steps_per_s": C * T * L / (ms * 1e-3),
                                "fp32_frac": C * T * L * radon_flop_per_leapfrog(J, D) / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
         # strong-scaling shards of the 65 536-chain job on ONE GPU (what a rank of a 2 / 4 / 8 GPU job runs)
@@ -423,7 +423,7 @@ def main():
                                      "frac": Ce * Te * Le * eflop / (ems * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                                      "algorithmic_flop_per_leapfrog": eflop}}
             del ste
-        extras["election"] = {"kernel": "hmc_kernel<ElectionLane>", "chains": Ce, "num_leapfrog_steps": Le, "forms": el}
+        extras["election"] = {"kernel": "pk_hmc_kernel<ElectionPk<4,13>>", "chains": Ce, "num_leapfrog_steps": Le, "forms": el}
         del eeng
 
     # ESS/sec (second half of the BASELINE metric) from the reference flow at the headline size
@@ -449,7 +449,7 @@ def main():
         traffic = prof["hbm_bytes_per_launch"] if prof and prof.get("config_matches_this_run") else None
         roof = {"bound": "valu", "achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / FP32_PEAK_TFLOPS, "traffic": traffic,
-                "kernel": "radon_interleaved_kernel<RadonPk<4,17>>" if inter else "radon_hmc_kernel<RadonPk<4,17>,CP>",
+                "kernel": "radon_interleaved_kernel<RadonPk<4,17>>" if inter else "pk_hmc_kernel<RadonPk<4,17>,CP>",
                 "kernel_ms": kern_ms, "algorithmic_flop_per_leapfrog": flop_lf,
                 "note": "FP32 vector issue binds this kernel (state in registers for the whole launch); frac = SURVEY 8(d) "
                         "algorithmic flops / HIP-event kernel time / 157.3 TFLOP/s",
