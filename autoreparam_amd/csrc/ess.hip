@@ -97,13 +97,20 @@ __global__ __launch_bounds__(256) void ess_kernel(const float* __restrict__ trac
   for (int j = 1; j < kEssWin; ++j) r += j < nh ? fh[j] - fh[0] : 0.0f;
   r = fh[0] + r / (float)nh;
 
-  double dacc[kEssWin + 1], T;
-  ess_sweep<true>(x, S, stride, r, 0, dacc, T);
-  const double mp = T / (double)S;          // mean of y
-  const float mean = r + (float)mp;         // mean of x, for the sweeps past lag 16
-  // centred sums: lag 0 first
+  double dacc[kEssWin + 1], T, mp, c0;
+  float mean;
+  for (int attempt = 0;; ++attempt) {
+    ess_sweep<true>(x, S, stride, r, 0, dacc, T);
+    mp = T / (double)S;                     // mean of y
+    mean = r + (float)mp;                   // mean of x, for the sweeps past lag 16
+    c0 = (dacc[0] - (double)S * mp * mp) / (double)S;
+    // A reference level far from the mean (a series that was still drifting over its first 16 samples) makes the
+    // products large against the variance they are meant to resolve: take the pass again around the mean itself.
+    if (attempt == 1 || !(mp * mp > 64.0 * c0)) break;
+    r = mean;
+  }
+  // centred sums of lags 1 .. 16
   double head = 0.0, tail = 0.0;            // sums of the first / last k values of y
-  const double c0 = (dacc[0] - (double)S * mp * mp) / (double)S;
 #pragma unroll
   for (int j = 1; j <= kEssWin; ++j) {
     head += (double)(fh[j - 1] - r); tail += (double)(ft[j - 1] - r);

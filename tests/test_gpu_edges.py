@@ -137,3 +137,13 @@ def test_native_ess_matches_fft_form_and_ar1(gpu):
     np.testing.assert_allclose(sub, native[3:11], rtol=1e-6)
     const = torch.ones(50, 2, 3, device=gpu)
     assert torch.isnan(util.effective_sample_size(const)).all()
+    # a series whose first samples sit far from where it settles (the one-pass form centres on the first 16 samples and
+    # must notice): float64 FFT form as the reference
+    drift = x.clone()
+    drift[:20] += torch.tensor([50.0, 5e3, 3.0, 2e4, -80.0])
+    nat = util.effective_sample_size(drift.to(gpu)).cpu().numpy()
+    ref = util.effective_sample_size_fft(drift.to(torch.float64)).numpy()
+    np.testing.assert_allclose(nat, ref, rtol=5e-3)
+    short = x[:9].contiguous()            # fewer samples than the window of lags
+    np.testing.assert_allclose(util.effective_sample_size(short.to(gpu)).cpu().numpy(),
+                               util.effective_sample_size_fft(short.to(torch.float64)).numpy(), rtol=2e-3)
