@@ -384,7 +384,7 @@ def main():
         gspec = models._spec_german()
         geng = engine.Engine(gspec, dev)
         geng.set_param(0, "NCP")
-        Cg, Lg, Tg = 16384, 4, 64   # 64 transitions per launch (the CLI runs up to 4 096): the per-launch costs -- state in and out, host call -- are 0.09 ms, 14 % of a 4-transition launch
+        Cg, Lg, Tg = 16384, 4, 64   # 64 transitions per launch (the CLI runs up to 4 096): what a launch costs once -- state in and out, the spread between workgroups over few transitions -- is 0.09 ms, 14 % of a 4-transition launch
         rsg = np.random.RandomState(1)
         stg = engine.ChainState(torch.as_tensor((0.1 * rsg.randn(Cg, gspec.D)).astype(np.float32), device=dev))
         epsg = np.full(gspec.D, 0.005, np.float32)
