@@ -290,9 +290,12 @@ struct GermanLane {
   // row 4g+s from lane group g: no movement between the two products.
   //
   // Tiles of 128 observations travel global memory -> LDS by LDS-DMA (see "tile image" above) into two buffers: while
-  // tile n is multiplied, tile n+1 lands; one workgroup barrier per tile (everybody has finished tile n-1 and
-  // everybody's pieces of tile n have landed).  Tile n uses buffer (n + tiles) & 1, so the last tile of a gradient is
-  // always in buffer 1 and buffer 0 is free for the kernels' row staging between gradients.
+  // tile n is multiplied, tile n+1 lands.  One workgroup barrier per tile, taken in front of the tile's LAST backward
+  // block: by then all of the wave's LDS reads of tile n are complete (the operands of that block are in registers),
+  // so the same barrier publishes tile n+1 (every wave has waited for its own pieces) and frees tile n's buffer for
+  // tile n+2, whose LDS-DMA and the first operand reads of tile n+1 then go out under those last 16 MFMAs.
+  // Tile n uses buffer (n + tiles) & 1, so the last tile of a gradient is always in buffer 1 and buffer 0 is free for
+  // the kernels' row staging between gradients (STAGE_ALIAS above).
   static ARP_DEV void glds16(const float* sbase, uint32_t voff, uint32_t lds_dst) {
     unsigned keep;   // M0 = LDS destination of the wave's 1 KiB; compiler-reserved, so saved and restored in the statement
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
