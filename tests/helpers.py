@@ -7,6 +7,9 @@ MODEL_SPECS = {
     "8schools": lambda: models._spec_eight_schools(),
     "radon_MN": lambda: models._spec_radon("MN"),
     "radon_PA": lambda: models._spec_radon("PA"),
+    "radon_IN": lambda: models._spec_radon("IN"),
+    "radon_MO": lambda: models._spec_radon("MO"),
+    "radon_ND": lambda: models._spec_radon("ND"),
     "german": lambda: models._spec_german(),
     "radon_sd_MN": lambda: models._spec_radon_stddvs("MN"),
     "funnel": lambda: models._spec_funnel(),

@@ -116,3 +116,44 @@ def test_german_observation_tiles(oracle_lib, gpu, n_obs):
             lp, g = lp.cpu().numpy(), g.cpu().numpy()
             assert np.abs(lp - lp_o).max() <= 2e-6 * max(1.0, np.abs(lp_o).max()) + 1e-3, (lanes, kind)
             assert np.abs(g - g_o).max() <= _tol(g_o), (lanes, kind)
+
+
+@pytest.mark.parametrize("ds", ["IN", "MO", "ND"])
+def test_other_radon_datasets(oracle_lib, gpu, ds):
+    """The reference's remaining radon data sets (91, 115 and 53 counties; main.py --dataset): every lanes-per-chain split
+    the library instantiates for them against the float64 oracle, the library's own choice included, and a short
+    interleaved run against the float32 oracle."""
+    import torch
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec("radon_" + ds)
+    eng = engine.Engine(sp, gpu)
+    orc = oracle_lib.OracleModel(sp)
+    x = helpers.states(sp, 70, seed=3)
+    served = []
+    for kind in ("CP", "NCP", "VIP"):
+        a, b = helpers.params(sp, kind)
+        eng.set_param(0, (a, b))
+        lp_o, g_o = orc.logp_grad(x, a, b, dtype=np.float64)
+        for lanes in (0, 4, 8, 16):
+            try:
+                lp, g = eng.logp_grad(x, which=0, lanes=lanes)
+            except RuntimeError:
+                assert lanes != 0          # the default must always be served
+                continue
+            served.append(lanes)
+            assert np.abs(lp.cpu().numpy() - lp_o).max() <= 2e-6 * max(1.0, np.abs(lp_o).max()) + 1e-3, (lanes, kind)
+            assert np.abs(g.cpu().numpy() - g_o).max() <= _tol(g_o), (lanes, kind)
+    assert len(set(served) - {0}) >= 2, served
+    # interleaved CP / NCP, 6 steps, against the float32 oracle on the same seeds and the same lanes per chain
+    cp, ncp = helpers.params(sp, "CP"), helpers.params(sp, "NCP")
+    eng.set_param(0, cp); eng.set_param(1, ncp)
+    q0 = helpers.states(sp, 64, seed=5, scale=0.1)
+    e = np.full(sp.D, 0.02, np.float32)
+    lanes = sorted(set(served) - {0})[0]
+    kw = dict(seed=11, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=4, lanes=lanes)
+    st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+    eng.interleaved_run(st, e, e, 3, 3, 6, **kw)
+    so = oracle_lib.new_state(q0, np.float32)
+    orc.interleaved_run(so, cp, ncp, e, e, 3, 3, 6, **kw)
+    err = np.abs(st.q.cpu().numpy() - so["q"]).max(axis=1) / (np.abs(so["q"]).max() + 1.0)
+    assert (err <= 2e-4).mean() >= 0.95, np.sort(err)[-5:]
