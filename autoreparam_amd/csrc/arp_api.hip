@@ -450,6 +450,15 @@ int arp_transform(arp_model* m, int which, int dir, const float* in, int n_chain
   return 0;
 }
 
+// The step-size recurrences compare log alpha itself with log(target) (kernels.h: adapt_update), which equals TFP's
+// min(log alpha, 0) > log(target) only for a target below 1; a rate <= -1 would flip or zero the step.
+static int check_adapt(const arp_hmc_config* cfg) {
+  if (cfg->adapt_kind == ARP_ADAPT_NONE) return 0;
+  if (!(cfg->adapt_target > 0.0f && cfg->adapt_target < 1.0f)) { set_error("adapt_target must lie in (0, 1)"); return 1; }
+  if (cfg->adapt_kind == ARP_ADAPT_SIMPLE && !(cfg->adapt_rate > 0.0f)) { set_error("adapt_rate must be positive"); return 1; }
+  return 0;
+}
+
 static int fill_params(arp_model* m, const arp_hmc_config* cfg, const arp_hmc_io* io, bool need_cache, HmcParams* Pp) {
   if (cfg->n_chains <= 0 || cfg->n_leapfrog <= 0 || cfg->n_steps < 0 || cfg->thin <= 0 || cfg->step_base < 0) {
     set_error("n_chains, n_leapfrog, thin must be positive and n_steps, step_base non-negative");
@@ -461,6 +470,7 @@ static int fill_params(arp_model* m, const arp_hmc_config* cfg, const arp_hmc_io
     return 1;
   }
   if (cfg->adapt_kind < ARP_ADAPT_NONE || cfg->adapt_kind > ARP_ADAPT_SIMPLE) { set_error("bad adapt_kind"); return 1; }
+  if (check_adapt(cfg)) return 1;
   if (m->D > kMaxD) { set_error("state dimension exceeds the chain kernels' limit (256)"); return 1; }
   HmcParams& P = *Pp;
   P.C = cfg->n_chains; P.L = cfg->n_leapfrog; P.n_steps = cfg->n_steps;
@@ -573,6 +583,23 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   P.prior = cfg->a_prior ? io->prior : nullptr;
   P.a_group = (cfg->learn_a && !cfg->tied_b) ? io->a_group : nullptr;
   P.b_group = (cfg->learn_a && io->wb) ? io->b_group : nullptr;
+  // The kernel indexes LDS with these (device) arrays and assumes a group's members sit contiguously behind their
+  // leader: check that here, once per fit ([D] ints each).
+  for (const int* grp : {P.a_group, P.b_group}) {
+    if (!grp) continue;
+    std::vector<int> g(m->D);
+    ARP_HIP_OK(hipMemcpyAsync(g.data(), grp, m->D * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ARP_HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    for (int d = 0; d < m->D; ++d) {
+      const int l = g[d];
+      bool ok = l >= 0 && l <= d && g[l] == l;
+      for (int e = l; ok && e <= d; ++e) ok = g[e] == l;     // every element between the leader and d belongs to it
+      if (!ok) {
+        set_error("arp_vi_run: a_group / b_group must map every element to the first element of a contiguous group (0 <= g[d] <= d, g[g[d]] == g[d])");
+        return 1;
+      }
+    }
+  }
   o->vi(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, cfg->n_lr, (hipStream_t)stream);
   ARP_HIP_OK(hipGetLastError());
   return 0;
@@ -585,6 +612,7 @@ int arp_adapt_probe(const arp_hmc_config* cfg, const float* log_accept, int n, f
     return 1;
   }
   if (cfg->adapt_kind < ARP_ADAPT_NONE || cfg->adapt_kind > ARP_ADAPT_SIMPLE) { set_error("bad adapt_kind"); return 1; }
+  if (check_adapt(cfg)) return 1;
   HmcParams P{};
   P.n_steps = cfg->n_steps; P.step_base = cfg->step_base;
   P.adapt_kind = cfg->adapt_kind; P.n_adapt = cfg->n_adapt;

@@ -27,8 +27,14 @@ constexpr int kEssWin = ARP_ESS_WIN;      // lags 1..kEssWin come out of the fir
 // the trace; a series whose first 16 auto-correlations are all positive takes another sweep per 16 lags.
 // Loads are issued in batches of 16 independent rows (a thread's consecutive samples are a whole trace row apart: one
 // load per iteration with its wait is latency bound -- the first version of this kernel was, at 29 ms for 18.6 GB).
-// Accumulation is in float, flushed into doubles every 256 samples (v_fma_f64 issues several times slower than
-// v_fma_f32 and made the sweep compute bound); no float sum is longer than 256 products.
+// Accumulation is in float, flushed into doubles every 8 windows = 128 samples (v_fma_f64 issues several times slower
+// than v_fma_f32 and made the sweep compute bound); no float sum is longer than 128 products.  Accuracy: a float sum of
+// 128 products carries <= 128 x 2^-24 ~ 8e-6 relative error on sum |y y'|; the first sweep centres afterwards from raw
+// sums about the reference level r, so with |mean(y)| = m sd the raw sums are (1 + m^2) times the centred ones and rho
+// carries up to ~ (1 + m^2) x 1e-5 absolute error.  The sweep is retaken around the mean itself when m^2 > 16 (below;
+// a whole WAVE retakes it when one of its 64 series does, so the threshold sits where a stationary chain's first 16
+// samples practically never land), which bounds that at 2e-4 -- two orders under the 1 / sqrt(S) sampling noise of rho
+// at any S this path sees.
 template <bool FIRST>
 __device__ __forceinline__ void ess_sweep(const float* __restrict__ x, long long S, long long stride, float mean,
                                           long long kb, double (&dacc)[kEssWin + 1], double& dtot) {
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void ess_kernel(const float* __restrict__ trac
     c0 = (dacc[0] - (double)S * mp * mp) / (double)S;
     // A reference level far from the mean (a series that was still drifting over its first 16 samples) makes the
     // products large against the variance they are meant to resolve: take the pass again around the mean itself.
-    if (attempt == 1 || !(mp * mp > 64.0 * c0)) break;
+    if (attempt == 1 || !(mp * mp > 16.0 * c0)) break;
     r = mean;
   }
   // centred sums of lags 1 .. 16

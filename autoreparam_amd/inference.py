@@ -265,7 +265,8 @@ def _sample(run_segment, st, S, B, thin, C, D, dev, keep_chains, n_acc, chunk_ro
     sample_chain schedule (result r after transition 1 + B + r*thin).  Whole-trace mode keeps the
     reference's [S, C, D] trace; when that does not fit in HBM (or --trace_chunk_rows forces it) the
     kernels accumulate the statistics themselves (arp_hmc_io.stats) and only the first `keep_chains`
-    chains keep a trace.  Returns (trace or None, kept host trace, accept arrays, ess [C, D], estimator)."""
+    chains keep a trace.  Returns (trace or None, kept host trace, accept arrays, ess [C, D], estimator, moments):
+    moments = (mean, var) [C, D] float64 from the in-kernel accumulators in streaming mode, None with a whole trace."""
     rows, streaming = _trace_plan(S, C, D, dev, chunk_rows)
     total = 1 + B + thin * (S - 1)
     if not streaming:
@@ -277,8 +278,8 @@ def _sample(run_segment, st, S, B, thin, C, D, dev, keep_chains, n_acc, chunk_ro
             run_segment(n, B, trace, accs)
             done += n
         ess = util.effective_sample_size(trace)
-        _sample.last_moments = None           # the whole trace is returned: moments are the caller's to take
-        return trace, None, [_DeviceAccept(a) for a in accs], ess, "autocorrelation"
+        # the whole trace is returned: moments are the caller's to take
+        return trace, None, [_DeviceAccept(a) for a in accs], ess, "autocorrelation", None
     batch = max(8, min(rows, S) // 8)
     stats = torch.zeros(6, C, D, dtype=torch.float32, device=dev)
     kept = torch.zeros(S, keep_chains, D, dtype=torch.float32, device=dev)
@@ -294,9 +295,8 @@ def _sample(run_segment, st, S, B, thin, C, D, dev, keep_chains, n_acc, chunk_ro
     mean, var, ess = _engine.stats_summary(stats, S, batch)
     # per-chain posterior mean / variance of every (centred) element from the in-kernel accumulators, [C, D] float64
     # (build-specific: the reference would take them from the [S, C, D] trace this mode does not materialise)
-    _sample.last_moments = (mean, var)
     return None, kept.cpu().numpy(), [a.cpu().numpy()[np.newaxis, :] for a in racc], ess.to(torch.float32), \
-        "batch_means(%d)" % batch
+        "batch_means(%d)" % batch, (mean, var)
 
 
 def _check_trace_fits(S, C, D, dev):
@@ -334,8 +334,9 @@ def hmc(target, model_config, step_size_init, initial_states, reparam, flags=FLA
                     lanes=flags.lanes_per_chain, rec_accept=rec_accept0, **extra)
 
     keep = max(1, int(flags.num_chains_to_save))
-    trace, kept, accs, ess_flat, estimator = _sample(run_segment, st, S, B, thin, C, spec.D, dev, min(keep, C), 1,
-                                                    getattr(flags, "trace_chunk_rows", None))
+    hmc.last_ess_estimator = hmc.last_moments = None      # nothing stale survives a run that raises
+    trace, kept, accs, ess_flat, estimator, moments = _sample(run_segment, st, S, B, thin, C, spec.D, dev, min(keep, C), 1,
+                                                             getattr(flags, "trace_chunk_rows", None))
     torch.cuda.synchronize(dev)
     ess = spec.unpack(ess_flat.cpu().numpy())
     step_mult = st.adapt[:, 0].cpu().numpy()
@@ -349,7 +350,7 @@ def hmc(target, model_config, step_size_init, initial_states, reparam, flags=FLA
         states_transformed = spec.unpack(kept)
         states_orig = None
     hmc.last_ess_estimator = estimator
-    hmc.last_moments = _sample.last_moments
+    hmc.last_moments = moments
     return states_orig, kernel_results, states_transformed, ess
 
 
@@ -380,8 +381,9 @@ def hmc_interleaved(model_config, target_cp, target_ncp, num_leapfrog_steps_cp, 
                             trace_centered=False, lanes=flags.lanes_per_chain, **extra)
 
     keep = max(1, int(flags.num_chains_to_save))
-    trace, kept, accs, ess_flat, estimator = _sample(run_segment, st, S, B, thin, C, spec.D, dev, min(keep, C), 2,
-                                                    getattr(flags, "trace_chunk_rows", None))
+    hmc_interleaved.last_ess_estimator = hmc_interleaved.last_moments = None
+    trace, kept, accs, ess_flat, estimator, moments = _sample(run_segment, st, S, B, thin, C, spec.D, dev, min(keep, C), 2,
+                                                             getattr(flags, "trace_chunk_rows", None))
     torch.cuda.synchronize(dev)
     states = _device_parts(spec, trace) if trace is not None else spec.unpack(kept)
     ess = spec.unpack(ess_flat.cpu().numpy())
@@ -389,5 +391,5 @@ def hmc_interleaved(model_config, target_cp, target_ncp, num_leapfrog_steps_cp, 
         cp_results=KernelResults(HmcInnerResults(accs[0]), st.adapt[:, 0].cpu().numpy(), st.step),
         ncp_results=KernelResults(HmcInnerResults(accs[1]), st.adapt1[:, 0].cpu().numpy(), st.step))
     hmc_interleaved.last_ess_estimator = estimator
-    hmc_interleaved.last_moments = _sample.last_moments
+    hmc_interleaved.last_moments = moments
     return states, kr, ess

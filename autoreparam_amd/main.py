@@ -322,16 +322,18 @@ def main(argv=None, flags=FLAGS):
         local = int(os.environ.get("LOCAL_RANK", "0"))
         flags.device = "cuda:%d" % local
         torch.cuda.set_device(local)
-        if not dist.is_initialized():
+        if flags.inference == "VI":
+            # VI is a one-workgroup-per-learning-rate job with nothing to exchange: rank 0 runs it and writes the
+            # JSON, the other ranks leave, and NO process group is created -- a communicator whose peers have exited
+            # (or a barrier sitting in the RCCL watchdog for as long as the fit takes) is exactly what to avoid.
+            if (dist.get_rank() if dist.is_initialized() else int(os.environ.get("RANK", "0"))) != 0:
+                return None
+        elif not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             try:
                 dist.init_process_group("nccl", device_id=torch.device(flags.device))
             except TypeError:                                     # older torch: no device_id keyword
                 dist.init_process_group("nccl")
-        if flags.inference == "VI" and dist.get_rank() != 0:
-            # VI is a single-workgroup-per-learning-rate job: rank 0 runs it and writes the JSON.  The other ranks
-            # leave without a collective -- a barrier here would sit in the RCCL watchdog for as long as the fit takes
-            return None
     util.print_("Loading model {} with dataset {}.".format(flags.model, flags.dataset))
     model_config = models.get_model_by_name(flags.model, dataset=flags.dataset)
     results_dir = flags.results_dir if flags.results_dir != "" else flags.model + "_" + flags.dataset

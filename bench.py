@@ -194,6 +194,8 @@ def reference_flow_ess(dataset, chains, dev_index, samples=1000, burnin=1000, ad
                 "mcmc_time_sec": float(mcmc_time), "vi_time_sec": t_vi, "tuning_time_sec": t_tune,
                 "trace_first_alloc_sec": t_alloc,
                 "ess_per_sec": ess / float(mcmc_time),
+                # what a fresh process would see: the first device allocation of the trace block inside the clock
+                "ess_per_sec_cold": ess / (float(mcmc_time) + t_alloc),
                 "ess_per_sec_all_chains": ess * chains / float(mcmc_time),
                 "leapfrog_steps_per_s_end_to_end": chains * total_steps * LL / float(mcmc_time),
                 "note": "mcmc_time_sec is main.py's wall clock around the kept candidate's run: sampling, arp_ess over the "

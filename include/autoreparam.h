@@ -188,7 +188,8 @@ typedef struct arp_vi_io {
   const int32_t* a_group;    /* [D] or NULL.  With untied parameters the reference gives `a` the shape of the variable's loc
                               * (program_transformations.py:486-493, 507-510): a vector variable whose loc is a scalar (german
                               * beta_log_scales, election a) learns ONE shared a.  a_group[d] = index of the first element of
-                              * d's group (d itself when its a is its own); groups are contiguous */
+                              * d's group (d itself when its a is its own); groups are contiguous.  DEVICE pointer, like every
+                              * array here; arp_vi_run copies it back once and rejects a map that is not of that form */
   const int32_t* b_group;    /* the same for the separately learned b (shape of the variable's scale; only read with wb) */
 } arp_vi_io;
 int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_io* io, void* stream);

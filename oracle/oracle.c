@@ -63,6 +63,12 @@ typedef struct orc_hmc_cfg {
   void* stats;
   uint32_t* rec_accept;
   uint32_t* rec_accept1;
+  /* test diagnostics, in the run's REAL type, indexed by the in-launch step s (or NULL):
+   * margin [n_steps][kernels][C] = log u - log alpha of every Metropolis test (its sign IS the decision, its size how
+   * close the test sat to its threshold), escale the same shape = max(|logp|, |logp'|, K, K') of that test (the size
+   * of the terms whose float32 rounding can flip it).  kernels = 1 (orc_hmc_run) or 2 (orc_interleaved_run). */
+  void* margin;
+  void* escale;
 } orc_hmc_cfg;
 
 /* ---- RNG: MWC64X streams seeded by Philox4x32-10 (DESIGN.md "Randomness").  The stream record

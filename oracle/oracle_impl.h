@@ -572,7 +572,7 @@ static void FN(draw_momentum)(const orc_model* M, orc_rng* streams, int lanes, R
  * leapfrog steps are merged into one full kick. */
 static REAL FN(hmc_transition)(const orc_model* M, const float* a, const float* b, orc_rng* streams,
                                int lanes, int L, const REAL* eps, REAL* q, REAL* g, REAL* lp,
-                               int* accepted, REAL* work) {
+                               int* accepted, REAL* work, REAL* margin, REAL* escale) {
   const int D = M->D;
   REAL* p = work; REAL* q1 = work + D; REAL* g1 = work + 2 * D;
   REAL u = 1;
@@ -595,6 +595,14 @@ static REAL FN(hmc_transition)(const orc_model* M, const float* a, const float* 
   REAL la = (lp1 - *lp) + (ke0 - ke1);
   if (!isfinite((double)la)) la = -(REAL)INFINITY;
   *accepted = (REAL)log((double)u) < la;
+  if (margin) *margin = (REAL)log((double)u) - la;
+  if (escale) {
+    REAL m = (REAL)fabs((double)*lp);
+    if ((REAL)fabs((double)lp1) > m) m = (REAL)fabs((double)lp1);
+    if (ke0 > m) m = ke0;
+    if (ke1 > m) m = ke1;
+    *escale = m;
+  }
   if (*accepted) {
     for (int d = 0; d < D; ++d) { q[d] = q1[d]; g[d] = g1[d]; }
     *lp = lp1;
@@ -702,7 +710,9 @@ int FN(orc_hmc_run)(const orc_model* M, const float* a, const float* b, const or
       for (int s = 0; s < cfg->n_steps; ++s) {
         for (int d = 0; d < D; ++d) eps[d] = (REAL)eps0[d] * kappa;
         int acc;
-        REAL la = FN(hmc_transition)(M, a, b, st, lanes, cfg->n_leapfrog, eps, qc, gc, &lp, &acc, work);
+        REAL la = FN(hmc_transition)(M, a, b, st, lanes, cfg->n_leapfrog, eps, qc, gc, &lp, &acc, work,
+                                     cfg->margin ? (REAL*)cfg->margin + (size_t)s * C + c : NULL,
+                                     cfg->escale ? (REAL*)cfg->escale + (size_t)s * C + c : NULL);
         nacc += (uint32_t)acc;
         const long long n = cfg->step_base + s + 1;
         FN(adapt_update)(cfg->adapt_kind, n, cfg->n_adapt, (REAL)cfg->adapt_target, (REAL)cfg->adapt_rate,
@@ -765,14 +775,16 @@ int FN(orc_interleaved_run)(const orc_model* M, const float* a0, const float* b0
         int a_0, a_1;
         REAL lp = FN(logp_grad)(M, a0, b0, qc, g);
         for (int d = 0; d < D; ++d) eps[d] = (REAL)eps0_0[d] * k0;
-        REAL la = FN(hmc_transition)(M, a0, b0, st, lanes, cfg->n_leapfrog, eps, qc, g, &lp, &a_0, work);
+        REAL* mg = cfg->margin ? (REAL*)cfg->margin + (size_t)s * 2 * C + c : NULL;
+        REAL* es = cfg->escale ? (REAL*)cfg->escale + (size_t)s * 2 * C + c : NULL;
+        REAL la = FN(hmc_transition)(M, a0, b0, st, lanes, cfg->n_leapfrog, eps, qc, g, &lp, &a_0, work, mg, es);
         n0 += (uint32_t)a_0;
         FN(adapt_update)(cfg->adapt_kind, n, cfg->n_adapt, (REAL)cfg->adapt_target, (REAL)cfg->adapt_rate, la, &k0, &e0, &l0);
         FN(to_centered)(M, a0, b0, qc, xc);
         FN(from_centered)(M, a1, b1, xc, qc);
         lp = FN(logp_grad)(M, a1, b1, qc, g);
         for (int d = 0; d < D; ++d) eps[d] = (REAL)eps0_1[d] * k1;
-        la = FN(hmc_transition)(M, a1, b1, st, lanes, L1, eps, qc, g, &lp, &a_1, work);
+        la = FN(hmc_transition)(M, a1, b1, st, lanes, L1, eps, qc, g, &lp, &a_1, work, mg ? mg + C : NULL, es ? es + C : NULL);
         n1 += (uint32_t)a_1;
         FN(adapt_update)(cfg->adapt_kind, n, cfg->n_adapt, (REAL)cfg->adapt_target, (REAL)cfg->adapt_rate, la, &k1, &e1, &l1);
         FN(to_centered)(M, a1, b1, qc, xc);

@@ -150,10 +150,10 @@ def test_other_radon_datasets(oracle_lib, gpu, ds):
     q0 = helpers.states(sp, 64, seed=5, scale=0.1)
     e = np.full(sp.D, 0.02, np.float32)
     lanes = sorted(set(served) - {0})[0]
-    kw = dict(seed=11, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=4, lanes=lanes)
-    st = engine.ChainState(torch.as_tensor(q0, device=gpu))
-    eng.interleaved_run(st, e, e, 3, 3, 6, **kw)
-    so = oracle_lib.new_state(q0, np.float32)
-    orc.interleaved_run(so, cp, ncp, e, e, 3, 3, 6, **kw)
-    err = np.abs(st.q.cpu().numpy() - so["q"]).max(axis=1) / (np.abs(so["q"]).max() + 1.0)
-    assert (err <= 2e-4).mean() >= 0.95, np.sort(err)[-5:]
+    import parity
+    r = parity.interleaved_every_step(oracle_lib, eng, orc, cp, ncp, q0, e, e, 3, 3, 6, 2e-4, "radon_%s lanes=%d" % (ds, lanes),
+                                      seed=11, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=4, lanes=lanes)
+    ok = r["clean"]
+    err = np.abs(r["st"].q.cpu().numpy() - r["so"]["q"]).max(axis=1) / r["scale"]
+    assert (err[ok] <= 2e-4).all(), np.sort(err[ok])[-5:]
+    assert np.array_equal(r["st"].accept_count.cpu().numpy()[ok], r["so"]["accept_count"][ok])

@@ -110,40 +110,39 @@ def test_electric_rejects_data_its_cell_collapse_cannot_hold(gpu):
         engine.Engine(bad, gpu)
 
 
-def test_native_ess_matches_fft_form_and_ar1(gpu):
-    """arp_ess (direct auto-covariances, cut at the first negative one) against the FFT restatement of
-    tfp.mcmc.effective_sample_size on the same traces, and against the AR(1) known answer
-    ESS / S -> (1 - rho) / (1 + rho)."""
+def test_native_ess_matches_oracle_and_ar1(gpu):
+    """arp_ess (direct auto-covariances, cut at the first negative one) against the ORACLE's float64
+    tfp.mcmc.effective_sample_size restatement (oracle/ess_ref.py: FFT form, TFP defaults; inference.py:240, 327) on the
+    same traces, and against the AR(1) known answer ESS / S -> (1 - rho) / (1 + rho)."""
+    from oracle import ess_ref
     from autoreparam_amd import util
-    g = torch.Generator(device="cpu").manual_seed(5)
     S, Cn, D = 600, 37, 5
-    rho = torch.tensor([0.0, 0.3, 0.6, 0.9, -0.4])
-    e = torch.randn(S, Cn, D, generator=g)
-    x = torch.zeros(S, Cn, D)
-    x[0] = e[0]
-    for t in range(1, S):
-        x[t] = rho * x[t - 1] + torch.sqrt(1 - rho ** 2) * e[t]
-    x = x * torch.tensor([1.0, 10.0, 0.1, 3.0, 1.0]) + torch.tensor([0.0, 100.0, -5.0, 1e3, 0.0])   # scales / offsets
+    rho = np.array([0.0, 0.3, 0.6, 0.9, -0.4])
+    x64 = ess_ref.ar1(S, (Cn, D), rho, seed=5) * [1.0, 10.0, 0.1, 3.0, 1.0] + [0.0, 100.0, -5.0, 1e3, 0.0]   # scales / offsets
+    x = torch.as_tensor(x64, dtype=torch.float32)
     xd = x.to(gpu)
     native = util.effective_sample_size(xd).cpu().numpy()
-    fft = util.effective_sample_size_fft(xd).cpu().numpy()
-    np.testing.assert_allclose(native, fft, rtol=2e-3)
-    expect = ((1 - rho) / (1 + rho)).numpy() * S
-    got = native.mean(axis=0)
-    # positive rho: the truncated estimator is consistent (at rho = 0.9 a 600-sample series is short: looser)
-    assert np.all(np.abs(got[:3] / expect[:3] - 1) < 0.1) and abs(got[3] / expect[3] - 1) < 0.35, (got, expect)
+    ref = ess_ref.ess_fft(x.numpy())                      # the float32 trace the kernel saw, statistic in float64
+    np.testing.assert_allclose(native, ref, rtol=1e-3)
+    # AR(1): a long run pins the estimator itself (ESS/S within 3 % of (1-rho)/(1+rho), averaged over 64 series)
+    long = ess_ref.ar1(20000, (64, 4), rho[:4], seed=6)
+    got = util.effective_sample_size(torch.as_tensor(long, dtype=torch.float32).to(gpu)).cpu().numpy().mean(axis=0) / 20000
+    expect = (1 - rho[:4]) / (1 + rho[:4])
+    assert np.all(np.abs(got / expect - 1) < 0.03), (got, expect)
+    assert np.allclose(native[:, 4], S)                   # negative first lag: the sum stops at lag 0
     # a strided view (sub-range of chains) and a constant series
     sub = util.effective_sample_size(xd[:, 3:11, :]).cpu().numpy()
     np.testing.assert_allclose(sub, native[3:11], rtol=1e-6)
     const = torch.ones(50, 2, 3, device=gpu)
     assert torch.isnan(util.effective_sample_size(const)).all()
     # a series whose first samples sit far from where it settles (the one-pass form centres on the first 16 samples and
-    # must notice): float64 FFT form as the reference
+    # must notice)
     drift = x.clone()
     drift[:20] += torch.tensor([50.0, 5e3, 3.0, 2e4, -80.0])
     nat = util.effective_sample_size(drift.to(gpu)).cpu().numpy()
-    ref = util.effective_sample_size_fft(drift.to(torch.float64)).numpy()
-    np.testing.assert_allclose(nat, ref, rtol=5e-3)
+    np.testing.assert_allclose(nat, ess_ref.ess_fft(drift.numpy()), rtol=5e-3)
     short = x[:9].contiguous()            # fewer samples than the window of lags
-    np.testing.assert_allclose(util.effective_sample_size(short.to(gpu)).cpu().numpy(),
-                               util.effective_sample_size_fft(short.to(torch.float64)).numpy(), rtol=2e-3)
+    np.testing.assert_allclose(util.effective_sample_size(short.to(gpu)).cpu().numpy(), ess_ref.ess_fft(short.numpy()), rtol=2e-3)
+    # series slow enough to need lag sweeps past the first window (rho = 0.98: ~ 100 positive lags)
+    slow = torch.as_tensor(ess_ref.ar1(3000, (16, 3), [0.98, 0.95, 0.5], seed=7), dtype=torch.float32)
+    np.testing.assert_allclose(util.effective_sample_size(slow.to(gpu)).cpu().numpy(), ess_ref.ess_fft(slow.numpy()), rtol=2e-3)

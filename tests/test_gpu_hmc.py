@@ -6,8 +6,10 @@ import pytest
 import torch
 
 import helpers
+import parity
 
 pytestmark = pytest.mark.gpu
+ADAPT_MARGIN = 0.05   # dual averaging: log alpha inherits the (<= 2 %) step-size difference of the two runs
 LANES = {"8schools": [1, 8], "radon_MN": [4, 8, 16], "radon_PA": [4, 8, 16], "election": [4, 8, 16], "german": [4, 8, 16], "radon_sd_MN": [8, 16], "funnel": [1], "electric": [16], "time_series": [4]}
 
 
@@ -29,9 +31,12 @@ def _eps0(oracle_lib, sp, a, b, x, frac):
     return (frac / np.sqrt(np.abs(diag) + 1.0)).astype(np.float32)
 
 
-def _compare(oracle_lib, gpu, mname, kind, lanes, adapt_kind, frac, L, n, n_adapt=0, sp=None):
-    """Run the HIP kernel and the float32 oracle on the same seeds; return per-chain
-    max |q_hip - q_oracle| (relative to the state scale) and the two final states."""
+def _compare(oracle_lib, gpu, mname, kind, lanes, adapt_kind, frac, L, n, n_adapt=0, sp=None, Cn=96, state_tol=1e-4,
+             margin_extra=0.0):
+    """Run the HIP kernel and the float32 oracle on the same seeds, twice: once on the recording schedule under test
+    (burn-in 2, every third transition: trace rows, accept flags) and once recording EVERY transition (state in sampler
+    coordinates + accept flag + the oracle's Metropolis margins), which is what `helpers.explain_divergence` needs to
+    hold every chain either to step-by-step agreement or to a decision that sat at its threshold.  Returns a dict."""
     from autoreparam_amd import engine
     if sp is None:
         sp = helpers.spec(mname)
@@ -41,46 +46,52 @@ def _compare(oracle_lib, gpu, mname, kind, lanes, adapt_kind, frac, L, n, n_adap
     orc = oracle_lib.OracleModel(sp)
     a, b = helpers.params(sp, kind)
     eng.set_param(0, (a, b))
-    Cn = 96
     q0 = helpers.states(sp, Cn, seed=2, scale=0.1)
     eps0 = _eps0(oracle_lib, sp, a, b, q0, frac)
+    kw = dict(seed=9, chain_offset=1000, adapt_kind=adapt_kind, n_adapt=n_adapt, lanes=lanes)
+    # run A: the schedule
     st = engine.ChainState(torch.as_tensor(q0, device=gpu))
     tr = torch.zeros(4, Cn, sp.D, device=gpu); ta = torch.zeros(4, Cn, dtype=torch.uint8, device=gpu)
-    eng.hmc_run(st, eps0, L, n, seed=9, chain_offset=1000, adapt_kind=adapt_kind, n_adapt=n_adapt,
-                n_burnin=2, thin=3, trace=tr, trace_accept=ta, trace_centered=True, lanes=lanes)
+    eng.hmc_run(st, eps0, L, n, n_burnin=2, thin=3, trace=tr, trace_accept=ta, trace_centered=True, **kw)
     so = oracle_lib.new_state(q0, np.float32)
     tro = np.zeros((4, Cn, sp.D), np.float32); tao = np.zeros((4, Cn), np.uint8)
-    orc.hmc_run(so, a, b, eps0, L, n, seed=9, chain_offset=1000, adapt_kind=adapt_kind, n_adapt=n_adapt,
-                n_burnin=2, thin=3, trace=tro, trace_accept=tao, trace_centered=True, lanes=lanes)
-    scale = np.abs(so["q"]).max() + 1.0
+    orc.hmc_run(so, a, b, eps0, L, n, n_burnin=2, thin=3, trace=tro, trace_accept=tao, trace_centered=True, **kw)
+    # run B: every transition
+    r = parity.hmc_every_step(oracle_lib, eng, orc, (a, b), q0, eps0, L, n, state_tol, "%s %s lanes=%d" % (mname, kind, lanes),
+                              margin_extra=margin_extra, **kw)
+    # what is recorded does not change the chain
+    assert torch.equal(st.q, r["st"].q) and torch.equal(st.rng, r["st"].rng) and np.array_equal(so["q"], r["so"]["q"])
+    scale, clean, first, mg, es = r["scale"], r["clean"], r["first"], r["margin"], r["escale"]
     err = np.abs(st.q.cpu().numpy() - so["q"]).max(axis=1) / scale
     # trace rows are in centred coordinates, whose magnitude can exceed the sampler coordinates'
     # (time_series accumulates its latents along the chain): scale each chain's rows by their own size
     terr = np.abs(tr.cpu().numpy() - tro).max(axis=(0, 2)) / np.maximum(scale, np.abs(tro).max(axis=(0, 2)) + 1.0)
-    return err, terr, st, so, ta.cpu().numpy(), tao
+    return dict(clean=clean, first=first, err=err, terr=terr, st=st, so=so, ta=ta.cpu().numpy(), tao=tao, margin=mg,
+                escale=es)
 
 
 @pytest.mark.parametrize("mname", ["8schools", "radon_MN", "radon_PA", "election", "german", "radon_sd_MN", "funnel", "electric", "time_series"])
 @pytest.mark.parametrize("kind", ["CP", "NCP", "VIP"])
 def test_trajectories_match_oracle_fixed_step(oracle_lib, gpu, mname, kind):
-    """Fixed step (the parity configuration of north_star): per-chain trajectories
-    agree with the float32 oracle to float32 tolerance after 12 transitions.  A
-    chain whose Metropolis test fell within rounding of its threshold may branch
-    the other way; at most 5 % of chains may do so, all others must agree."""
+    """Fixed step (the parity configuration of north_star): after 12 transitions EVERY chain either agrees with the
+    float32 oracle step by step to float32 tolerance, or parts from it at a Metropolis test whose margin in the oracle's
+    run was within rounding of zero (helpers.explain_divergence); the chains that never branched are then compared on
+    the final state, the trace schedule, acceptance and the log density, the random streams bitwise on all chains."""
     for lanes in LANES[mname]:
-        err, terr, st, so, ta, tao = _compare(oracle_lib, gpu, mname, kind, lanes, 0, 0.05, 4, 12)
-        ok = err <= 1e-4
-        assert ok.mean() >= 0.95, (lanes, ok.mean(), np.sort(err)[-5:])
+        r = _compare(oracle_lib, gpu, mname, kind, lanes, 0, 0.05, 4, 12)
+        ok, st, so = r["clean"], r["st"], r["so"]
+        assert (r["err"][ok] <= 1e-4).all(), (lanes, np.sort(r["err"][ok])[-5:])
         # the map to centred coordinates can amplify a state difference that is inside the tolerance
         # (time_series sums 60 latents along the chain): nearly all rows to 1e-4, every row to 1e-2
+        terr = r["terr"]
         assert (terr[ok] <= 1e-4).mean() >= 0.98 and (terr[ok] <= 1e-2).all(), (lanes, np.sort(terr[ok])[-3:])
         assert np.array_equal(st.accept_count.cpu().numpy()[ok], so["accept_count"][ok])
-        assert np.array_equal(ta[:, ok], tao[:, ok])
+        assert np.array_equal(r["ta"][:, ok], r["tao"][:, ok])
         # time_series: |logp| ~ 1e9 with gradients ~ 1e9 per unit at these states, so a state difference inside the
         # tolerance moves logp by more than float32 resolution
         lp_tol = 1e-4 if mname == "time_series" else 2e-5
         assert np.abs(st.logp.cpu().numpy()[ok] - so["logp"][ok]).max() <= lp_tol * np.abs(so["logp"]).max() + 2e-3
-        # the streams are part of the specification: states must be bitwise equal
+        # the streams are part of the specification: states must be bitwise equal (branched chains included)
         assert np.array_equal(st.rng.cpu().numpy().view(np.uint32)[:, :lanes], so["rng"][:, :lanes])
 
 
@@ -94,12 +105,12 @@ def test_german_trajectories_on_one_three_and_five_tiles(oracle_lib, gpu, n_obs)
     sp = copy.copy(full)
     sp.raw = dict(full.raw); sp.raw["X"] = full.raw["X"][:n_obs]; sp.raw["y"] = full.raw["y"][:n_obs]
     sp.observed = {"y": sp.raw["y"][None]}
-    err, terr, st, so, ta, tao = _compare(oracle_lib, gpu, "german", "NCP", 4, 0, 0.05, 4, 12, sp=sp)
-    ok = err <= 1e-4
-    assert ok.mean() >= 0.95, (ok.mean(), np.sort(err)[-5:])
-    assert (terr[ok] <= 1e-4).mean() >= 0.98 and (terr[ok] <= 1e-2).all()
-    assert np.array_equal(st.accept_count.cpu().numpy()[ok], so["accept_count"][ok])
-    assert np.array_equal(ta[:, ok], tao[:, ok])
+    r = _compare(oracle_lib, gpu, "german", "NCP", 4, 0, 0.05, 4, 12, sp=sp)
+    ok = r["clean"]
+    assert (r["err"][ok] <= 1e-4).all()
+    assert (r["terr"][ok] <= 1e-4).mean() >= 0.98 and (r["terr"][ok] <= 1e-2).all()
+    assert np.array_equal(r["st"].accept_count.cpu().numpy()[ok], r["so"]["accept_count"][ok])
+    assert np.array_equal(r["ta"][:, ok], r["tao"][:, ok])
 
 
 @pytest.mark.parametrize("mname", ["election", "radon_PA", "german"])
@@ -107,12 +118,12 @@ def test_trajectories_match_oracle_b_equal_one(oracle_lib, gpu, mname):
     """a free, b = 1 (the parameterisation tied cVIP / dVIP runs execute): election has a compile-time form
     for it, the other models take the general path; both against the oracle."""
     for lanes in LANES[mname]:
-        err, terr, st, so, ta, tao = _compare(oracle_lib, gpu, mname, "B1", lanes, 0, 0.05, 4, 12)
-        ok = err <= 1e-4
-        assert ok.mean() >= 0.95, (lanes, ok.mean(), np.sort(err)[-5:])
-        assert (terr[ok] <= 1e-4).mean() >= 0.98 and (terr[ok] <= 1e-2).all()
-        assert np.array_equal(st.accept_count.cpu().numpy()[ok], so["accept_count"][ok])
-        assert np.array_equal(st.rng.cpu().numpy().view(np.uint32)[:, :lanes], so["rng"][:, :lanes])
+        r = _compare(oracle_lib, gpu, mname, "B1", lanes, 0, 0.05, 4, 12)
+        ok = r["clean"]
+        assert (r["err"][ok] <= 1e-4).all(), (lanes, np.sort(r["err"][ok])[-5:])
+        assert (r["terr"][ok] <= 1e-4).mean() >= 0.98 and (r["terr"][ok] <= 1e-2).all()
+        assert np.array_equal(r["st"].accept_count.cpu().numpy()[ok], r["so"]["accept_count"][ok])
+        assert np.array_equal(r["st"].rng.cpu().numpy().view(np.uint32)[:, :lanes], r["so"]["rng"][:, :lanes])
 
 
 def test_adaptation_recurrence_on_scripted_acceptance(oracle_lib, gpu):
@@ -152,19 +163,20 @@ def test_adaptation_recurrence_on_scripted_acceptance(oracle_lib, gpu):
                                         ("radon_PA", "CP")])
 @pytest.mark.parametrize("adapt", [1, 2])
 def test_adaptation_matches_oracle(oracle_lib, gpu, mname, kind, adapt):
-    """Dual-averaging / simple adaptation state after 10 adapting + 4 frozen
-    transitions.  Dual averaging starts by exploring at 10x the base step, where
-    the energy error (hence the acceptance probability fed back into the step) is
-    very sensitive to rounding, so states are compared on the step multiplier and
-    the error sum with a 2 % tolerance rather than coordinate by coordinate."""
+    """Dual-averaging / simple adaptation state after 10 adapting + 4 frozen transitions.  Dual averaging starts by
+    exploring at 10x the base step and feeds exp(log alpha) back into the step, so a rounding difference in an energy
+    moves the NEXT step size (continuously: no branching), and states are compared to 2 % on the step multiplier and
+    0.02 on the error sum rather than coordinate by coordinate.  Every chain must still be explained: no accept
+    decision may differ unless its margin sat at the threshold (widened by the 2 % the step sizes may differ by)."""
     lanes = LANES[mname][0] if mname in ("german", "radon_PA") else LANES[mname][-1]   # the lane counts the configs run
     frac = 0.002 if mname in ("election", "german") else 0.02   # keep the 10x exploration phase inside the stable region
-    err, terr, st, so, ta, tao = _compare(oracle_lib, gpu, mname, kind, lanes, adapt, frac, 3, 14, n_adapt=10)
+    r = _compare(oracle_lib, gpu, mname, kind, lanes, adapt, frac, 3, 14, n_adapt=10,
+                 state_tol=5e-3 if adapt == 1 else 1e-4, margin_extra=ADAPT_MARGIN if adapt == 1 else 0.0)
+    ok, st, so = r["clean"], r["st"], r["so"]
     ad, ado = st.adapt.cpu().numpy()[:, :3], so["adapt"][:, :3]
     close = (np.abs(ad[:, 0] / ado[:, 0] - 1) <= 0.02) & (np.abs(ad[:, 1] - ado[:, 1]) <= 0.02)
-    assert close.mean() >= 0.8, close.mean()
-    same_acc = st.accept_count.cpu().numpy() == so["accept_count"]
-    assert same_acc.mean() >= 0.85, same_acc.mean()
+    assert close[ok].all(), (int((~close[ok]).sum()), int(ok.sum()))
+    assert np.array_equal(st.accept_count.cpu().numpy()[ok], so["accept_count"][ok])
 
 
 @pytest.mark.parametrize("mname", ["radon_MN", "election"])
@@ -291,39 +303,45 @@ def test_full_size_interleaved_posterior(gpu, oracle_lib):
 
 @pytest.mark.parametrize("mname", ["8schools", "radon_PA", "election", "german", "radon_sd_MN", "funnel", "electric", "time_series"])
 def test_interleaved_matches_oracle(oracle_lib, gpu, mname):
-    """Interleaved CP/NCP kernel (interleaved.py:113-155) against the float32 oracle:
-    fixed small step sizes during the compared stretch, simple adaptation on."""
+    """Interleaved CP/NCP kernel (interleaved.py:113-155) against the float32 oracle, EVERY lanes-per-chain split the
+    library instantiates (radon_PA at 4 lanes is the instantiation bench.py times): fixed small step sizes, simple
+    adaptation on, the GPU run cut into two launches.  96 chains fill whole waves (radon: the compile-time row-store
+    branch), 70 leave a ragged last wave (the general branch).  Every chain agrees step by step or parts at a
+    Metropolis test at its threshold; trace rows, both accept arrays and both adaptation states are compared."""
     from autoreparam_amd import engine, _lib
     sp = helpers.spec(mname)
     eng = _eng(mname, gpu)
     orc = oracle_lib.OracleModel(sp)
     cp, ncp = helpers.params(sp, "CP"), helpers.params(sp, "NCP")
     eng.set_param(0, cp); eng.set_param(1, ncp)
-    Cn = 96
-    q0 = helpers.states(sp, Cn, seed=6, scale=0.1)
-    e0 = _eps0(oracle_lib, sp, cp[0], cp[1], q0, 0.03)
-    q0n = orc.transform(q0, ncp[0], ncp[1], to_centered=False).astype(np.float32)
-    e1 = _eps0(oracle_lib, sp, ncp[0], ncp[1], q0n, 0.03)
-    for lanes in LANES[mname][-2:]:
-        st = engine.ChainState(torch.as_tensor(q0, device=gpu))
-        tr = torch.zeros(3, Cn, sp.D, device=gpu)
-        t0 = torch.zeros(3, Cn, dtype=torch.uint8, device=gpu); t1 = torch.zeros(3, Cn, dtype=torch.uint8, device=gpu)
-        kw = dict(seed=13, chain_offset=77, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=4, n_burnin=1, thin=2, lanes=lanes)
-        eng.interleaved_run(st, e0, e1, 3, 2, 3, trace=tr, trace_accept0=t0, trace_accept1=t1, **kw)
-        eng.interleaved_run(st, e0, e1, 3, 2, 3, trace=tr, trace_accept0=t0, trace_accept1=t1, **kw)  # chunked
-        so = oracle_lib.new_state(q0, np.float32)
-        tro = np.zeros((3, Cn, sp.D), np.float32); t0o = np.zeros((3, Cn), np.uint8); t1o = np.zeros((3, Cn), np.uint8)
-        orc.interleaved_run(so, cp, ncp, e0, e1, 3, 2, 6, trace=tro, trace_acc0=t0o, trace_acc1=t1o, **kw)
-        scale = np.abs(so["q"]).max() + 1.0
-        err = np.abs(st.q.cpu().numpy() - so["q"]).max(axis=1) / scale
-        ok = err <= 2e-4
-        assert ok.mean() >= 0.95, (lanes, ok.mean(), np.sort(err)[-4:])
-        assert np.array_equal(st.accept_count.cpu().numpy()[ok], so["accept_count"][ok])
-        assert np.array_equal(st.accept_count1.cpu().numpy()[ok], so["accept_count1"][ok])
-        assert np.abs(tr.cpu().numpy()[:, ok] - tro[:, ok]).max() <= 2e-4 * scale
-        assert np.array_equal(t0.cpu().numpy()[:, ok], t0o[:, ok]) and np.array_equal(t1.cpu().numpy()[:, ok], t1o[:, ok])
-        np.testing.assert_allclose(st.adapt.cpu().numpy()[ok, 0], so["adapt"][ok, 0], rtol=1e-5)
-        np.testing.assert_allclose(st.adapt1.cpu().numpy()[ok, 0], so["adapt1"][ok, 0], rtol=1e-5)
+    for lanes in LANES[mname]:
+        for Cn in (96, 70):
+            q0 = helpers.states(sp, Cn, seed=6, scale=0.1)
+            e0 = _eps0(oracle_lib, sp, cp[0], cp[1], q0, 0.03)
+            q0n = orc.transform(q0, ncp[0], ncp[1], to_centered=False).astype(np.float32)
+            e1 = _eps0(oracle_lib, sp, ncp[0], ncp[1], q0n, 0.03)
+            kw = dict(seed=13, chain_offset=77, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=4, lanes=lanes)
+            r = parity.interleaved_every_step(oracle_lib, eng, orc, cp, ncp, q0, e0, e1, 3, 2, 6, 2e-4,
+                                              "%s lanes=%d C=%d" % (mname, lanes, Cn), chunks=[3, 3], **kw)
+            ok, so, scale = r["clean"], r["so"], r["scale"]
+            # the recording schedule under test: burn-in 1, every second step, the run cut into two launches
+            st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+            tr = torch.zeros(3, Cn, sp.D, device=gpu)
+            t0 = torch.zeros(3, Cn, dtype=torch.uint8, device=gpu); t1 = torch.zeros(3, Cn, dtype=torch.uint8, device=gpu)
+            for _ in range(2):
+                eng.interleaved_run(st, e0, e1, 3, 2, 3, trace=tr, trace_accept0=t0, trace_accept1=t1, n_burnin=1, thin=2, **kw)
+            assert torch.equal(st.q, r["st"].q) and torch.equal(st.rng, r["st"].rng)     # recording does not change the chain
+            assert torch.equal(tr, r["x"][1::2]) and np.array_equal(t0.cpu().numpy(), r["acc"][1::2, 0]) \
+                and np.array_equal(t1.cpu().numpy(), r["acc"][1::2, 1])
+            err = np.abs(st.q.cpu().numpy() - so["q"]).max(axis=1) / scale
+            assert (err[ok] <= 2e-4).all(), (lanes, Cn, np.sort(err[ok])[-4:])
+            assert np.array_equal(st.accept_count.cpu().numpy()[ok], so["accept_count"][ok])
+            assert np.array_equal(st.accept_count1.cpu().numpy()[ok], so["accept_count1"][ok])
+            assert np.abs(r["x"].cpu().numpy()[:, ok] - r["xo"][:, ok]).max() <= 2e-4 * scale
+            assert np.array_equal(r["acc"][:, :, ok], r["acco"][:, :, ok])
+            np.testing.assert_allclose(st.adapt.cpu().numpy()[ok, 0], so["adapt"][ok, 0], rtol=1e-5)
+            np.testing.assert_allclose(st.adapt1.cpu().numpy()[ok, 0], so["adapt1"][ok, 0], rtol=1e-5)
+            assert np.array_equal(st.rng.cpu().numpy().view(np.uint32)[:, :lanes], so["rng"][:, :lanes])
 
 
 def _schools_quadrature():
@@ -443,15 +461,22 @@ def test_in_kernel_statistics_match_trace_and_oracle(oracle_lib, gpu, mname, lan
     ss = inference.StreamingStats(Cn, sp.D, batch, gpu); ss.update(tr_a)
     ok = torch.isfinite(ss.ess()) & (ss.ess() < S)
     assert torch.allclose(ess.float()[ok], ss.ess()[ok], rtol=2e-3)
-    # oracle, float32, same schedule
+    # oracle, float32, same schedule; chains are compared unless they parted from the oracle at a Metropolis test at
+    # its threshold (every-step run of the same seeds)
     so = oracle_lib.new_state(q0, np.float32)
     stats_o = np.zeros((6, Cn, sp.D), np.float32); racc_o = np.zeros(Cn, np.uint32)
     orc.hmc_run(so, a, b, eps0, 3, total, stats=stats_o, stats_batch=batch, n_samples=S, rec_accept=racc_o, **kw)
-    same = np.abs(st_b.q.cpu().numpy() - so["q"]).max(axis=1) <= 1e-4 * (np.abs(so["q"]).max() + 1)
-    assert same.mean() >= 0.9
-    sg = stats.cpu().numpy()
-    tol = 1e-4 * (np.abs(stats_o).max(axis=(1, 2), keepdims=True) + 1)
-    assert (np.abs(sg - stats_o)[:, same] <= tol).all()
+    r = parity.hmc_every_step(oracle_lib, eng, orc, (a, b), q0, eps0, 3, total, 1e-4, "%s lanes=%d stats" % (mname, lanes),
+                              seed=8, lanes=lanes)
+    same = r["clean"]
+    assert torch.equal(r["st"].q, st_b.q)
+    assert (np.abs(st_b.q.cpu().numpy() - so["q"]).max(axis=1)[same] <= 1e-4 * (np.abs(so["q"]).max() + 1)).all()
+    mean_o, var_o, ess_o = engine.stats_summary(torch.as_tensor(stats_o), S, batch)
+    sc, sm = scale.cpu(), torch.as_tensor(same)
+    assert ((mean.cpu() - mean_o).abs() / sc)[sm].max() < 2e-5
+    assert ((var.cpu() - var_o).abs() / (sc * sc))[sm].max() < 2e-5
+    fin = torch.isfinite(ess_o) & (ess_o < S) & ok.cpu() & sm[:, None]
+    assert torch.allclose(ess.cpu()[fin], ess_o[fin], rtol=5e-3)
     assert np.array_equal(racc.cpu().numpy()[same], racc_o[same].astype(np.int64))
 
 

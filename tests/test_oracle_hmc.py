@@ -239,3 +239,41 @@ def test_streaming_statistics_equal_trace_moments(oracle_lib):
     bm = (tr - ref).reshape(S // batch, batch, C, sp.D).mean(axis=1)
     np.testing.assert_allclose(sb1, bm.sum(axis=0), rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(sb2, (bm * bm).sum(axis=0), rtol=1e-10, atol=1e-12)
+
+
+def test_metropolis_margins_explain_the_decisions(oracle_lib):
+    """The diagnostics the GPU parity tests lean on: margin = log u - log alpha of every Metropolis test (negative iff
+    the proposal was accepted) and escale = the largest energy term that test compared, for orc_hmc_run and for both
+    kernels of orc_interleaved_run; the float32 and float64 runs agree on every decision whose margin is not tiny."""
+    sp = helpers.spec("radon_PA")
+    orc = oracle_lib.OracleModel(sp)
+    cp, ncp = helpers.params(sp, "CP"), helpers.params(sp, "NCP")
+    Cn, n = 40, 9
+    q0 = helpers.states(sp, Cn, seed=3, scale=0.1)
+    eps0 = np.full(sp.D, 0.05, np.float32)
+    runs = {}
+    for dt in (np.float32, np.float64):
+        st = oracle_lib.new_state(q0, dt)
+        mg = np.full((n, Cn), np.nan, dt); es = np.full((n, Cn), np.nan, dt); ta = np.zeros((n, Cn), np.uint8)
+        orc.hmc_run(st, cp[0], cp[1], eps0, 4, n, seed=2, lanes=4, n_burnin=0, thin=1, trace_accept=ta, margin=mg, escale=es)
+        assert np.isfinite(es).all() and not np.isnan(mg).any()
+        assert np.array_equal(mg < 0, ta.astype(bool))
+        assert (es >= np.abs(st["logp"]).min() * 0).all() and es.max() > 1.0
+        runs[dt] = (mg, ta, es)
+    (m32, a32, _), (m64, a64, e64) = runs[np.float32], runs[np.float64]
+    differ = (a32 != a64).any(axis=0)
+    # float32 rounding of the energies moves log alpha by a few ulps of their size: only a decision that close can differ
+    tol = 1e-3 + 64 * np.finfo(np.float32).eps * e64
+    for c in np.where(differ)[0]:
+        s = int(np.argmax(a32[:, c] != a64[:, c]))
+        assert abs(m64[s, c]) < tol[s, c], (c, s, m64[s, c])
+    same = ~differ
+    assert (np.abs(m32 - m64)[:, same] <= 8 * tol[:, same]).all()   # trajectories agree; rounding accumulates over the run
+    # interleaved: [n_steps, 2, C], kernel 0 = parameterisation 0
+    st = oracle_lib.new_state(q0, np.float64)
+    mg = np.full((n, 2, Cn), np.nan); es = np.full((n, 2, Cn), np.nan)
+    t0 = np.zeros((n, Cn), np.uint8); t1 = np.zeros((n, Cn), np.uint8)
+    orc.interleaved_run(st, cp, ncp, eps0, eps0, 3, 2, n, seed=4, lanes=4, n_burnin=0, thin=1, trace_acc0=t0, trace_acc1=t1,
+                        margin=mg, escale=es)
+    assert np.array_equal(mg[:, 0] < 0, t0.astype(bool)) and np.array_equal(mg[:, 1] < 0, t1.astype(bool))
+    assert np.isfinite(es).all()
