@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -112,6 +113,12 @@ struct Launch {
   }
 };
 
+// experiments only: ARP_STATS_LDS=0 sends statistics runs down the plane-per-sample route of kernels.h again
+inline bool stats_lds_enabled() {
+  static const bool on = [] { const char* e = getenv("ARP_STATS_LDS"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 // Radon: the generic lane kernels serve the general VIP form, the packed kernels of radon_fast.h the two
 // compile-time parameterisations (centred, non-centred) and their interleaving.
 template <int K, int NL>
@@ -119,18 +126,23 @@ LaneOps radon_lane_ops() {
   LaneOps o = Launch<RadonLane<K, NL>>::ops();
   if constexpr (K >= 4) {
     using T = RadonPk<K, NL>;
+    // a run that accumulates statistics takes the instantiation with the accumulators in LDS when they fit
+    constexpr bool SL = PkBlock<T>::kStatsFit;
     o.hmc_cp = [](const void* args, const float*, const float*, const HmcParams& P, hipStream_t s) {
-      hipLaunchKernelGGL((pk_hmc_kernel<T, kModeCP>), dim3(Launch<RadonLane<K, NL>>::blocks(P.C)), dim3(kBlock), 0, s,
-                         *(const RadonArgs*)args, nullptr, nullptr, P);
+      const dim3 g(Launch<RadonLane<K, NL>>::blocks(P.C));
+      if (SL && P.stats && stats_lds_enabled()) hipLaunchKernelGGL((pk_hmc_kernel<T, kModeCP, SL>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, nullptr, nullptr, P);
+      else hipLaunchKernelGGL((pk_hmc_kernel<T, kModeCP>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, nullptr, nullptr, P);
     };
     o.hmc_ncp = [](const void* args, const float*, const float*, const HmcParams& P, hipStream_t s) {
-      hipLaunchKernelGGL((pk_hmc_kernel<T, kModeNCP>), dim3(Launch<RadonLane<K, NL>>::blocks(P.C)), dim3(kBlock), 0, s,
-                         *(const RadonArgs*)args, nullptr, nullptr, P);
+      const dim3 g(Launch<RadonLane<K, NL>>::blocks(P.C));
+      if (SL && P.stats && stats_lds_enabled()) hipLaunchKernelGGL((pk_hmc_kernel<T, kModeNCP, SL>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, nullptr, nullptr, P);
+      else hipLaunchKernelGGL((pk_hmc_kernel<T, kModeNCP>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, nullptr, nullptr, P);
     };
     o.interleaved_cp_ncp = [](const void* args, const float*, const float*, const float*, const float*,
                               const HmcParams& P, hipStream_t s) {
-      hipLaunchKernelGGL((radon_interleaved_kernel<T>), dim3(Launch<RadonLane<K, NL>>::blocks(P.C)), dim3(kBlock), 0, s,
-                         *(const RadonArgs*)args, P);
+      const dim3 g(Launch<RadonLane<K, NL>>::blocks(P.C));
+      if (SL && P.stats && stats_lds_enabled()) hipLaunchKernelGGL((radon_interleaved_kernel<T, SL>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, P);
+      else hipLaunchKernelGGL((radon_interleaved_kernel<T>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, P);
     };
   }
   return o;
@@ -143,10 +155,14 @@ LaneOps election_lane_ops() {
   LaneOps o = Launch<ElectionLane<K, NL>>::ops();
   if constexpr (K >= 4) {
     using T = ElectionPk<K, NL>;
+    constexpr bool SL = PkBlock<T>::kStatsFit;   // statistics accumulators in LDS (two workgroups per CU instead of three)
 #define ARP_EL(MODE)                                                                                              \
     [](const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s) {                     \
-      hipLaunchKernelGGL((pk_hmc_kernel<T, MODE>), dim3(Launch<ElectionLane<K, NL>>::blocks(P.C)), dim3(kBlock), 0, s, \
-                         *(const ElectionArgs*)args, a, b, P);                                                     \
+      const dim3 g(Launch<ElectionLane<K, NL>>::blocks(P.C));                                                      \
+      if (SL && P.stats && stats_lds_enabled())                                                                    \
+        hipLaunchKernelGGL((pk_hmc_kernel<T, MODE, SL>), g, dim3(kBlock), 0, s, *(const ElectionArgs*)args, a, b, P); \
+      else                                                                                                         \
+        hipLaunchKernelGGL((pk_hmc_kernel<T, MODE>), g, dim3(kBlock), 0, s, *(const ElectionArgs*)args, a, b, P);  \
     }
     o.hmc_cp = ARP_EL(kModeCP);
     o.hmc_ncp = ARP_EL(kModeNCP);

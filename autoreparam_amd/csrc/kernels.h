@@ -208,6 +208,62 @@ __device__ __noinline__ void stats_update_staged(const float* stage, float* g, s
   }
 }
 
+// The packed chain kernels (pk_chain.h) keep the running mean m and the centred second moment M2 of the samples of the
+// current batch in LDS (Welford updates, no HBM traffic per sample) and FOLD them into the six planes when a batch or the
+// launch ends: `sm` / `sM2` are the wave's rows of m and M2 staged like the memory image, n the samples they hold.
+//   ref (plane 0) = m of the first fold (any level near the samples serves; the planes are zero before it),
+//   d = m - ref,  s1 += n d,  s2 += M2 + n d^2;  at a batch end bm = (s1 - cur) / batch, sb1 += bm, sb2 += bm^2, cur = s1
+// -- the same six sums as stats_update_staged up to rounding, with 11 plane slices moved per batch (or launch)
+// instead of 5 per sample.
+__device__ __noinline__ void stats_fold_staged(const float* sm, const float* sM2, float* g, size_t comp, int nvalid,
+                                               float n, bool first, bool batch_end, float invb) {
+  const int lane = threadIdx.x & 63;
+  auto fold = [&](float m, float M2, float& ref, float& s1, float& s2) {
+    ref = first ? m : ref;
+    const float d = m - ref, nd = n * d;
+    s1 += nd; s2 += fmaf(nd, d, M2);
+  };
+  auto bend = [&](float s1, float& cur, float& b1, float& b2) {
+    const float bm = (s1 - cur) * invb;
+    b1 += bm; b2 = fmaf(bm, bm, b2); cur = s1;
+  };
+  const bool aligned = ((reinterpret_cast<uintptr_t>(g) | (comp * sizeof(float))) & 15) == 0;
+  for (int k = lane * 4; k < nvalid; k += 256) {
+    if (aligned && k + 3 < nvalid) {
+      const float4 m = *reinterpret_cast<const float4*>(sm + k), M2 = *reinterpret_cast<const float4*>(sM2 + k);
+      float4 ref = first ? m : *reinterpret_cast<float4*>(g + k);
+      float4 s1 = *reinterpret_cast<float4*>(g + comp + k), s2 = *reinterpret_cast<float4*>(g + 2 * comp + k);
+      float4 cur, b1, b2;
+      if (batch_end) {
+        cur = *reinterpret_cast<float4*>(g + 3 * comp + k); b1 = *reinterpret_cast<float4*>(g + 4 * comp + k);
+        b2 = *reinterpret_cast<float4*>(g + 5 * comp + k);
+      }
+      fold(m.x, M2.x, ref.x, s1.x, s2.x); fold(m.y, M2.y, ref.y, s1.y, s2.y);
+      fold(m.z, M2.z, ref.z, s1.z, s2.z); fold(m.w, M2.w, ref.w, s1.w, s2.w);
+      if (first) *reinterpret_cast<float4*>(g + k) = ref;
+      *reinterpret_cast<float4*>(g + comp + k) = s1; *reinterpret_cast<float4*>(g + 2 * comp + k) = s2;
+      if (batch_end) {
+        bend(s1.x, cur.x, b1.x, b2.x); bend(s1.y, cur.y, b1.y, b2.y);
+        bend(s1.z, cur.z, b1.z, b2.z); bend(s1.w, cur.w, b1.w, b2.w);
+        *reinterpret_cast<float4*>(g + 3 * comp + k) = cur; *reinterpret_cast<float4*>(g + 4 * comp + k) = b1;
+        *reinterpret_cast<float4*>(g + 5 * comp + k) = b2;
+      }
+    } else {   // unaligned planes or the ragged tail of the wave's block: element by element, nothing past it is touched
+      for (int j = k; j < nvalid && j < k + 4; ++j) {
+        float ref = g[j], s1 = g[comp + j], s2 = g[2 * comp + j];
+        fold(sm[j], sM2[j], ref, s1, s2);
+        if (first) g[j] = ref;
+        g[comp + j] = s1; g[2 * comp + j] = s2;
+        if (batch_end) {
+          float cur = g[3 * comp + j], b1 = g[4 * comp + j], b2 = g[5 * comp + j];
+          bend(s1, cur, b1, b2);
+          g[3 * comp + j] = cur; g[4 * comp + j] = b1; g[5 * comp + j] = b2;
+        }
+      }
+    }
+  }
+}
+
 template <class Lane>
 ARP_DEV void stats_update_wave(const Lane& M, float* stage, const HmcParams& P, long long cw0, int cl, int D,
                                int nvalid, const float (&v)[Lane::ND], bool first, bool batch_end) {

@@ -33,9 +33,10 @@ ARP_DEV v2f normal_pair2(uint32_t w0, uint32_t w1) {
 }
 
 // Parked start-of-trajectory state, one region per WAVE (so that a wave's row staging block can alias its own region:
-// waves of a workgroup are not in step): pairs as 8-byte columns of 64 lanes, the 2 NG top-level floats as 4-byte columns
-// behind them (all conflict free: consecutive lanes touch consecutive 8- or 4-byte words).
-template <class T> constexpr int pk_save_wave_floats() { return (4 * T::NP + 2 * T::NG) * 64; }
+// waves of a workgroup are not in step): pairs as 8-byte columns of 64 lanes (conflict free: consecutive lanes touch
+// consecutive 8-byte words), the 2 NG top-level floats behind them as 4-byte columns of the wave's 64 / K CHAINS (the K
+// lanes of a chain hold identical copies: they write the same word and read it back as a broadcast).
+template <class T> constexpr int pk_save_wave_floats() { return 4 * T::NP * 64 + 2 * T::NG * (64 / T::K); }
 template <class T> constexpr int pk_save_floats() { return (kBlock / 64) * pk_save_wave_floats<T>(); }
 
 // One HMC transition (mcmc.HamiltonianMonteCarlo.one_step as wired at inference.py:218-222); the contract of
@@ -62,9 +63,9 @@ ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const floa
     v2f* s2 = reinterpret_cast<v2f*>(save);
 #pragma unroll
     for (int k = 0; k < NP; ++k) { s2[k * 64] = qc[k]; s2[(NP + k) * 64] = gc[k]; }
-    float* s1 = save + 4 * NP * 64 - (threadIdx.x & 63);   // float columns behind the pair columns
+    float* s1 = save + 4 * NP * 64 - 2 * (threadIdx.x & 63) + (threadIdx.x & 63) / K;   // chain columns behind the pair columns
 #pragma unroll
-    for (int i = 0; i < NG; ++i) { s1[i * 64] = qg[i]; s1[(NG + i) * 64] = gg_[i]; }
+    for (int i = 0; i < NG; ++i) { s1[i * (64 / K)] = qg[i]; s1[(NG + i) * (64 / K)] = gg_[i]; }
   }
   // momenta
   float pg[NG]; v2f pc[NP];
@@ -121,9 +122,9 @@ ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const floa
     const v2f* s2 = reinterpret_cast<const v2f*>(save);
 #pragma unroll
     for (int k = 0; k < NP; ++k) { qc[k] = s2[k * 64]; gc[k] = s2[(NP + k) * 64]; }
-    const float* s1 = save + 4 * NP * 64 - (threadIdx.x & 63);
+    const float* s1 = save + 4 * NP * 64 - 2 * (threadIdx.x & 63) + (threadIdx.x & 63) / K;
 #pragma unroll
-    for (int i = 0; i < NG; ++i) { qg[i] = s1[i * 64]; gg_[i] = s1[(NG + i) * 64]; }
+    for (int i = 0; i < NG; ++i) { qg[i] = s1[i * (64 / K)]; gg_[i] = s1[(NG + i) * (64 / K)]; }
   }
   lp = accepted ? lp1 : lp;
   return la;
@@ -195,6 +196,89 @@ ARP_DEV void pk_store_rows(const T& M, float* stage, float* gdst, int cl, int D,
   }
 }
 
+// ---------------------------------------------------------------------------
+// In-kernel statistics of the recorded samples (arp_hmc_io.stats) without HBM traffic per sample: the running mean m
+// and centred second moment M2 of the samples recorded since the last fold live in LDS -- Welford updates, so no
+// reference level is needed and nothing cancels --, one float4 {m.x, m.y, M2.x, M2.y} per county pair in the thread's
+// own column (conflict free) and one float2 {m, M2} per top-level scalar in the chain's column (the K lanes of a chain
+// write identical values).  When a batch ends, and when the launch does, the wave stages its rows of m and M2 like
+// the memory image and folds them into the six planes (kernels.h: stats_fold_staged).
+// ---------------------------------------------------------------------------
+template <class T>
+struct PkStats {
+  static constexpr int kPair = 4 * T::NP * kBlock;              // floats: [k][thread] float4
+  static constexpr int kTop = 2 * T::NG * (kBlock / T::K);      // floats: [i][chain] float2
+  static constexpr int kFloats = kPair + kTop;
+};
+
+// sample number n (1-based, wave uniform) of the current accumulation
+template <class T>
+ARP_DEV void pk_stats_accumulate(float* s_stats, int n, const float (&xg)[T::NG], const v2f (&xc)[T::NP]) {
+  constexpr int K = T::K, NP = T::NP, NG = T::NG;
+  // the thread's column index is formed afresh here: kept live across the sampling loop it would cost registers the
+  // chain kernels do not have
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  float4* a = reinterpret_cast<float4*>(s_stats) + tid;
+  float2* t = reinterpret_cast<float2*>(s_stats + PkStats<T>::kPair) + tid / K;
+  if (n == 1) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) a[k * kBlock] = float4{xc[k][0], xc[k][1], 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < NG; ++i) t[i * (kBlock / K)] = float2{xg[i], 0.0f};
+  } else {
+    const float rn = __builtin_amdgcn_rcpf((float)n);
+    const v2f vrn = splat(rn);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const float4 v = a[k * kBlock];
+      v2f m = {v.x, v.y}, M2 = {v.z, v.w};
+      const v2f d = xc[k] - m;
+      m = vfma(d, vrn, m);
+      M2 = vfma(d, xc[k] - m, M2);
+      a[k * kBlock] = float4{m[0], m[1], M2[0], M2[1]};
+    }
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      float2 v = t[i * (kBlock / K)];
+      const float d = xg[i] - v.x;
+      v.x = fmaf(d, rn, v.x);
+      v.y = fmaf(d, xg[i] - v.x, v.y);
+      t[i * (kBlock / K)] = v;
+    }
+  }
+}
+
+// Fold the n samples the accumulators hold into the planes; `stage` is the wave's parked-state region (dead between
+// transitions), which holds two row blocks (pk_save_wave_floats >= 2 stage_floats, checked in PkBlock).
+template <class T>
+ARP_DEV void pk_stats_fold(const T& M, float* stage, const float* s_stats, const HmcParams& P, long long cw0, int cl, int D,
+                           int nvalid, int n, bool first, bool batch_end) {
+  constexpr int K = T::K, NP = T::NP, NG = T::NG, NL = T::NL;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const float4* a = reinterpret_cast<const float4*>(s_stats) + tid;
+  const float2* t = reinterpret_cast<const float2*>(s_stats + PkStats<T>::kPair) + tid / K;
+  float* rm = stage + cl * D;
+  float* rM = rm + stage_floats<T>();
+  if (M.slot == 0) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) { const float2 v = t[i * (kBlock / K)]; rm[M.gg(i)] = v.x; rM[M.gg(i)] = v.y; }
+  }
+  float* em = rm + T::LBASE + M.slot;
+  float* eM = rM + T::LBASE + M.slot;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const float4 v = a[k * kBlock];
+    if (M.lvalid(2 * k)) { em[K * 2 * k] = v.x; eM[K * 2 * k] = v.z; }
+    if (2 * k + 1 < NL && M.lvalid(2 * k + 1)) { em[K * (2 * k + 1)] = v.y; eM[K * (2 * k + 1)] = v.w; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  stats_fold_staged(stage, stage + stage_floats<T>(), P.stats + cw0 * D, (size_t)P.C * D, nvalid, (float)n, first, batch_end,
+                    1.0f / (float)P.stats_batch);
+  __builtin_amdgcn_wave_barrier();
+}
+
 // LDS of one 256-thread workgroup of the packed chain kernels
 
 template <class T>
@@ -203,13 +287,19 @@ struct PkBlock {
   // blocks (a row is staged only between transitions, when the parked state is dead), and the base step sizes
   static constexpr int kSave = pk_save_floats<T>();
   static constexpr int kStage = (kBlock / 64) * stage_floats<T>();
-  static_assert(stage_floats<T>() <= pk_save_wave_floats<T>(), "a wave's staging block aliases its own parked state");
+  static_assert(2 * stage_floats<T>() <= pk_save_wave_floats<T>(),
+                "a wave's staging block -- two of them when statistics are folded -- aliases its own parked state");
   static constexpr int kEps = (T::LBASE + 2 * T::K * T::NP + 4 + 3) & ~3;   // every index a lane forms, zero beyond D
+  // the statistics accumulators fit next to everything else with two workgroups on a CU (160 KB of LDS)
+  static constexpr bool kStatsFit = (kSave + 2 * kEps + PkStats<T>::kFloats + lane_smem<T>::value) * 4 + 256 <= 80 * 1024;
 };
 
-template <class T, int MODE>
-__global__ __launch_bounds__(kBlock, T::MINW) void pk_hmc_kernel(typename T::Args A, const float* __restrict__ av,
-                                                                const float* __restrict__ bv, HmcParams P) {
+// STATS: the instantiation that keeps the statistics accumulators in LDS (P.stats is set); its LDS footprint allows two
+// workgroups per CU, so it is compiled for at most two waves per SIMD.  Without STATS a run that asks for statistics
+// takes the plane-per-sample route of kernels.h (lane models whose accumulators do not fit: PkBlock::kStatsFit).
+template <class T, int MODE, bool STATS = false>
+__global__ __launch_bounds__(kBlock, STATS && T::MINW > 2 ? 2 : T::MINW) void pk_hmc_kernel(
+    typename T::Args A, const float* __restrict__ av, const float* __restrict__ bv, HmcParams P) {
   constexpr int K = T::K, NP = T::NP, ND = T::ND, NG = T::NG;
   // chain of this lane (a launch holds fewer than 2^31 / K chains: 32-bit lane arithmetic)
   const unsigned t = blockIdx.x * (unsigned)kBlock + threadIdx.x;
@@ -225,7 +315,9 @@ __global__ __launch_bounds__(kBlock, T::MINW) void pk_hmc_kernel(typename T::Arg
 
   __shared__ float s_eps[PkBlock<T>::kEps];
   __shared__ __attribute__((aligned(16))) float s_save[PkBlock<T>::kSave];
-  // this wave's region: pair columns addressed as v2f[lane], the float columns behind them as float[lane]
+  __shared__ __attribute__((aligned(16))) float s_stats[STATS ? PkStats<T>::kFloats : 4];
+  int n_acc = 0;   // recorded samples in the LDS accumulators (STATS)
+  // this wave's region: pair columns addressed as v2f[lane], the chains' float columns behind them
   float* wsave = s_save + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * pk_save_wave_floats<T>();
   float* save = wsave + 2 * (threadIdx.x & 63);
   float* stage = wsave;   // the wave's staging block aliases its own parked state (dead between transitions)
@@ -274,7 +366,7 @@ __global__ __launch_bounds__(kBlock, T::MINW) void pk_hmc_kernel(typename T::Arg
 
     if (s == next_rec && rec_row < P.n_samples) {
       const bool to_trace = P.trace && cw0 < P.trace_chains;
-      if (to_trace || P.stats) {
+      if (to_trace || STATS || P.stats) {
         float xg[NG]; v2f xc[NP];
         if (P.trace_centered) {
           M.template to_centered<MODE>(qg, qc, xg, xc);
@@ -288,7 +380,15 @@ __global__ __launch_bounds__(kBlock, T::MINW) void pk_hmc_kernel(typename T::Arg
           const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
           pk_store_rows(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, xg, xc);
         }
-        if (P.stats) {
+        if (STATS) {
+          pk_stats_accumulate<T>(s_stats, ++n_acc, xg, xc);
+          const bool bend = bpos + 1 == P.stats_batch;
+          if (bend) {
+            pk_stats_fold(M, stage, s_stats, P, cw0, cl, D, nvalid, n_acc, rec_row + 1 == n_acc, true);
+            n_acc = 0;
+          }
+          bpos = bend ? 0 : bpos + 1;
+        } else if (P.stats) {
           float x[ND];
           T::pack(xg, xc, x);
           stats_update_wave(M, stage, P, cw0, cl, D, nvalid, x, rec_row == 0, bpos + 1 == P.stats_batch);
@@ -307,6 +407,8 @@ __global__ __launch_bounds__(kBlock, T::MINW) void pk_hmc_kernel(typename T::Arg
     }
   }
 
+  // the launch ends inside a batch: what the accumulators hold goes into s1 / s2 now, the batch mean when the batch ends
+  if (STATS && n_acc > 0) pk_stats_fold(M, stage, s_stats, P, cw0, cl, D, nvalid, n_acc, rec_row == n_acc, false);
   size_t c2 = (size_t)c;
   asm volatile("" : "+v"(c2));
   const long long cw2 = cw0;

@@ -183,7 +183,7 @@ struct RadonPk {
 // the change of coordinates, a non-centred transition, the change back; each inner kernel keeps its own
 // step-size adaptation state (inference.py:288-306).  The gradient and log density are carried across the
 // shear instead of being recomputed (kernels.h: interleaved_kernel, CARRY), 2*num_ls gradient evaluations per step.
-template <class T>
+template <class T, bool STATS = false>
 __global__ __launch_bounds__(kBlock, T::MINW) void radon_interleaved_kernel(RadonArgs A, HmcParams P) {
   constexpr int K = T::K, NP = T::NP, ND = T::ND;
   const unsigned t = blockIdx.x * (unsigned)kBlock + threadIdx.x;
@@ -197,6 +197,8 @@ __global__ __launch_bounds__(kBlock, T::MINW) void radon_interleaved_kernel(Rado
 
   __shared__ float s_eps[2][PkBlock<T>::kEps];
   __shared__ __attribute__((aligned(16))) float s_save[PkBlock<T>::kSave];
+  __shared__ __attribute__((aligned(16))) float s_stats[STATS ? PkStats<T>::kFloats : 4];   // pk_chain.h: PkStats
+  int n_acc = 0;
   float* wsave = s_save + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * pk_save_wave_floats<T>();
   float* save = wsave + 2 * (threadIdx.x & 63);
   float* stage = wsave;   // the wave's staging block aliases its own parked state (dead between transitions)
@@ -260,7 +262,15 @@ __global__ __launch_bounds__(kBlock, T::MINW) void radon_interleaved_kernel(Rado
         const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
         pk_store_rows(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, qg, qc);
       }
-      if (P.stats) {
+      if (STATS) {
+        pk_stats_accumulate<T>(s_stats, ++n_acc, qg, qc);
+        const bool bend = bpos + 1 == P.stats_batch;
+        if (bend) {
+          pk_stats_fold(M, stage, s_stats, P, cw0, cl, D, nvalid, n_acc, rec_row + 1 == n_acc, true);
+          n_acc = 0;
+        }
+        bpos = bend ? 0 : bpos + 1;
+      } else if (P.stats) {
         float x[ND];
         T::pack(qg, qc, x);
         const bool bend = bpos + 1 == P.stats_batch;
@@ -280,6 +290,7 @@ __global__ __launch_bounds__(kBlock, T::MINW) void radon_interleaved_kernel(Rado
     }
   }
 
+  if (STATS && n_acc > 0) pk_stats_fold(M, stage, s_stats, P, cw0, cl, D, nvalid, n_acc, rec_row == n_acc, false);
   size_t c2 = (size_t)c;
   asm volatile("" : "+v"(c2));
   const long long cw2 = cw0;

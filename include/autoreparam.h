@@ -108,10 +108,14 @@ typedef struct arp_hmc_io {
   uint8_t* trace_accept;     /* [S][C] is_accepted of recorded transitions, or NULL */
   float* stats;              /* [6][C][D] in/out or NULL: streaming statistics of the recorded samples (same schedule and
                               * coordinates as the trace rows), accumulated in the kernel so that a run needs no trace:
-                              * {ref = first recorded sample, s1 = sum (x - ref), s2 = sum (x - ref)^2, cur = s1 at the start of
-                              * the current batch, sb1 = sum of batch means (of x - ref), sb2 = sum of their squares}; zero it
-                              * before the first call.  mean = ref + s1/n, var = (s2 - s1^2/n)/(n-1), batch-means ESS =
-                              * n var / (stats_batch var(batch means)) */
+                              * {ref = a reference level near the samples, s1 = sum (x - ref), s2 = sum (x - ref)^2, cur = s1 at
+                              * the start of the current batch, sb1 = sum of batch means (of x - ref), sb2 = sum of their
+                              * squares}; zero it before the first call.  mean = ref + s1/n, var = (s2 - s1^2/n)/(n-1),
+                              * batch-means ESS = n var / (stats_batch var(batch means)).  ref is chosen by
+                              * the kernel on the first call that records and is only meaningful through these formulas (the
+                              * first recorded sample, or -- kernels that keep the running moments of a batch in LDS and touch
+                              * the planes once per batch or launch -- the mean of the first stretch they fold); the planes are
+                              * sums, so they are exact to rounding however a run is cut into launches */
   uint32_t* rec_accept_count; /* [C] in/out or NULL: accepted transitions among the recorded ones (sum of is_accepted) */
 } arp_hmc_io;
 

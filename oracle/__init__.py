@@ -28,7 +28,7 @@ class HmcCfg(C.Structure):
                 ("trace_centered", C.c_int), ("lanes", C.c_int),
                 ("stats_batch", C.c_int), ("trace_chains", C.c_int), ("stats", C.c_void_p),
                 ("rec_accept", C.c_void_p), ("rec_accept1", C.c_void_p),
-                ("margin", C.c_void_p), ("escale", C.c_void_p)]
+                ("margin", C.c_void_p), ("escale", C.c_void_p), ("log_alpha", C.c_void_p)]
 
 
 def lib():
@@ -134,18 +134,19 @@ class OracleModel(object):
     def hmc_run(self, st, a, b, eps0, n_leapfrog, n_steps, seed=0, chain_offset=0, adapt_kind=0, n_adapt=0,
                 adapt_target=0.75, adapt_rate=0.05, n_burnin=0, thin=1, trace=None, trace_accept=None,
                 trace_centered=True, lanes=4, stats=None, stats_batch=1, n_samples=None, trace_chains=0,
-                rec_accept=None, margin=None, escale=None):
+                rec_accept=None, margin=None, escale=None, log_alpha=None):
         """`st` is a dict with q, grad, logp, adapt, rng, accept_count (numpy, dtype of st['q']) and 'step'.
         `stats` ([6, C, D], dtype of st['q'], zeroed) / `rec_accept` ([C] uint32) as arp_hmc_io.stats / rec_accept_count.
         `margin` / `escale` ([n_steps, C], dtype of st['q']): log u - log alpha of every Metropolis test of this call and
-        the size of the energies it compared (test diagnostics: how close a decision sat to its threshold)."""
+        the size of the energies it compared (test diagnostics: how close a decision sat to its threshold); `log_alpha`
+        (same shape): log alpha itself."""
         dtype = st["q"].dtype
         ns = n_samples if n_samples is not None else (
             trace.shape[0] if trace is not None else (trace_accept.shape[0] if trace_accept is not None else 0))
         cfg = HmcCfg(st["q"].shape[0], n_leapfrog, n_steps, st["step"], chain_offset, seed, adapt_kind, n_adapt,
                      adapt_target, adapt_rate, n_burnin, thin, ns, 1 if trace_centered else 0, lanes,
-                     stats_batch, trace_chains, _p(stats), _p(rec_accept), C.c_void_p(0), _p(margin), _p(escale))
-        for d in (margin, escale):
+                     stats_batch, trace_chains, _p(stats), _p(rec_accept), C.c_void_p(0), _p(margin), _p(escale), _p(log_alpha))
+        for d in (margin, escale, log_alpha):
             assert d is None or (d.dtype == dtype and d.shape == (n_steps, st["q"].shape[0]) and d.flags.c_contiguous)
         a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
         eps0 = np.ascontiguousarray(eps0, np.float32)
@@ -159,15 +160,15 @@ class OracleModel(object):
 def _interleaved(self, st, ab0, ab1, eps0_0, eps0_1, L0, L1, n_steps, seed=0, chain_offset=0, adapt_kind=2,
                  n_adapt=0, adapt_target=0.75, adapt_rate=0.05, n_burnin=0, thin=1, trace=None, trace_acc0=None,
                  trace_acc1=None, trace_centered=True, lanes=4, stats=None, stats_batch=1, n_samples=None,
-                 trace_chains=0, rec_accept0=None, rec_accept1=None, margin=None, escale=None):
+                 trace_chains=0, rec_accept0=None, rec_accept1=None, margin=None, escale=None, log_alpha=None):
     """`st`: dict from new_state plus 'adapt1' and 'accept_count1'.  `margin` / `escale`: [n_steps, 2, C] (see hmc_run)."""
     dtype = st["q"].dtype
     ns = n_samples if n_samples is not None else (
         trace.shape[0] if trace is not None else (trace_acc0.shape[0] if trace_acc0 is not None else 0))
     cfg = HmcCfg(st["q"].shape[0], L0, n_steps, st["step"], chain_offset, seed, adapt_kind, n_adapt, adapt_target,
                  adapt_rate, n_burnin, thin, ns, 1 if trace_centered else 0, lanes, stats_batch, trace_chains,
-                 _p(stats), _p(rec_accept0), _p(rec_accept1), _p(margin), _p(escale))
-    for d in (margin, escale):
+                 _p(stats), _p(rec_accept0), _p(rec_accept1), _p(margin), _p(escale), _p(log_alpha))
+    for d in (margin, escale, log_alpha):
         assert d is None or (d.dtype == dtype and d.shape == (n_steps, 2, st["q"].shape[0]) and d.flags.c_contiguous)
     f32 = lambda v: np.ascontiguousarray(v, np.float32)
     a0, b0, a1, b1 = f32(ab0[0]), f32(ab0[1]), f32(ab1[0]), f32(ab1[1])

@@ -69,6 +69,7 @@ typedef struct orc_hmc_cfg {
    * of the terms whose float32 rounding can flip it).  kernels = 1 (orc_hmc_run) or 2 (orc_interleaved_run). */
   void* margin;
   void* escale;
+  void* log_alpha;   /* same shape: log alpha itself (what the step-size recurrences consume) */
 } orc_hmc_cfg;
 
 /* ---- RNG: MWC64X streams seeded by Philox4x32-10 (DESIGN.md "Randomness").  The stream record

@@ -714,6 +714,7 @@ int FN(orc_hmc_run)(const orc_model* M, const float* a, const float* b, const or
                                      cfg->margin ? (REAL*)cfg->margin + (size_t)s * C + c : NULL,
                                      cfg->escale ? (REAL*)cfg->escale + (size_t)s * C + c : NULL);
         nacc += (uint32_t)acc;
+        if (cfg->log_alpha) ((REAL*)cfg->log_alpha)[(size_t)s * C + c] = la;
         const long long n = cfg->step_base + s + 1;
         FN(adapt_update)(cfg->adapt_kind, n, cfg->n_adapt, (REAL)cfg->adapt_target, (REAL)cfg->adapt_rate,
                          la, &kappa, &esum, &logavg);
@@ -779,6 +780,7 @@ int FN(orc_interleaved_run)(const orc_model* M, const float* a0, const float* b0
         REAL* es = cfg->escale ? (REAL*)cfg->escale + (size_t)s * 2 * C + c : NULL;
         REAL la = FN(hmc_transition)(M, a0, b0, st, lanes, cfg->n_leapfrog, eps, qc, g, &lp, &a_0, work, mg, es);
         n0 += (uint32_t)a_0;
+        if (cfg->log_alpha) ((REAL*)cfg->log_alpha)[(size_t)s * 2 * C + c] = la;
         FN(adapt_update)(cfg->adapt_kind, n, cfg->n_adapt, (REAL)cfg->adapt_target, (REAL)cfg->adapt_rate, la, &k0, &e0, &l0);
         FN(to_centered)(M, a0, b0, qc, xc);
         FN(from_centered)(M, a1, b1, xc, qc);
@@ -786,6 +788,7 @@ int FN(orc_interleaved_run)(const orc_model* M, const float* a0, const float* b0
         for (int d = 0; d < D; ++d) eps[d] = (REAL)eps0_1[d] * k1;
         la = FN(hmc_transition)(M, a1, b1, st, lanes, L1, eps, qc, g, &lp, &a_1, work, mg ? mg + C : NULL, es ? es + C : NULL);
         n1 += (uint32_t)a_1;
+        if (cfg->log_alpha) ((REAL*)cfg->log_alpha)[(size_t)s * 2 * C + C + c] = la;
         FN(adapt_update)(cfg->adapt_kind, n, cfg->n_adapt, (REAL)cfg->adapt_target, (REAL)cfg->adapt_rate, la, &k1, &e1, &l1);
         FN(to_centered)(M, a1, b1, qc, xc);
         FN(from_centered)(M, a0, b0, xc, qc);

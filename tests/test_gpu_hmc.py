@@ -9,7 +9,6 @@ import helpers
 import parity
 
 pytestmark = pytest.mark.gpu
-ADAPT_MARGIN = 0.05   # dual averaging: log alpha inherits the (<= 2 %) step-size difference of the two runs
 LANES = {"8schools": [1, 8], "radon_MN": [4, 8, 16], "radon_PA": [4, 8, 16], "election": [4, 8, 16], "german": [4, 8, 16], "radon_sd_MN": [8, 16], "funnel": [1], "electric": [16], "time_series": [4]}
 
 
@@ -31,8 +30,7 @@ def _eps0(oracle_lib, sp, a, b, x, frac):
     return (frac / np.sqrt(np.abs(diag) + 1.0)).astype(np.float32)
 
 
-def _compare(oracle_lib, gpu, mname, kind, lanes, adapt_kind, frac, L, n, n_adapt=0, sp=None, Cn=96, state_tol=1e-4,
-             margin_extra=0.0):
+def _compare(oracle_lib, gpu, mname, kind, lanes, adapt_kind, frac, L, n, n_adapt=0, sp=None, Cn=96, state_tol=1e-4):
     """Run the HIP kernel and the float32 oracle on the same seeds, twice: once on the recording schedule under test
     (burn-in 2, every third transition: trace rows, accept flags) and once recording EVERY transition (state in sampler
     coordinates + accept flag + the oracle's Metropolis margins), which is what `helpers.explain_divergence` needs to
@@ -57,8 +55,7 @@ def _compare(oracle_lib, gpu, mname, kind, lanes, adapt_kind, frac, L, n, n_adap
     tro = np.zeros((4, Cn, sp.D), np.float32); tao = np.zeros((4, Cn), np.uint8)
     orc.hmc_run(so, a, b, eps0, L, n, n_burnin=2, thin=3, trace=tro, trace_accept=tao, trace_centered=True, **kw)
     # run B: every transition
-    r = parity.hmc_every_step(oracle_lib, eng, orc, (a, b), q0, eps0, L, n, state_tol, "%s %s lanes=%d" % (mname, kind, lanes),
-                              margin_extra=margin_extra, **kw)
+    r = parity.hmc_every_step(oracle_lib, eng, orc, (a, b), q0, eps0, L, n, state_tol, "%s %s lanes=%d" % (mname, kind, lanes), **kw)
     # what is recorded does not change the chain
     assert torch.equal(st.q, r["st"].q) and torch.equal(st.rng, r["st"].rng) and np.array_equal(so["q"], r["so"]["q"])
     scale, clean, first, mg, es = r["scale"], r["clean"], r["first"], r["margin"], r["escale"]
@@ -163,20 +160,29 @@ def test_adaptation_recurrence_on_scripted_acceptance(oracle_lib, gpu):
                                         ("radon_PA", "CP")])
 @pytest.mark.parametrize("adapt", [1, 2])
 def test_adaptation_matches_oracle(oracle_lib, gpu, mname, kind, adapt):
-    """Dual-averaging / simple adaptation state after 10 adapting + 4 frozen transitions.  Dual averaging starts by
-    exploring at 10x the base step and feeds exp(log alpha) back into the step, so a rounding difference in an energy
-    moves the NEXT step size (continuously: no branching), and states are compared to 2 % on the step multiplier and
-    0.02 on the error sum rather than coordinate by coordinate.  Every chain must still be explained: no accept
-    decision may differ unless its margin sat at the threshold (widened by the 2 % the step sizes may differ by)."""
+    """Dual-averaging / simple step-size adaptation inside the kernels, 10 adapting + 4 frozen transitions, EVERY chain
+    at EVERY transition (parity.hmc_teacher_forced): the oracle is restarted from the HIP path's own state before each
+    transition, because dual averaging explores up to the integrator's stability limit, where free-running float32
+    trajectories part within a few steps whatever computes them.  Each transition's decision, new state, cached log
+    density, random streams and adaptation state must agree within the float32 rounding of the energies compared.
+    Simple adaptation is also compared free-running (explained divergence, as in the fixed-step test)."""
     lanes = LANES[mname][0] if mname in ("german", "radon_PA") else LANES[mname][-1]   # the lane counts the configs run
-    frac = 0.002 if mname in ("election", "german") else 0.02   # keep the 10x exploration phase inside the stable region
-    r = _compare(oracle_lib, gpu, mname, kind, lanes, adapt, frac, 3, 14, n_adapt=10,
-                 state_tol=5e-3 if adapt == 1 else 1e-4, margin_extra=ADAPT_MARGIN if adapt == 1 else 0.0)
-    ok, st, so = r["clean"], r["st"], r["so"]
-    ad, ado = st.adapt.cpu().numpy()[:, :3], so["adapt"][:, :3]
-    close = (np.abs(ad[:, 0] / ado[:, 0] - 1) <= 0.02) & (np.abs(ad[:, 1] - ado[:, 1]) <= 0.02)
-    assert close[ok].all(), (int((~close[ok]).sum()), int(ok.sum()))
-    assert np.array_equal(st.accept_count.cpu().numpy()[ok], so["accept_count"][ok])
+    frac = 0.002 if mname in ("election", "german") else 0.02
+    sp = helpers.spec(mname)
+    eng = _eng(mname, gpu)
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, kind)
+    eng.set_param(0, (a, b))
+    q0 = helpers.states(sp, 96, seed=2, scale=0.1)
+    eps0 = _eps0(oracle_lib, sp, a, b, q0, frac)
+    flipped = parity.hmc_teacher_forced(oracle_lib, eng, orc, (a, b), q0, eps0, 3, 14, "%s %s lanes=%d adapt=%d" % (
+        mname, kind, lanes, adapt), adapt, 10, seed=9, chain_offset=1000, lanes=lanes)
+    assert flipped <= 4, flipped     # sanity: decisions at their threshold are rare (96 chains x 14 transitions)
+    if adapt == 2:
+        r = _compare(oracle_lib, gpu, mname, kind, lanes, adapt, frac, 3, 14, n_adapt=10)
+        ok, st, so = r["clean"], r["st"], r["so"]
+        np.testing.assert_allclose(st.adapt.cpu().numpy()[ok, 0], so["adapt"][ok, 0], rtol=1e-6)
+        assert np.array_equal(st.accept_count.cpu().numpy()[ok], so["accept_count"][ok])
 
 
 @pytest.mark.parametrize("mname", ["radon_MN", "election"])
