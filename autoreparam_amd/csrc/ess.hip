@@ -5,10 +5,20 @@
 // The autocovariances are formed directly and only until the first negative one -- no FFT, no work buffers,
 // no plan creation.  One thread per series; consecutive threads read consecutive floats of a trace
 // row, so every pass streams the trace coalesced.  Sums are accumulated in double.
-// The first 16 lags come out of ONE pass over the series, without a mean pass in front of it: with y_t = x_t - r
-// (r = the mean of the first 16 samples, so that y is small) and m' = mean(y),
-//   sum_{t>=k} (y_t - m')(y_{t-k} - m') = sum_{t>=k} y_t y_{t-k} - m' (2 T - head_k - tail_k) + (S - k) m'^2,
-// T = sum_t y_t, head_k / tail_k = the sums of the first / last k values (two 16-sample loops).
+//
+// Bound: HBM.  A series is S floats a whole trace row apart, so the kernel is a strided stream of the trace; the work
+// per sample (W + 1 multiply-adds for W lags) is ~ 1 ms of vector issue for the 18.6 GB headline trace against >= 2.3 ms
+// of HBM time.  What decides the time is (i) how many bytes are in flight -- every window's loads are issued one window
+// AHEAD of their use (two register buffers, ping-pong), four waves per SIMD -- and (ii) how often the trace is read:
+//   sweep 1  lags 0 .. W = 32 and the mean in ONE pass (no mean pass in front of it): with y_t = x_t - r (r = the mean of
+//            the first W samples, so that y is small) and m' = mean(y),
+//              sum_{t>=k} (y_t - m')(y_{t-k} - m') = sum_{t>=k} y_t y_{t-k} - m' (2 T - head_k - tail_k) + (S - k) m'^2,
+//            T = sum_t y_t, head_k / tail_k = the sums of the first / last k values (two W-sample loops).
+//            A WAVE goes on to further sweeps when any of its 64 series is still positive at the last lag, and a wave
+//            is about one chain's elements, slow ones included: with 16 lags two waves in three of the headline trace
+//            needed a second pass over it (8.3 ms); 32 lags leave few.  The 33 running totals of a thread live in its
+//            own LDS column (float: the register file holds the 33 window sums, the 32-deep window and two load buffers);
+//   sweep 2+ lags beyond W, 16 at a time: the leading and the lagged stream are both read (slowly mixing series only).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "host_common.h"
@@ -18,125 +28,295 @@ namespace arp {
 #ifndef ARP_ESS_WIN
 #define ARP_ESS_WIN 16
 #endif
-constexpr int kEssWin = ARP_ESS_WIN;      // lags 1..kEssWin come out of the first pass over the series
+#ifndef ARP_ESS_MINB
+#define ARP_ESS_MINB 4
+#endif
+constexpr int kEssWin = ARP_ESS_WIN;      // lags per sweep
+constexpr int kEssFar = 16;               // lags per sweep past the first
+constexpr int kEssLoad = kEssWin % 16 == 0 ? 16 : 8;   // samples per load batch of the first sweep (two batches in flight)
 
-// One sweep over a series forms kEssWin consecutive auto-covariance sums at once, lags kb+1 .. kb+16 (and c_0 when
-// kb == 0): the 16 mean-removed values y_{t-kb-1} .. y_{t-kb-16} sit in a register window that is addressed at compile
-// time (the time loop is unrolled by the window length, so nothing is ever shifted), 17 accumulators next to it.  Chains
-// that mix stop within a few dozen lags, so with the mean pass almost every series is done after two coalesced sweeps of
-// the trace; a series whose first 16 auto-correlations are all positive takes another sweep per 16 lags.
-// Loads are issued in batches of 16 independent rows (a thread's consecutive samples are a whole trace row apart: one
-// load per iteration with its wait is latency bound -- the first version of this kernel was, at 29 ms for 18.6 GB).
-// Accumulation is in float, flushed into doubles every 8 windows = 128 samples (v_fma_f64 issues several times slower
-// than v_fma_f32 and made the sweep compute bound); no float sum is longer than 128 products.  Accuracy: a float sum of
-// 128 products carries <= 128 x 2^-24 ~ 8e-6 relative error on sum |y y'|; the first sweep centres afterwards from raw
-// sums about the reference level r, so with |mean(y)| = m sd the raw sums are (1 + m^2) times the centred ones and rho
-// carries up to ~ (1 + m^2) x 1e-5 absolute error.  The sweep is retaken around the mean itself when m^2 > 16 (below;
-// a whole WAVE retakes it when one of its 64 series does, so the threshold sits where a stationary chain's first 16
-// samples practically never land), which bounds that at 2e-4 -- two orders under the 1 / sqrt(S) sampling noise of rho
-// at any S this path sees.
-template <bool FIRST>
-__device__ __forceinline__ void ess_sweep(const float* __restrict__ x, long long S, long long stride, float mean,
-                                          long long kb, double (&dacc)[kEssWin + 1], double& dtot) {
-  float acc[kEssWin + 1];
-  float tot = 0.0f;
-  dtot = 0.0;
-  float w[kEssWin];          // w[tt] = y at time t0 + tt - kb of the previous window (0 before the series starts)
-#pragma unroll
-  for (int j = 0; j <= kEssWin; ++j) { acc[j] = 0.0f; dacc[j] = 0.0; }
-#pragma unroll
-  for (int j = 0; j < kEssWin; ++j) w[j] = 0.0f;
-  // window t0: times t0 .. t0+15 of the leading stream; the lagged stream runs kb behind.  Start where the lagged
-  // stream starts (t0 = kb, rounded down to a window): products with times before 0 are zeros.
-  for (long long t0 = 0; t0 < S; t0 += kEssWin) {
-    float xv[kEssWin], xl[kEssWin];
-    if (t0 + kEssWin <= S) {
-#pragma unroll
-      for (int tt = 0; tt < kEssWin; ++tt) xv[tt] = x[(t0 + tt) * stride];
-    } else {   // the last, partial window: the mean past the end, i.e. y = 0, which adds nothing
-#pragma unroll
-      for (int tt = 0; tt < kEssWin; ++tt) xv[tt] = t0 + tt < S ? x[(t0 + tt) * stride] : mean;
-    }
-    if (!FIRST) {
-      if (t0 - kb >= 0 && t0 - kb + kEssWin <= S) {
-#pragma unroll
-        for (int tt = 0; tt < kEssWin; ++tt) xl[tt] = x[(t0 + tt - kb) * stride];
-      } else {
-#pragma unroll
-        for (int tt = 0; tt < kEssWin; ++tt) {
-          const long long tl = t0 + tt - kb;
-          xl[tt] = (tl >= 0 && tl < S) ? x[tl * stride] : mean;
-        }
-      }
-    }
-#pragma unroll
-    for (int tt = 0; tt < kEssWin; ++tt) {
-      const float y = xv[tt] - mean;
-      if (FIRST) { acc[0] = fmaf(y, y, acc[0]); tot += y; }
-#pragma unroll
-      for (int j = 1; j <= kEssWin; ++j) acc[j] = fmaf(y, w[(tt - j + 2 * kEssWin) % kEssWin], acc[j]);
-      w[tt] = FIRST ? y : xl[tt] - mean;
-    }
-    if (((t0 / kEssWin) & 7) == 7 || t0 + kEssWin >= S) {
-#pragma unroll
-      for (int j = 0; j <= kEssWin; ++j) { dacc[j] += (double)acc[j]; acc[j] = 0.0f; }
-      if (FIRST) { dtot += (double)tot; tot = 0.0f; }
-    }
+// Accuracy: blocked float summation -- window sums of <= 128 products, added into float running totals (S / 128 of them
+// per lag): relative error ~ sqrt(128 + S / 128) x 2^-24 ~ 1e-6 typical, (128 + S / 128) x 2^-24 <= 4e-5 worst case at
+// S = 50 000, on sum |y y'|.  Sweep 1 centres afterwards from raw sums about the reference level r; with |mean(y)| = m sd
+// the raw sums are (1 + m^2) times the centred ones, so rho carries ~ (1 + m^2) x that.  The sweep is retaken around the
+// mean itself when m^2 > 16 (a whole WAVE retakes it when one of its 64 series does, so the threshold sits where a
+// stationary chain's first samples practically never land): rho is good to ~ 2e-5 typical, 7e-4 worst case -- against a
+// sampling noise of 1 / sqrt(S) >= 4e-3.  The sweeps past the first flush into doubles (registers are free there).
+
+// A series is addressed as (wave-uniform row base)[32-bit lane byte offset] through BUFFER loads: the row base is a
+// buffer resource in scalar registers (rebuilt per row with two scalar adds), the lane's offset one VGPR shared by all of
+// a window's loads -- `buffer_load_dword v, v_off, s[rsrc], 0 offen`.  With plain pointers the compiler folds the lane
+// index into the pointer and keeps W loop-invariant 64-bit lane addresses, which alone pushed the sweep over the 128
+// registers that four waves per SIMD allow (and serialised the loads behind their reloads from scratch).
+struct EssSeries {
+  const float* __restrict__ base;   // trace (uniform)
+  unsigned boff;                    // 4 x series index (lane): byte offset within a row
+  long long stride;
+  unsigned row_bytes;               // bytes of a row that hold series: the buffer's range
+  __device__ __forceinline__ float at(long long t) const {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + t * stride), 0,
+                                                                        (int)row_bytes, 0x00020000);   // raw dword buffer
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)boff, 0, 0));
+  }
+};
+
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void ess_unrolled_batches(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    ess_unrolled_batches<N, I + 1>(f);
   }
 }
 
-__global__ __launch_bounds__(256) void ess_kernel(const float* __restrict__ trace, long long S, long long n,
-                                                  long long stride, float* __restrict__ ess) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* x = trace + i;
-  // reference level r and the sums of the first / last k values (k <= 16)
-  const int nh = S < kEssWin ? (int)S : kEssWin;
-  float fh[kEssWin], ft[kEssWin];
+template <int W>
+__device__ __forceinline__ void ess_load(const EssSeries& x, long long t0, long long S, float fill, float (&v)[W]) {
+  if (t0 + W <= S) {
 #pragma unroll
-  for (int j = 0; j < kEssWin; ++j) {
-    fh[j] = j < nh ? x[(long long)j * stride] : 0.0f;
-    ft[j] = j < nh ? x[(S - 1 - j) * stride] : 0.0f;     // ft[j] = x_{S-1-j}
+    for (int tt = 0; tt < W; ++tt) v[tt] = x.at(t0 + tt);
+  } else {   // the last, partial window: `fill` (the centre) past the end, i.e. y = 0, which adds nothing
+#pragma unroll
+    for (int tt = 0; tt < W; ++tt) v[tt] = t0 + tt < S ? x.at(t0 + tt) : fill;
   }
-  float r = 0.0f;   // x_0 + mean(x_j - x_0): exactly x_0 for a constant series
-#pragma unroll
-  for (int j = 1; j < kEssWin; ++j) r += j < nh ? fh[j] - fh[0] : 0.0f;
-  r = fh[0] + r / (float)nh;
+}
 
-  double dacc[kEssWin + 1], T, mp, c0;
+// sweep 1: c_0, lags 1 .. W and the total, about the centre r.  `tot` is the lane's column of W + 2 running totals in its
+// wave's LDS block (stride 64 floats): [0] = sum y^2, [j] = sum y_t y_{t-j}, [W + 1] = sum y.
+template <int W>
+__device__ __forceinline__ void ess_sweep_first(const EssSeries& x, long long S, float r, float* __restrict__ tot) {
+  constexpr int LB = kEssLoad;
+  static_assert(W % LB == 0 && (128 % LB) == 0, "load batches tile the window and the flush interval");
+  float acc[W + 1], w[W];
+  float sy = 0.0f;
+#pragma unroll
+  for (int j = 0; j <= W; ++j) { acc[j] = 0.0f; tot[j * 64] = 0.0f; }
+  tot[(W + 1) * 64] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < W; ++j) w[j] = 0.0f;     // ring of the last W values of y: w[t mod W] = y_t (0 before the start)
+  auto flush = [&]() {
+#pragma unroll
+    for (int j = 0; j <= W; ++j) { tot[j * 64] += acc[j]; acc[j] = 0.0f; }
+    tot[(W + 1) * 64] += sy; sy = 0.0f;
+  };
+  // batch `ph` (compile time: its position within the ring) of LB consecutive samples
+  auto block = [&](const float (&v)[LB], auto ph) {
+    constexpr int P = decltype(ph)::value;
+#pragma unroll
+    for (int tl = 0; tl < LB; ++tl) {
+      constexpr int dummy = 0; (void)dummy;
+      const int tt = (P * LB + tl) % W;
+      const float y = v[tl] - r;
+      acc[0] = fmaf(y, y, acc[0]); sy += y;
+#pragma unroll
+      for (int j = 1; j <= W; ++j) acc[j] = fmaf(y, w[(tt - j + 2 * W) % W], acc[j]);
+      w[tt] = y;
+    }
+  };
+  float a[LB], b[LB];
+  ess_load<LB>(x, 0, S, r, a);
+  int nb = 0;
+  // the time loop is unrolled by an even number of batches that is a whole number of ring lengths: the two load buffers
+  // alternate, and every ring position is a compile-time constant
+  constexpr int NB = (W / LB) % 2 == 0 ? W / LB : 2 * (W / LB);
+  for (long long t0 = 0; t0 < S; t0 += NB * LB) {
+    ess_unrolled_batches<NB>([&](auto ph) {
+      constexpr int P = decltype(ph)::value;
+      const long long tb = t0 + P * LB;            // first sample of this batch
+      if (tb >= S) return;
+      if (P % 2 == 0) {
+        if (tb + LB < S) ess_load<LB>(x, tb + LB, S, r, b);        // one batch ahead
+        block(a, ph);
+      } else {
+        if (tb + LB < S) ess_load<LB>(x, tb + LB, S, r, a);
+        block(b, ph);
+      }
+      if (++nb == 128 / LB) { flush(); nb = 0; }
+    });
+  }
+  flush();
+}
+
+// sweeps 2+: lags kb+1 .. kb+W (W = kEssFar here): the W mean-removed values y_{t-kb-1} .. y_{t-kb-W} of the LAGGED stream sit in
+// the register window, the leading stream is read next to it
+template <int W>
+__device__ __forceinline__ void ess_sweep_far(const EssSeries& x, long long S, float mean,
+                                              long long kb, double (&dacc)[W + 1]) {
+  float acc[W + 1], w[W];
+#pragma unroll
+  for (int j = 0; j <= W; ++j) { acc[j] = 0.0f; dacc[j] = 0.0; }
+#pragma unroll
+  for (int j = 0; j < W; ++j) w[j] = 0.0f;
+  int nb = 0;
+  for (long long t0 = 0; t0 < S; t0 += W) {
+    float xv[W], xl[W];
+    ess_load<W>(x, t0, S, mean, xv);
+    if (t0 - kb >= 0 && t0 - kb + W <= S) {
+#pragma unroll
+      for (int tt = 0; tt < W; ++tt) xl[tt] = x.at(t0 + tt - kb);
+    } else {
+#pragma unroll
+      for (int tt = 0; tt < W; ++tt) {
+        const long long tl = t0 + tt - kb;
+        xl[tt] = (tl >= 0 && tl < S) ? x.at(tl) : mean;
+      }
+    }
+#pragma unroll
+    for (int tt = 0; tt < W; ++tt) {
+      const float y = xv[tt] - mean;
+#pragma unroll
+      for (int j = 1; j <= W; ++j) acc[j] = fmaf(y, w[(tt - j + 2 * W) % W], acc[j]);
+      w[tt] = xl[tt] - mean;
+    }
+    if (++nb == 128 / W) {
+#pragma unroll
+      for (int j = 1; j <= W; ++j) { dacc[j] += (double)acc[j]; acc[j] = 0.0f; }
+      nb = 0;
+    }
+  }
+#pragma unroll
+  for (int j = 1; j <= W; ++j) dacc[j] += (double)acc[j];
+}
+
+// Lags beyond W of ONE series, by the whole wave.  After the first sweep a wave typically holds a few series that are
+// still positive at lag W (a chain's slowly mixing elements) next to sixty that are finished; sweeping on per lane would
+// issue a full wave's instructions for three live lanes.  Instead the wave copies the series into its LDS block once
+// (mean removed, zero padded) and lane l forms lag kb + 1 + l over the whole series -- 64 lags per round, one broadcast
+// ds_read_b128 and two ds_read2_b32 per four products -- then the first negative lag is found with a ballot.
+// Returns the sum over the lags taken of (S - k) / S rho_k.
+__device__ __forceinline__ double ess_tail_cooperative(const float* __restrict__ trace, long long stride, long long S,
+                                                       unsigned idx_u, float mean_u, double c0_u, int W,
+                                                       float* __restrict__ wbuf, int lane) {
+  const int Si = (int)S;
+  // the series, mean removed; zeros behind it so that every lane can run to the longest lag sum's end
+  // (a lane's samples are 64 rows apart: every load is its own sector, so eight are put in flight at a time)
+  for (int tb = 0; tb < Si + 72; tb += 8 * 64) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int t = tb + q * 64 + lane;
+      v[q] = t < Si ? trace[(long long)t * stride + idx_u] : mean_u;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int t = tb + q * 64 + lane;
+      if (t < Si + 72) wbuf[t] = v[q] - mean_u;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  double sum = 0.0;
+  for (int kb = W; kb < Si; kb += 64) {
+    const int k = kb + 1 + lane;
+    // sum_u y_u y_{u+k}, u = 0 .. S-k-1; every lane runs to u < S - kb - 1 (products past its own end meet the zero pad)
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    const float* lead = wbuf + k;
+    const int nu = Si - kb - 1;
+#pragma unroll 4
+    for (int u = 0; u < nu; u += 4) {
+      const float4 b = *reinterpret_cast<const float4*>(wbuf + u);          // same address in every lane: a broadcast
+      a0 = fmaf(b.x, lead[u], a0); a1 = fmaf(b.y, lead[u + 1], a1);
+      a2 = fmaf(b.z, lead[u + 2], a2); a3 = fmaf(b.w, lead[u + 3], a3);
+    }
+    const bool in_range = k < Si;
+    const double rho = ((double)a0 + (double)a1 + ((double)a2 + (double)a3)) / (double)(in_range ? Si - k : 1) / c0_u;
+    const unsigned long long stop = __ballot(!in_range || rho < 0.0);
+    const int first = stop ? __builtin_ctzll(stop) : 64;
+    double part = lane < first ? (double)(Si - k) / (double)Si * rho : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    sum += part;
+    if (first < 64) break;
+  }
+  __builtin_amdgcn_wave_barrier();
+  return sum;
+}
+
+constexpr int kEssRows = 36;   // LDS floats per lane: the first sweep's totals, then (per wave) a whole series + padding
+
+__global__ __launch_bounds__(256, ARP_ESS_MINB) void ess_kernel(const float* __restrict__ trace, long long S, long long n,
+                                                                long long stride, float* __restrict__ ess) {
+  constexpr int W = kEssWin, WF = kEssFar;
+  static_assert(W + 2 <= kEssRows, "the totals of the first sweep fit the lane's LDS column");
+  __shared__ __attribute__((aligned(16))) float s_buf[kEssRows * 256];   // one block of kEssRows x 64 floats per wave
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i0 < n;
+  const long long i = valid ? i0 : n - 1;          // lanes past the end shadow the last series and never store
+  const int lane = threadIdx.x & 63;
+  float* wbuf = s_buf + (threadIdx.x >> 6) * (kEssRows * 64);
+  float* tot = wbuf + lane;
+  const EssSeries x{trace, (unsigned)i * 4u, stride, (unsigned)n * 4u};   // n_series < 2^30 is checked on the host
+  // reference level r = x_0 + mean(x_j - x_0) over the first W samples: exactly x_0 for a constant series
+  const int nh = S < W ? (int)S : W;
+  float r;
+  {
+    float f0 = x.at(0), d = 0.0f;
+#pragma unroll
+    for (int j = 1; j < W; ++j) d += j < nh ? x.at(j) - f0 : 0.0f;
+    r = f0 + d / (float)nh;
+  }
+  double T, mp, c0;
   float mean;
   for (int attempt = 0;; ++attempt) {
-    ess_sweep<true>(x, S, stride, r, 0, dacc, T);
+    ess_sweep_first<W>(x, S, r, tot);
+    T = (double)tot[(W + 1) * 64];
     mp = T / (double)S;                     // mean of y
-    mean = r + (float)mp;                   // mean of x, for the sweeps past lag 16
-    c0 = (dacc[0] - (double)S * mp * mp) / (double)S;
-    // A reference level far from the mean (a series that was still drifting over its first 16 samples) makes the
+    mean = r + (float)mp;                   // mean of x, for the lags past W
+    c0 = ((double)tot[0] - (double)S * mp * mp) / (double)S;
+    // A reference level far from the mean (a series that was still drifting over its first samples) makes the
     // products large against the variance they are meant to resolve: take the pass again around the mean itself.
     if (attempt == 1 || !(mp * mp > 16.0 * c0)) break;
     r = mean;
   }
-  // centred sums of lags 1 .. 16
-  double head = 0.0, tail = 0.0;            // sums of the first / last k values of y
-#pragma unroll
-  for (int j = 1; j <= kEssWin; ++j) {
-    head += (double)(fh[j - 1] - r); tail += (double)(ft[j - 1] - r);
-    dacc[j] = dacc[j] - mp * (2.0 * T - head - tail) + (double)(S - j) * mp * mp;
-  }
-  if (!(c0 > 0.0)) { ess[i] = __builtin_nanf(""); return; }   // constant series: 0/0 as in the FFT form
+  const bool constant = !(c0 > 0.0);        // constant series: 0/0 as in the FFT form
+  // centred sums of lags 1 .. W (the first / last W values are read again here rather than kept across the sweep)
   double total = 1.0;   // lag 0: (S - 0)/S * rho_0
-  bool done = false;
-  for (long long kb = 0; kb < S && !done; kb += kEssWin) {
-    if (kb > 0) { double unused; ess_sweep<false>(x, S, stride, mean, kb, dacc, unused); }
+  bool done = constant;
+  {
+    double head = 0.0, tail = 0.0;            // sums of the first / last k values of y
 #pragma unroll
-    for (int j = 1; j <= kEssWin; ++j) {
-      const long long k = kb + j;
-      if (done || k >= S) { done = true; break; }
-      const double rho = dacc[j] / (double)(S - k) / c0;
-      if (rho < 0.0) { done = true; break; }
-      total += (double)(S - k) / (double)S * rho;
+    for (int j = 1; j <= W; ++j) {
+      const bool have = j - 1 < nh;
+      head += have ? (double)(x.at(j - 1) - r) : 0.0;
+      tail += have ? (double)(x.at(S - j) - r) : 0.0;          // x_{S-1-(j-1)}
+      const double cj = (double)tot[j * 64] - mp * (2.0 * T - head - tail) + (double)(S - j) * mp * mp;
+      const bool in_range = j < S;
+      const double rho = cj / (double)(in_range ? S - j : 1) / c0;
+      done = done || !in_range || rho < 0.0;
+      total += done ? 0.0 : (double)(S - j) / (double)S * rho;
     }
   }
-  ess[i] = (float)((double)S / (-1.0 + 2.0 * total));
+  done = done || S <= W;
+  if (S + 72 <= kEssRows * 64) {
+    // the wave's unfinished series, one after the other, 64 lags at a time by all lanes
+    __builtin_amdgcn_wave_barrier();          // every lane has consumed its totals: the block is free
+    unsigned long long pending = __ballot(!done);
+    while (pending) {
+      const int u = __builtin_amdgcn_readfirstlane(__builtin_ctzll(pending));
+      pending &= pending - 1;
+      const unsigned idx_u = __builtin_amdgcn_readlane((int)(x.boff >> 2), u);
+      const float mean_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mean), u));
+      const unsigned long long c0b = __builtin_bit_cast(unsigned long long, c0);
+      const unsigned long long c0u = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(c0b >> 32), u) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((int)c0b, u);
+      const double add = ess_tail_cooperative(trace, stride, S, idx_u, mean_u, __builtin_bit_cast(double, c0u), W, wbuf, lane);
+      if (lane == u) total += add;
+    }
+  } else {
+    // a series too long for the wave's LDS block: per lane, lags kb+1 .. kb+16 per sweep, leading and lagged stream read
+    for (long long kb = W; kb < S && !done; kb += WF) {
+      double dacc[WF + 1];
+      ess_sweep_far<WF>(x, S, mean, kb, dacc);
+#pragma unroll
+      for (int j = 1; j <= WF; ++j) {      // no early exit: the loop unrolls completely and dacc[] stays in registers
+        const long long k = kb + j;
+        const bool in_range = k < S;
+        const double rho = dacc[j] / (double)(in_range ? S - k : 1) / c0;
+        done = done || !in_range || rho < 0.0;
+        total += done ? 0.0 : (double)(S - k) / (double)S * rho;
+      }
+    }
+  }
+  if (valid) ess[i] = constant ? __builtin_nanf("") : (float)((double)S / (-1.0 + 2.0 * total));
 }
 
 }  // namespace arp
@@ -148,6 +328,7 @@ extern "C" int arp_ess(const float* trace, int64_t n_samples, int64_t n_series, 
     set_error("arp_ess: trace/ess, n_samples > 0, n_series > 0 and row_stride >= n_series are required");
     return 1;
   }
+  if (n_series >= (1ll << 30)) { set_error("arp_ess: at most 2^30 - 1 series per call (32-bit lane offsets)"); return 1; }
   const long long blocks = (n_series + 255) / 256;
   hipLaunchKernelGGL(ess_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, trace, (long long)n_samples,
                      (long long)n_series, (long long)row_stride, ess);

@@ -335,7 +335,8 @@ def test_interleaved_matches_oracle(oracle_lib, gpu, mname):
             tr = torch.zeros(3, Cn, sp.D, device=gpu)
             t0 = torch.zeros(3, Cn, dtype=torch.uint8, device=gpu); t1 = torch.zeros(3, Cn, dtype=torch.uint8, device=gpu)
             for _ in range(2):
-                eng.interleaved_run(st, e0, e1, 3, 2, 3, trace=tr, trace_accept0=t0, trace_accept1=t1, n_burnin=1, thin=2, **kw)
+                eng.interleaved_run(st, e0, e1, 3, 2, 3, trace=tr, trace_accept0=t0, trace_accept1=t1, n_burnin=1, thin=2,
+                                    trace_centered=False, **kw)   # parameterisation-0 coordinates, as inference.hmc_interleaved records
             assert torch.equal(st.q, r["st"].q) and torch.equal(st.rng, r["st"].rng)     # recording does not change the chain
             assert torch.equal(tr, r["x"][1::2]) and np.array_equal(t0.cpu().numpy(), r["acc"][1::2, 0]) \
                 and np.array_equal(t1.cpu().numpy(), r["acc"][1::2, 1])

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""GPU box: arp_ess on the headline trace (radon PA interleaved, 65 536 chains x 1 000 recorded samples = 18.6 GB) and on
+synthetic AR(1) traces of the same shape whose mixing is known -- how the time splits between the first sweep (every
+series) and the later ones (waves with a slowly mixing series).  One library per process (ARP_LIB_PATH selects a variant)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from autoreparam_amd import models, engine, _lib, util  # noqa: E402
+
+dev = torch.device("cuda:0")
+C, S = int(os.environ.get("ESS_C", "65536")), int(os.environ.get("ESS_S", "1000"))
+spec = models._spec_radon("PA")
+D = spec.D
+
+
+def timeit(x, n=5):
+    util.effective_sample_size(x); torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); e = util.effective_sample_size(x); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(np.median(ts)), e
+
+
+print("lib:", _lib.LIB_PATH)
+trace = torch.empty(S, C, D, dtype=torch.float32, device=dev)
+gb = trace.numel() * 4 / 1e9
+# (1) white noise: every series stops at its first or second lag -> the first sweep alone
+trace.normal_()
+ms, _ = timeit(trace)
+print("white noise          : %.3f ms  %.2f TB/s (one pass over %.1f GB)" % (ms, gb / ms, gb), flush=True)
+# (2) AR(1), rho = 0.75 on 3 of 71 elements (the top-level scalars), 0.3 elsewhere
+rho = torch.full((D,), 0.3, device=dev); rho[:3] = 0.75
+e = trace.clone() if False else None
+x = trace
+prev = torch.randn(C, D, device=dev)
+for t in range(S):
+    prev = rho * prev + torch.sqrt(1 - rho * rho) * torch.randn(C, D, device=dev)
+    x[t] = prev
+ms, ev = timeit(x)
+print("AR(1) 0.75 x3 / 0.3  : %.3f ms  %.2f TB/s; mean min-ESS %.1f" % (ms, gb / ms, float(ev.min(dim=1).values.mean())), flush=True)
+# (3) the headline sampler's own trace
+eng = engine.Engine(spec, dev); eng.set_param(0, "CP"); eng.set_param(1, "NCP")
+L = 4
+ee = np.full(D, 0.08, np.float32); ee[2] = 0.02
+st = engine.ChainState((0.1 * torch.randn(C, D)).to(dev))
+B = 1000
+total = 1 + B + 2 * (S - 1); done = 0
+while done < total:
+    n = min(4096, total - done)
+    eng.interleaved_run(st, ee, ee, L, L, n, seed=1, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=600, n_burnin=B, thin=2, trace=trace,
+                        trace_centered=False)
+    done += n
+ms, ev = timeit(trace)
+print("headline sampler run : %.3f ms  %.2f TB/s; mean min-ESS %.1f" % (ms, gb / ms, float(ev.min(dim=1).values.mean())), flush=True)
