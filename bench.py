@@ -95,7 +95,7 @@ def cpu_baseline(spec, L, n_chains, n_trans, eps0, lanes, inter):
                                                  LL, cores, dt)}
 
 
-def cpu_baseline_reference_shaped(spec, L, n_chains=1024, budget_s=6.0):
+def cpu_baseline_reference_shaped(spec, L, n_chains=128, budget_s=6.0, min_transitions=100, cap_s=30.0):
     """SURVEY.md 8(d) baseline (A): what the reference's XLA:CPU path executes, restated in torch on the host --
     float32, the county gather as a dense [N, J] one-hot matmul batched over chains, gradients by reverse-mode
     autodiff, one pass per leapfrog step (CP radon, momentum refresh and Metropolis test included).  Not the
@@ -122,7 +122,7 @@ def cpu_baseline_reference_shaped(spec, L, n_chains=1024, budget_s=6.0):
     eps = torch.full((3 + J,), 0.02)
     lp, g = grad(q)
     done, t0 = 0, time.time()
-    while time.time() - t0 < budget_s:
+    while (time.time() - t0 < budget_s or done < min_transitions) and time.time() - t0 < cap_s:
         p = torch.randn_like(q)
         h0 = -lp + 0.5 * (p * p).sum(1)
         qn, pn = q, p + 0.5 * eps * g
@@ -206,17 +206,20 @@ def reference_flow_ess(dataset, chains, dev_index, samples=1000, burnin=1000, ad
 
 
 def load_profile(tag_cfg):
-    """profiles/r02_headline.json (tools/summarize_profile.py) if it was taken on this configuration."""
-    p = os.path.join(ROOT, "profiles", "r02_headline.json")
-    if not os.path.exists(p):
+    """The newest profiles/rNN_headline.json (tools/summarize_profile.py), flagged with whether it was taken on this
+    configuration."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_headline.json")))
+    if not found:
         return None
+    p = found[-1]
     try:
         prof = json.load(open(p))
     except Exception:
         return None
     same = all(prof.get("config", {}).get(k) == v for k, v in tag_cfg.items())
     prof["config_matches_this_run"] = bool(same)
-    prof["source"] = "profiles/r02_headline.json"
+    prof["source"] = "profiles/" + os.path.basename(p)
     return prof
 
 
@@ -291,7 +294,7 @@ def main():
         rows = (Tn + thin_n - 1) // thin_n
         trace = torch.empty(rows, Cn, D, dtype=torch.float32, device=dev) if (record and not stats) else None
         stats_t = torch.zeros(6, Cn, D, dtype=torch.float32, device=dev) if stats else None
-        skw = dict(stats=stats_t, stats_batch=8, n_samples=1 << 30) if stats else {}
+        skw = dict(stats=stats_t, stats_batch=64, n_samples=1 << 30) if stats else {}   # the CLI's batches are S/8 samples
 
         def launch():
             # rows cycle through a bounded buffer (n_burnin = steps done: row 0 is this launch's first sample)
@@ -325,17 +328,23 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    per_launch_ms = [float(a.elapsed_time(b)) for a, b in ev]
+    kern_ms = float(np.mean(per_launch_ms))
 
     # end-of-run statistics exchange (the only collectives of the path, parallel.py): all-gather of a per-chain
     # statistic (here the acceptance rate; a sampling run gathers the per-chain minimum ESS the same way) and the
     # all-reduce of the acceptance counts
     acc = st.accept_count.float() / st.step
     t_coll = 0.0
+    rank_ms = [kern_ms]
     if dist is not None:
         tm = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         elapsed = float(tm.item())
+        # every rank's own kernel time (HIP events): the spread is the load imbalance of the sharding
+        km = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(km, torch.tensor([kern_ms], dtype=torch.float64, device=dev))
+        rank_ms = [float(t.item()) for t in km]
         torch.cuda.synchronize(); tc = time.perf_counter()
         acc = parallel.all_gather_chains(acc, C_total, dev)
         tot = parallel.all_reduce_sum(float(st.accept_count.sum().item()), dev)
@@ -358,8 +367,10 @@ def main():
         extras["no_trace"] = {"transitions_per_launch": T, "kernel_ms": ms, "leapfrog_steps_per_s": C * T * LL / (ms * 1e-3)}
         lst, _ = make_launcher(T, thin, stats=True)
         ms = _time_launches(lst, 5, 2)
-        extras["in_kernel_stats"] = {"transitions_per_launch": T, "thin": thin, "kernel_ms": ms,
-                                     "leapfrog_steps_per_s": C * T * LL / (ms * 1e-3)}
+        extras["in_kernel_stats"] = {"transitions_per_launch": T, "thin": thin, "stats_batch": 64, "kernel_ms": ms,
+                                     "leapfrog_steps_per_s": C * T * LL / (ms * 1e-3),
+                                     "overhead_vs_no_trace": ms / extras["no_trace"]["kernel_ms"] - 1.0,
+                                     "overhead_vs_headline": ms / kern_ms - 1.0}
         # the plain fused HMC kernel (CP, dual averaging, L leapfrogs, centred trace row every `thin`-th transition)
         lp_, _ = make_launcher(T, thin, plain=True)
         ms = _time_launches(lp_, 5, 2)
@@ -428,6 +439,40 @@ def main():
         extras["election"] = {"kernel": "pk_hmc_kernel<ElectionPk<4,13>>", "chains": Ce, "num_leapfrog_steps": Le, "forms": el}
         del eeng
 
+    # arp_ess on its own: the [S, C, D] trace of a sampling run at the headline size (1 000 recorded samples = 18.6 GB),
+    # priced against HBM: the kernel is a strided stream of the trace (algorithmic bytes = one read of it)
+    if secondary and inter and not args.no_ess:
+        try:
+            S_e = 1000
+            tr_e = torch.empty(S_e, C, D, dtype=torch.float32, device=dev)
+            st_e = engine.ChainState(q0)
+            total_e, done_e = 1 + 1000 + 2 * (S_e - 1), 0
+            while done_e < total_e:
+                n_e = min(4096, total_e - done_e)
+                eng.interleaved_run(st_e, eps_i, eps_i, num_ls, num_ls, n_e, seed=11, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=600,
+                                    n_burnin=1000, thin=2, trace=tr_e, trace_centered=False, lanes=args.lanes)
+                done_e += n_e
+            ess_t = []
+            ess_v = util.effective_sample_size(tr_e)
+            torch.cuda.synchronize()
+            for _ in range(5):
+                a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a_.record(); ess_v = util.effective_sample_size(tr_e); b_.record(); torch.cuda.synchronize()
+                ess_t.append(a_.elapsed_time(b_))
+            ems_ = float(np.median(ess_t))
+            nbytes = 4.0 * S_e * C * D
+            extras["ess_kernel"] = {
+                "kernel": "ess_kernel", "samples": S_e, "series": C * D, "kernel_ms": ems_, "kernel_ms_min": float(min(ess_t)),
+                "kernel_ms_max": float(max(ess_t)), "mean_min_ess_per_chain": float(ess_v.min(dim=1).values.mean().item()),
+                "roofline": {"bound": "hbm", "achieved": nbytes / (ems_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": nbytes / (ems_ * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                             "algorithmic_bytes": nbytes,
+                             "note": "algorithmic bytes = one read of the trace; series still positive at lag 16 are read "
+                                     "once more by their wave (64-byte sectors), so the HBM traffic is higher"}}
+            del tr_e, st_e, ess_v
+        except Exception as e:
+            extras["ess_kernel"] = {"error": repr(e)}
+
     # ESS/sec (second half of the BASELINE metric) from the reference flow at the headline size
     ess_info = None
     if secondary and inter and not args.no_ess:
@@ -452,7 +497,9 @@ def main():
         roof = {"bound": "valu", "achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / FP32_PEAK_TFLOPS, "traffic": traffic,
                 "kernel": "radon_interleaved_kernel<RadonPk<4,17>>" if inter else "pk_hmc_kernel<RadonPk<4,17>,CP>",
-                "kernel_ms": kern_ms, "algorithmic_flop_per_leapfrog": flop_lf,
+                "kernel_ms": kern_ms, "kernel_ms_min": float(np.min(per_launch_ms)),
+                "kernel_ms_median": float(np.median(per_launch_ms)), "kernel_ms_max": float(np.max(per_launch_ms)),
+                "algorithmic_flop_per_leapfrog": flop_lf,
                 "note": "FP32 vector issue binds this kernel (state in registers for the whole launch); frac = SURVEY 8(d) "
                         "algorithmic flops / HIP-event kernel time / 157.3 TFLOP/s",
                 "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
@@ -464,6 +511,11 @@ def main():
                                 "once per launch; the measured figure is what crosses HBM"}}
         if prof:
             roof["profile"] = prof
+            # shader clock held under this kernel's load (GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the profiled pass);
+            # the 157.3 TFLOP/s peak assumes 2.4 GHz
+            clk = prof.get("derived", {}).get("clock_ghz_estimate")
+            roof["clock_ghz_estimate"] = clk
+            roof["clock_source"] = prof["source"] if clk else None
         out = {
             "metric": "leapfrog-steps/sec (all chains) + ESS/sec, radon(%s) %d chains%s" % (
                 args.dataset, args.chains, " per GPU" if args.scaling == "weak" else " in total"),
@@ -484,7 +536,8 @@ def main():
                        "trace_thin": thin if rec else 0, "D": D, "lanes_per_chain": args.lanes,
                        "parallelism": "chains sharded, %d rank(s), %s scaling" % (world, args.scaling)},
             "roofline": roof,
-            "accept_rate": accept_rate, "rccl_ranks": world, "stats_allgather_s": t_coll, "ess": ess_info,
+            "accept_rate": accept_rate, "rccl_ranks": world, "stats_allgather_s": t_coll,
+            "kernel_ms_per_rank": rank_ms, "rank_imbalance_max_over_min": max(rank_ms) / min(rank_ms), "ess": ess_info,
         }
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:

@@ -106,7 +106,12 @@ summary = {
     "kernel": kname, "calls": int(dom["Calls"]), "avg_ns": avg_ns,
     "avg_ns_timed_launches": avg_timed_ns, "hip_events_ms_same_profiled_process": events_ms_same_process,
     "percentage_of_gpu_time": float(dom["Percentage"]),
-    "vgpr": int(vg["VGPR_Count"]), "agpr": int(vg["Accum_VGPR_Count"]), "sgpr": int(vg["SGPR_Count"]),
+    # rocprofv3's VGPR_Count is in half-granules on gfx950 (124 for a kernel the compiler reports at 247 architected
+    # VGPRs, allocated as 248 = 31 granules of 8): the register file figure is twice the column
+    "vgpr_rocprofv3_column": int(vg["VGPR_Count"]), "vgpr": 2 * int(vg["VGPR_Count"]),
+    "vgpr_note": "vgpr = 2 x rocprofv3 VGPR_Count (allocated registers, granule 8); the compiler's own count is in "
+                 "tools/kernel_resources.py's output (-Rpass-analysis=kernel-resource-usage)",
+    "agpr": int(vg["Accum_VGPR_Count"]), "sgpr": int(vg["SGPR_Count"]),
     "lds_bytes": int(vg["LDS_Block_Size"]), "scratch_bytes": int(vg["Scratch_Size"]),
     "grid": int(vg["Grid_Size_X"]), "workgroup": int(vg["Workgroup_Size_X"]),
     "config": {"chains": cfg["chains_per_gpu"], "transitions": cfg["transitions_per_step"], "thin": cfg["trace_thin"],
