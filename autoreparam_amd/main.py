@@ -167,6 +167,9 @@ def run_hmc(model_config, results_dir, file_path, tuning=False, flags=FLAGS):
     ess_min, sem_min, acceptance_rate, _ = parallel.summarize(
         normalized_ess_final, is_accepted, flags.num_samples, flags.num_chains, device=flags.device if ws > 1 else None)
     util.print_("ESS per 1000 gradients: {} +/- {}".format(ess_min, sem_min))
+    if ws > 1 and not tuning:
+        # _ess.npz / _ess.txt hold every chain's per-element ESS: collect the other ranks' blocks (a collective: all ranks)
+        normalized_ess_final = parallel.gather_parts(normalized_ess_final, flags.num_chains, flags.device)
     if rank != 0:
         return ess_min, sem_min, acceptance_rate, mcmc_time
     if tuning:
@@ -207,6 +210,8 @@ def run_interleaved_hmc_with_leapfrog_steps(model_config, results_dir, num_leapf
     acc_ncp = float(parallel.all_reduce_sum(float(np.sum(is_accepted_ncp)), dev).item()) * 100.0 / float(
         flags.num_samples * flags.num_chains)
     util.print_("ESS: {} +/- {}".format(ess_min, sem_min))
+    if ws > 1:
+        normalized_ess_final = parallel.gather_parts(normalized_ess_final, flags.num_chains, flags.device)
     # Only `[:, :num_chains_to_save]` of the samples is ever read again (save_ess).  Taking that slice to the host now
     # releases the [S, C, D] device trace before the next candidate leapfrog count allocates its own (two 18.6 GB traces
     # alive at once at the headline size, and a fresh device allocation of that size can cost half a second).
@@ -321,7 +326,8 @@ def main(argv=None, flags=FLAGS):
         import torch.distributed as dist
         local = int(os.environ.get("LOCAL_RANK", "0"))
         flags.device = "cuda:%d" % local
-        torch.cuda.set_device(local)
+        if torch.cuda.is_available():          # (the engine itself fails loudly without a GPU)
+            torch.cuda.set_device(local)
         if flags.inference == "VI":
             # VI is a one-workgroup-per-learning-rate job with nothing to exchange: rank 0 runs it and writes the
             # JSON, the other ranks leave, and NO process group is created -- a communicator whose peers have exited

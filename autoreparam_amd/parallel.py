@@ -12,6 +12,12 @@ import torch
 import torch.distributed as dist
 
 
+def _collective_device(device):
+    """Where a tensor has to live for the initialised backend: the rank's GPU for RCCL ("nccl"), the host for gloo
+    (the CPU tests of the rank logic)."""
+    return None if (device is None or dist.get_backend() == "gloo") else device
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -38,6 +44,7 @@ def all_gather_chains(local, n_total, device=None):
     t = torch.as_tensor(local)
     if ws == 1:
         return t
+    device = _collective_device(device)
     if device is not None:
         t = t.to(device)
     sizes = [shard_bounds(n_total, r, ws)[1] - shard_bounds(n_total, r, ws)[0] for r in range(ws)]
@@ -54,6 +61,7 @@ def all_reduce_sum(value, device=None):
     t = torch.as_tensor(value, dtype=torch.float64)
     if ws == 1:
         return t
+    device = _collective_device(device)
     if device is not None:
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -70,3 +78,11 @@ def summarize(normalized_ess_parts, is_accepted, num_samples, num_chains_total, 
     ess_min = float(np.mean(mins))
     sem_min = float(np.std(mins) / np.sqrt(len(mins)))
     return ess_min, sem_min, acc * 100.0 / float(num_samples * num_chains_total), mins
+
+
+def gather_parts(parts, num_chains_total, device=None):
+    """Every rank's [C_local, *event] arrays -> the [C, *event] arrays of the whole job, in chain order (the per-element
+    ESS that rank 0 writes to _ess.npz: <= 4 bytes per chain and element, once per run)."""
+    if world()[1] == 1:
+        return [np.asarray(p) for p in parts]
+    return [all_gather_chains(torch.as_tensor(np.asarray(p)), num_chains_total, device).cpu().numpy() for p in parts]

@@ -56,3 +56,127 @@ def test_two_rank_statistics_match_single_process(tmp_path):
     for r in range(2):
         e, s, a = np.load(os.path.join(str(tmp_path), "r%d.npy" % r))
         assert abs(e - e_ref) < 1e-5 and abs(s - s_ref) < 1e-5 and abs(a - a_ref) < 1e-9
+
+
+# ---------------------------------------------------------------------------
+# The CLI's own rank logic (autoreparam_amd/main.py) on two gloo ranks, with the engine calls replaced by
+# deterministic stand-ins keyed by the GLOBAL chain id: what is under test is everything main.py does around them --
+# VI on rank 0 only (the other ranks leave without a process group of their own), shard_states + chain_offset,
+# summarize over the real result objects, rank 0 writing the JSON / ESS files -- against the one-process run.
+# ---------------------------------------------------------------------------
+def _fake_engine(monkeypatch_target):
+    import collections
+    from autoreparam_amd import inference
+
+    def fake_vi(elbo, vp, learnable_parameters_prior=None, learnable_parameters=None, flags=None):
+        spec = elbo.target.spec
+        lv = collections.OrderedDict()
+        for k, name in enumerate(spec.part_names):
+            lv[name + "_loc"] = np.full(spec.part_shapes[k], 0.1 * (k + 1), np.float32)
+            lv[name + "_scale"] = np.full(spec.part_shapes[k], 0.5, np.float32)
+        return (np.float64(-12.5), [-13.0] * 40, 0.1, util.get_approximate_step_size(lv, 1), lv, None)
+
+    def _ess_parts(spec, g):
+        return [(10.0 + (g % 7)[(slice(None),) + (None,) * len(sh)] + k + np.zeros((len(g),) + tuple(sh))).astype(np.float32)
+                for k, sh in enumerate(spec.part_shapes)]
+
+    def fake_hmc(target, model_config, step_size_init, initial_states, reparam, flags=None, chain_offset=0):
+        spec = target.spec
+        Cl, S = initial_states[0].shape[0], int(flags.num_samples)
+        g = chain_offset + np.arange(Cl)
+        acc = ((np.arange(S)[:, None] + g[None, :]) % 3 != 0)
+        samples = [np.broadcast_to(g.reshape((1, Cl) + (1,) * len(sh)).astype(np.float32), (S, Cl) + tuple(sh)).copy()
+                   for sh in spec.part_shapes]
+        kr = inference.KernelResults(inference.HmcInnerResults(acc), np.ones(Cl, np.float32), S)
+        return None, kr, samples, _ess_parts(spec, g)
+
+    def fake_inter(model_config, target_cp, target_ncp, num_leapfrog_steps_cp, num_leapfrog_steps_ncp, step_size_cp,
+                   step_size_ncp, initial_states_cp, flags=None, chain_offset=0):
+        _, kr, samples, ess = fake_hmc(target_cp, model_config, step_size_cp, initial_states_cp, None, flags, chain_offset)
+        acc1 = ~np.asarray(kr.inner_results.is_accepted)
+        return samples, inference.InterleavedKernelResults(kr, inference.KernelResults(
+            inference.HmcInnerResults(acc1), kr.new_step_size, kr.step)), ess
+
+    inference.find_best_learning_rate = fake_vi
+    inference.hmc = fake_hmc
+    inference.hmc_interleaved = fake_inter
+
+
+def _cli_sequence(results_dir):
+    from autoreparam_amd import main as cli
+    from autoreparam_amd.flags import FLAGS
+    base = ["--model=8schools", "--results_dir=%s" % results_dir, "--seed=3", "--num_chains=7", "--num_samples=12",
+            "--num_burnin_steps=4", "--num_adaptation_steps=3", "--num_chains_to_save=2"]
+    out = {}
+    for m in ("CP", "NCP"):
+        out["vi_" + m] = cli.main(base + ["--inference=VI", "--method=" + m], flags=FLAGS.copy())
+        if dist.is_initialized():
+            dist.barrier()      # on the command line the VI run has ended (rank 0 has written its JSON) before HMC is launched
+        for L in (2, 4):
+            cli.main(base + ["--inference=HMCtuning", "--method=" + m, "--num_leapfrog_steps=%d" % L], flags=FLAGS.copy())
+    out["hmc"] = cli.main(base + ["--inference=HMC", "--method=CP"], flags=FLAGS.copy())
+    out["inter"] = cli.main(base + ["--inference=HMC", "--method=i"], flags=FLAGS.copy())
+    return out
+
+
+def _cli_worker(rank, ws, port, results_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(ws), RANK=str(rank), LOCAL_RANK=str(rank))
+    _fake_engine(None)
+    # VI first, BEFORE any process group exists: ranks != 0 must leave on RANK alone, rank 0 runs without one
+    from autoreparam_amd import main as cli
+    from autoreparam_amd.flags import FLAGS
+    r = cli.main(["--model=8schools", "--results_dir=%s" % results_dir, "--inference=VI", "--method=CP"], flags=FLAGS.copy())
+    assert (r is None) == (rank != 0) and not dist.is_initialized()
+    dist.init_process_group("gloo", rank=rank, world_size=ws)     # main() keeps an initialised group (RCCL on the GPU box)
+    dist.barrier()
+    out = _cli_sequence(results_dir)
+    assert (out["vi_NCP"] is None) == (rank != 0)
+    np.save(os.path.join(results_dir, "ret%d.npy" % rank), np.array([out["hmc"][0], out["hmc"][1], out["hmc"][2],
+                                                                      out["inter"][0], out["inter"][2], out["inter"][3]], np.float64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _results(d):
+    import json
+    out = {}
+    for f in sorted(os.listdir(d)):
+        if f.endswith(".json"):
+            r = json.load(open(os.path.join(d, f)))
+            for k in ("mcmc_time_sec", "variational_fit_time_secs"):
+                r.pop(k, None)
+            for t in r.get("tuning_runs", []):
+                t.pop("mcmc_time", None)
+            out[f] = r
+        elif f.endswith("_ess.npz") or f.endswith("_traces.npz"):
+            z = np.load(os.path.join(d, f))
+            out[f] = {k: z[k] for k in z.files}
+    return out
+
+
+def test_cli_rank_logic_two_ranks_equal_one(tmp_path):
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    os.makedirs(one); os.makedirs(two)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    import importlib
+    from autoreparam_amd import inference
+    saved = (inference.find_best_learning_rate, inference.hmc, inference.hmc_interleaved)
+    try:
+        _fake_engine(None)
+        ref = _cli_sequence(one)
+    finally:
+        inference.find_best_learning_rate, inference.hmc, inference.hmc_interleaved = saved
+    mp.spawn(_cli_worker, args=(2, _free_port(), two), nprocs=2, join=True)
+    a, b = _results(one), _results(two)
+    assert sorted(a) == sorted(b) and any(k.endswith("_ess.npz") for k in a)
+    for k in a:
+        for kk in a[k]:
+            va, vb = a[k][kk], b[k][kk]
+            if isinstance(va, np.ndarray):
+                assert np.array_equal(va, vb), (k, kk)
+            else:
+                assert va == vb or np.allclose(va, vb, rtol=1e-6), (k, kk, va, vb)
+    want = np.array([ref["hmc"][0], ref["hmc"][1], ref["hmc"][2], ref["inter"][0], ref["inter"][2], ref["inter"][3]])
+    for r in range(2):   # every rank returns the statistics over ALL chains
+        np.testing.assert_allclose(np.load(os.path.join(two, "ret%d.npy" % r)), want, rtol=1e-6)
