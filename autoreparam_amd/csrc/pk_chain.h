@@ -13,12 +13,18 @@
 
 namespace arp {
 
+// The value held by slot SRC (< 4) of a chain, in all of its K lanes: a quad broadcast, then -- the chain's first quad
+// being right -- a mirror into the other quads that writes only them (DPP bank masks; a bank is a quad of a 16-lane row).
+// Two or three v_mov_dpp instead of a select and a log2(K)-step butterfly of adds.
 template <int K, int SRC>
-ARP_DEV float group_bcast_from(float v, int slot) {
+ARP_DEV float group_bcast_from(float v, int) {
   static_assert(SRC < 4, "source slot must lie in the first quad");
+  static_assert(K == 1 || K >= 4, "a quad holds one chain or part of one");
   if (K == 1) return v;
-  if (K == 4 || K == 2) return dpp_mov<SRC * 0x55>(v);            // quad_perm [SRC, SRC, SRC, SRC]
-  return group_sum<K>(slot == SRC ? v : 0.0f);
+  int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), SRC * 0x55, 0xF, 0xF, true);      // quad_perm [SRC, SRC, SRC, SRC]
+  if (K >= 8) x = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, K == 8 ? 0xA : 0x2, false);     // row_half_mirror -> quad 1 (and 3)
+  if (K >= 16) x = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xC, false);                   // row_mirror -> quads 2, 3
+  return __int_as_float(x);
 }
 
 ARP_DEV v2f splat(float x) { return v2f{x, x}; }
@@ -110,7 +116,17 @@ ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const floa
     ke0 = 0.5f * (group_sum<K>(a[0] + a[1]) + kg);
   }
   float dlp, dke;
-  for (int l = 1; l < L; ++l) M.template pass<MODE, 0>(qg, qc, pg, pc, eg, ec, gg_, gc, dlp, dke);
+  // interior steps three at a time (the reference's num_leapfrog_steps = 4 is one such block): a loop around a single
+  // pass ends every pass with a round of register copies for its loop-carried state (8 - 9 v_mov per pass)
+  int l = 1;
+#pragma unroll 1
+  for (; l + 3 <= L; l += 3) {
+    M.template pass<MODE, 0>(qg, qc, pg, pc, eg, ec, gg_, gc, dlp, dke);
+    M.template pass<MODE, 0>(qg, qc, pg, pc, eg, ec, gg_, gc, dlp, dke);
+    M.template pass<MODE, 0>(qg, qc, pg, pc, eg, ec, gg_, gc, dlp, dke);
+  }
+#pragma unroll 1
+  for (; l < L; ++l) M.template pass<MODE, 0>(qg, qc, pg, pc, eg, ec, gg_, gc, dlp, dke);
   float lp1, ke1;
   M.template pass<MODE, 1>(qg, qc, pg, pc, eg, ec, gg_, gc, lp1, ke1);
 
@@ -180,7 +196,34 @@ ARP_DEV void pk_store_rows(const T& M, float* stage, float* gdst, int cl, int D,
       if ((it + 1) * 64 <= NV / 4 || k < NV / 4) g4[k] = s4[k];
     }
     __builtin_amdgcn_wave_barrier();
-  } else {   // ragged tail of the launch, or a county count that leaves padding: general offsets, out-of-line copy
+  } else if (nvalid == (64 / K) * D && (nvalid & 3) == 0 && (reinterpret_cast<uintptr_t>(gdst) & 15) == 0) {
+    // a full wave of a county count that leaves padding slices (D < DCAP: PA at 8 lanes per chain, the strong-scaling
+    // shard): run-time row stride, but the copy stays inline -- the out-of-line one below returns through
+    // s_waitcnt vmcnt(0), i.e. waits for the row it has just stored, and a lone wave per SIMD has nothing to hide that
+    // behind (12 % of the 8 192-chain launch).
+    float* row = stage + cl * D;
+    if (M.slot == 0) {
+#pragma unroll
+      for (int i = 0; i < T::NG; ++i) row[M.gg(i)] = xg[i];
+    }
+    float* e = row + T::LBASE + M.slot;
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (M.lvalid(i)) e[K * i] = xc[i >> 1][i & 1];
+    __builtin_amdgcn_wave_barrier();
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    lane &= 63;
+    const float4* s4 = reinterpret_cast<const float4*>(stage);
+    float4* g4 = reinterpret_cast<float4*>(gdst);
+    const int n4 = nvalid >> 2;
+#pragma unroll
+    for (int it = 0; it < (NV / 4 + 63) / 64; ++it) {
+      const int k = lane + 64 * it;
+      if (k < n4) g4[k] = s4[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+  } else {   // ragged tail of the launch, or an unaligned destination: general offsets, out-of-line copy
     float* row = stage + cl * D;
     if (M.slot == 0) {
 #pragma unroll
