@@ -25,6 +25,7 @@ struct ElectionPk {
   static_assert(NL_ >= 3, "at least two state pairs per lane");
   // three waves per SIMD (measured at K = 4: four waves cap the lane at 128 registers, spill 26 values and run 4 % slower)
   static constexpr int MINW = NL_ <= 13 ? 3 : 2;
+  static constexpr int PASS_BLOCK = 1;   // pk_chain.h: pk_transition's interior loop, one pass per iteration
   using Args = ElectionArgs;
 
   // ---- cell tables in LDS: entry (pair k, slot s) = 5 float4 ----
@@ -247,6 +248,24 @@ struct ElectionPk {
       else if (MODE == kModeNCP) x = vfma(vsig, qc[k], vmua);                   // a = b = 0: mua + sigma q
       else x = vfma((last ? mlast : splat(1.0f)) - al2[k], vmua, qc[k]);        // b = 1: q + (1 - a) mua
       xc[k] = (last && MODE == kModeNCP) ? x * mlast : x;
+    }
+  }
+
+  // the inverse: the state in parameterisation MODE of centred coordinates (xg, xc) (models.py:84-102 with election's scales)
+  template <int MODE>
+  ARP_DEV void from_centered(const float (&xg)[NG], const v2f (&xc)[NP], float (&qg)[NG], v2f (&qc)[NP]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qg[i] = xg[i] * (1.0f / cs<MODE>(i));
+    const v2f vmua = splat(xg[0]);
+    const v2f vis = splat(MODE == kModeNCP ? fast_exp(-xg[1]) : 1.0f);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const bool last = k == NP - 1;
+      v2f q;
+      if (MODE == kModeCP) q = xc[k];
+      else if (MODE == kModeNCP) q = (xc[k] - vmua) * vis;                      // (x - mua) / sigma
+      else q = vfma(al2[k] - (last ? mlast : splat(1.0f)), vmua, xc[k]);        // b = 1: x - (1 - a) mua
+      qc[k] = (last && MODE == kModeNCP) ? q * mlast : q;
     }
   }
 };

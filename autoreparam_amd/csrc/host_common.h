@@ -168,6 +168,15 @@ LaneOps election_lane_ops() {
     o.hmc_ncp = ARP_EL(kModeNCP);
     o.hmc_b1 = ARP_EL(kModeB1);
 #undef ARP_EL
+    // --method=i: centred / non-centred interleaving on the packed layer (pk_chain.h: pk_interleaved_kernel)
+    o.interleaved_cp_ncp = [](const void* args, const float* a0, const float* b0, const float*, const float*,
+                              const HmcParams& P, hipStream_t s) {
+      const dim3 g(Launch<ElectionLane<K, NL>>::blocks(P.C));
+      if (SL && P.stats && stats_lds_enabled())
+        hipLaunchKernelGGL((pk_interleaved_kernel<T, kModeCP, kModeNCP, SL>), g, dim3(kBlock), 0, s, *(const ElectionArgs*)args, a0, b0, P);
+      else
+        hipLaunchKernelGGL((pk_interleaved_kernel<T, kModeCP, kModeNCP>), g, dim3(kBlock), 0, s, *(const ElectionArgs*)args, a0, b0, P);
+    };
   }
   return o;
 }

@@ -29,6 +29,11 @@ ARP_DEV float group_bcast_from(float v, int) {
 
 ARP_DEV v2f splat(float x) { return v2f{x, x}; }
 
+// interior leapfrog passes per block of the transition loop: 3 unless the lane model says otherwise (PASS_BLOCK = 1:
+// election's passes are long enough that the copies do not matter and a three-pass block costs it registers)
+template <class T, class = void> struct pk_pass_block { static constexpr int value = 3; };
+template <class T> struct pk_pass_block<T, std::void_t<decltype(T::PASS_BLOCK)>> { static constexpr int value = T::PASS_BLOCK; };
+
 // Box-Muller pair as a register pair: (r cos, r sin) = one packed multiply
 ARP_DEV v2f normal_pair2(uint32_t w0, uint32_t w1) {
   const float u = fmaf((float)w0, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
@@ -119,11 +124,13 @@ ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const floa
   // interior steps three at a time (the reference's num_leapfrog_steps = 4 is one such block): a loop around a single
   // pass ends every pass with a round of register copies for its loop-carried state (8 - 9 v_mov per pass)
   int l = 1;
+  if constexpr (pk_pass_block<T>::value == 3) {
 #pragma unroll 1
-  for (; l + 3 <= L; l += 3) {
-    M.template pass<MODE, 0>(qg, qc, pg, pc, eg, ec, gg_, gc, dlp, dke);
-    M.template pass<MODE, 0>(qg, qc, pg, pc, eg, ec, gg_, gc, dlp, dke);
-    M.template pass<MODE, 0>(qg, qc, pg, pc, eg, ec, gg_, gc, dlp, dke);
+    for (; l + 3 <= L; l += 3) {
+      M.template pass<MODE, 0>(qg, qc, pg, pc, eg, ec, gg_, gc, dlp, dke);
+      M.template pass<MODE, 0>(qg, qc, pg, pc, eg, ec, gg_, gc, dlp, dke);
+      M.template pass<MODE, 0>(qg, qc, pg, pc, eg, ec, gg_, gc, dlp, dke);
+    }
   }
 #pragma unroll 1
   for (; l < L; ++l) M.template pass<MODE, 0>(qg, qc, pg, pc, eg, ec, gg_, gc, dlp, dke);
@@ -464,6 +471,142 @@ __global__ __launch_bounds__(kBlock, STATS && T::MINW > 2 ? 2 : T::MINW) void pk
       P.logp[c2] = lp;
       P.adapt[c2 * 4 + 0] = kappa; P.adapt[c2 * 4 + 1] = esum; P.adapt[c2 * 4 + 2] = logavg;
       P.accept_count[c2] = nacc;
+    }
+  }
+}
+
+// Interleaved sampling on the packed chain layer for lane models whose change of coordinates is NOT a unit-Jacobian
+// shear (election: x = mua + sigma z rescales): interleaved.Interleaved.one_step as the reference runs it
+// (interleaved.py:113-155) -- re-bootstrap logp / grad under parameterisation M0, one transition, the state through
+// centred coordinates into M1, re-bootstrap, one transition, and back; each inner kernel keeps its own adaptation state.
+// 2 (L + 1) gradient evaluations per step.  (Radon's shear carries the gradient instead: radon_fast.h.)
+// T additionally provides from_centered<MODE>.
+template <class T, int M0, int M1, bool STATS = false>
+__global__ __launch_bounds__(kBlock, STATS && T::MINW > 2 ? 2 : T::MINW) void pk_interleaved_kernel(
+    typename T::Args A, const float* __restrict__ av0, const float* __restrict__ bv0, HmcParams P) {
+  constexpr int K = T::K, NP = T::NP, ND = T::ND, NG = T::NG;
+  const unsigned t = blockIdx.x * (unsigned)kBlock + threadIdx.x;
+  const int slot = (int)(t % K);
+  int c = (int)(t / K);
+  const bool live = c < P.C;
+  if (!live) c = P.C - 1;
+  const int D = P.D;
+  ARP_LANE_SMEM(T);
+  T M;
+  lane_tables(M, A, s_lane_tab);
+  M.init(A, av0, bv0, slot);
+
+  __shared__ float s_eps[2][PkBlock<T>::kEps];
+  __shared__ __attribute__((aligned(16))) float s_save[PkBlock<T>::kSave];
+  __shared__ __attribute__((aligned(16))) float s_stats[STATS ? PkStats<T>::kFloats : 4];
+  int n_acc = 0;
+  float* wsave = s_save + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * pk_save_wave_floats<T>();
+  float* save = wsave + 2 * (threadIdx.x & 63);
+  float* stage = wsave;
+  const long long cw0 = (long long)((blockIdx.x * (unsigned)kBlock + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x & ~63)) / K);
+  const int cl = (threadIdx.x & 63) / K;
+  const int nvalid = (int)(P.C - cw0 < 64 / K ? (P.C - cw0 > 0 ? P.C - cw0 : 0) : 64 / K) * D;
+  for (int d = threadIdx.x; d < PkBlock<T>::kEps; d += kBlock) {
+    s_eps[0][d] = d < D ? P.eps0[d] : 0.0f;
+    s_eps[1][d] = d < D ? P.eps0_1[d] : 0.0f;
+  }
+  __syncthreads();
+
+  float qg[NG], gg_[NG]; v2f qc[NP], gc[NP];
+  {
+    float v[ND];
+    load_row(M, P.q + (size_t)c * D, v);
+    T::unpack(v, qg, qc);
+  }
+  float kap[2], es[2], la_[2];
+  Rng rng;
+  uint32_t* rs = P.rng + ((size_t)c * kRngSlots + slot) * 4;
+  uint32_t nacc0, nacc1;
+  if (P.step_base == 0) {
+    kap[0] = kap[1] = 1.0f; es[0] = es[1] = 0.0f; la_[0] = la_[1] = 0.0f;
+    nacc0 = nacc1 = 0u;
+    rng = rng_seed(P.seed, (unsigned long long)(P.chain_offset + c), (uint32_t)slot, (uint32_t)K);
+  } else {
+    kap[0] = P.adapt[(size_t)c * 4 + 0]; es[0] = P.adapt[(size_t)c * 4 + 1]; la_[0] = P.adapt[(size_t)c * 4 + 2];
+    kap[1] = P.adapt1[(size_t)c * 4 + 0]; es[1] = P.adapt1[(size_t)c * 4 + 1]; la_[1] = P.adapt1[(size_t)c * 4 + 2];
+    nacc0 = P.accept_count[c]; nacc1 = P.accept_count1[c];
+    rng = Rng{rs[0], rs[1]};
+  }
+  int next_rec = P.rec_step, rec_row = P.rec_row, bpos = P.stats_bpos;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  for (int s = 0; s < P.n_steps; ++s) {
+    const long long n = P.step_base + s + 1;
+    bool acc0, acc1;
+    float lp, ke;
+    float xg[NG]; v2f xc[NP];
+    {
+      float pg[NG] = {}, eg[NG] = {}; v2f pc[NP], ec[NP];
+      M.template pass<M0, 2>(qg, qc, pg, pc, eg, ec, gg_, gc, lp, ke);
+    }
+    float la = pk_transition<M0>(M, rng, P.L, kap[0], s_eps[0], qg, qc, gg_, gc, lp, acc0, save);
+    nacc0 += acc0 ? 1u : 0u;
+    adapt_update(P, n, la, kap[0], es[0], la_[0]);
+    M.template to_centered<M0>(qg, qc, xg, xc);
+    M.template from_centered<M1>(xg, xc, qg, qc);
+    {
+      float pg[NG] = {}, eg[NG] = {}; v2f pc[NP], ec[NP];
+      M.template pass<M1, 2>(qg, qc, pg, pc, eg, ec, gg_, gc, lp, ke);
+    }
+    la = pk_transition<M1>(M, rng, P.L1, kap[1], s_eps[1], qg, qc, gg_, gc, lp, acc1, save);
+    nacc1 += acc1 ? 1u : 0u;
+    adapt_update(P, n, la, kap[1], es[1], la_[1]);
+    M.template to_centered<M1>(qg, qc, xg, xc);
+    M.template from_centered<M0>(xg, xc, qg, qc);
+
+    if (s == next_rec && rec_row < P.n_samples) {
+      // x holds the centred state, q the parameterisation-0 state the reference records
+      const bool to_trace = P.trace && cw0 < P.trace_chains;
+      const bool use_x = P.trace_centered;
+      if (to_trace) {
+        const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
+        float* dst = P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D;
+        if (use_x) pk_store_rows(M, stage, dst, cl, D, nv, xg, xc); else pk_store_rows(M, stage, dst, cl, D, nv, qg, qc);
+      }
+      if (STATS) {
+        ++n_acc;
+        if (use_x) pk_stats_accumulate<T>(s_stats, n_acc, xg, xc); else pk_stats_accumulate<T>(s_stats, n_acc, qg, qc);
+        const bool bend = bpos + 1 == P.stats_batch;
+        if (bend) {
+          pk_stats_fold(M, stage, s_stats, P, cw0, cl, D, nvalid, n_acc, rec_row + 1 == n_acc, true);
+          n_acc = 0;
+        }
+        bpos = bend ? 0 : bpos + 1;
+      } else if (P.stats) {
+        float x[ND];
+        if (use_x) T::pack(xg, xc, x); else T::pack(qg, qc, x);
+        const bool bend = bpos + 1 == P.stats_batch;
+        stats_update_wave(M, stage, P, cw0, cl, D, nvalid, x, rec_row == 0, bend);
+        bpos = bend ? 0 : bpos + 1;
+      }
+      if (live && slot == 0) {
+        unsigned ci = (unsigned)c;
+        asm volatile("" : "+v"(ci));
+        if (P.trace_accept) (P.trace_accept + (size_t)rec_row * P.C)[ci] = acc0 ? 1 : 0;
+        if (P.trace_accept1) (P.trace_accept1 + (size_t)rec_row * P.C)[ci] = acc1 ? 1 : 0;
+        if (P.rec_accept) P.rec_accept[ci] += acc0 ? 1u : 0u;
+        if (P.rec_accept1) P.rec_accept1[ci] += acc1 ? 1u : 0u;
+      }
+      next_rec += P.thin;
+      rec_row += 1;
+    }
+  }
+  if (STATS && n_acc > 0) pk_stats_fold(M, stage, s_stats, P, cw0, cl, D, nvalid, n_acc, rec_row == n_acc, false);
+  size_t c2 = (size_t)c;
+  asm volatile("" : "+v"(c2));
+  const long long cw2 = cw0;
+  pk_store_rows(M, stage, P.q + cw2 * D, cl, D, nvalid, qg, qc);
+  if (live) {
+    uint32_t* rs2 = P.rng + ((size_t)c2 * kRngSlots + slot) * 4;
+    rs2[0] = rng.x; rs2[1] = rng.c; rs2[2] = 0u; rs2[3] = 0u;
+    if (slot == 0) {
+      P.adapt[c2 * 4 + 0] = kap[0]; P.adapt[c2 * 4 + 1] = es[0]; P.adapt[c2 * 4 + 2] = la_[0];
+      P.adapt1[c2 * 4 + 0] = kap[1]; P.adapt1[c2 * 4 + 1] = es[1]; P.adapt1[c2 * 4 + 2] = la_[1];
+      P.accept_count[c2] = nacc0; P.accept_count1[c2] = nacc1;
     }
   }
 }

@@ -53,6 +53,29 @@ def radon_flop_per_leapfrog(J, D):
     return 30.0 * J + 20.0 + 4.0 * D
 
 
+# Vector-issue bound of the election kernels.  Their FMA count understates them: every state costs one v_exp and four
+# v_rcp per gradient (eight v_log more in the closing pass), and transcendentals issue at a quarter of the FMA rate.
+# Instruction counts per WAVE (16 chains at 4 lanes per chain) from the ISA of pk_hmc_kernel<ElectionPk<4,13>, MODE>
+# (tools/asm_loops.py: interior leapfrog pass, closing pass, momentum draw + first drift + Metropolis + adaptation),
+# priced with the issue costs measured on MI355X (tools/valu_bench.hip, cycles per wave instruction at >= 2 waves per
+# SIMD): transcendental 8.2, v_pk_*_f32 4.4, other vector 2.6.
+ISSUE_CYCLES = {"trans": 8.2, "pk": 4.4, "other": 2.6}
+ELECTION_MIX = {
+    "NCP": {"interior": {"trans": 73, "pk": 149, "other": 50}, "closing": {"trans": 130, "pk": 238, "other": 80},
+            "start": {"trans": 36, "pk": 43, "other": 105}},
+    "tied_cVIP_b1": {"interior": {"trans": 74, "pk": 177, "other": 50}, "closing": {"trans": 131, "pk": 266, "other": 85},
+                     "start": {"trans": 36, "pk": 43, "other": 105}},
+}
+
+
+def election_issue_bound(form, L, clock_ghz=2.4):
+    """leapfrog-steps/s if the vector pipes of all 1 024 SIMDs issued this instruction mix back to back"""
+    m = ELECTION_MIX[form]
+    cyc = lambda b: sum(ISSUE_CYCLES[k] * v for k, v in b.items())
+    per_transition = (L - 1) * cyc(m["interior"]) + cyc(m["closing"]) + cyc(m["start"])      # one wave = 16 chains
+    return 256 * 4 * clock_ghz * 1e9 * 16 * L / per_transition, per_transition
+
+
 def _time_launches(fn, n, warm=2):
     for _ in range(warm):
         fn()
@@ -430,11 +453,19 @@ def main():
             epse = np.full(espec.D, 0.02, np.float32)
             kwe = dict(seed=5, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9)
             ems = _time_launches(lambda: eeng.hmc_run(ste, epse, Le, Te, **kwe), 3, 1)
-            el[name] = {"kernel_ms": ems, "leapfrog_steps_per_s": Ce * Te * Le / (ems * 1e-3),
+            rate = Ce * Te * Le / (ems * 1e-3)
+            ib, ib_cyc = election_issue_bound(name, Le)
+            el[name] = {"kernel_ms": ems, "leapfrog_steps_per_s": rate,
                         "roofline": {"bound": "valu", "achieved": Ce * Te * Le * eflop / (ems * 1e-3) / 1e12,
                                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                      "frac": Ce * Te * Le * eflop / (ems * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                                     "algorithmic_flop_per_leapfrog": eflop}}
+                                     "algorithmic_flop_per_leapfrog": eflop},
+                        # the ceiling the transcendentals set: the same kernel's instruction mix issued back to back
+                        "issue_bound": {"leapfrog_steps_per_s": ib, "frac": rate / ib, "clock_ghz": 2.4,
+                                        "issue_cycles_per_wave_transition": ib_cyc, "mix_per_wave": ELECTION_MIX[name],
+                                        "cycles_per_instruction": ISSUE_CYCLES,
+                                        "note": "per state and gradient: 1 v_exp + 4 v_rcp (+ 8 v_log per state pair in the "
+                                                "closing pass) at a quarter of the FMA issue rate; counts from the ISA"}}
             del ste
         extras["election"] = {"kernel": "pk_hmc_kernel<ElectionPk<4,13>>", "chains": Ce, "num_leapfrog_steps": Le, "forms": el}
         del eeng
