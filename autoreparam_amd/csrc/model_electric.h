@@ -18,9 +18,9 @@
 //   loglik_j = -(n_0 + n_1) s_g - w Q / 2,  w = exp(-2 s_g)
 //   d/da = w (n_0 r_0 + n_1 r_1),  d/db_g = w n_1 r_1,  d/ds_g = w Q - (n_0 + n_1)
 // The grade look-ups and scatters are one-hot FMAs against the replicated grade scalars.  The
-// one-hot weights depend on (slot, slice) only, not on the chain, so they live in a 3.5 KB LDS
-// table shared by the workgroup (two ds_read_b128 per pair and gradient) instead of 56 registers
-// per lane: that is what lets two waves share a SIMD.
+// one-hot weights and the five cell statistics depend on (slot, slice) only, not on the chain, so
+// they live in a 7 KB LDS table shared by the workgroup (four ds_read_b128 per pair and gradient)
+// instead of 91 registers per lane: that is what lets two waves share a SIMD without scratch.
 #pragma once
 #include "arp_device.h"
 
@@ -58,22 +58,37 @@ struct ElectricLane {
   static constexpr int MINW = 2;   // waves per SIMD the register allocator must leave room for
   using Args = ElectricArgs;
 
-  float n0[NL], y0[NL], n1[NL], y1[NL], ss[NL], al[NL];
+  float al[NL];
   float lat_last;   // 1 if the lane's last slice is a pair effect, 0 if it is the observation-only group P or padding
   ARP_DEV float lat(int i) const { return i < NL - 1 ? 1.0f : lat_last; }
   float si[kElG], cs[kElG];   // 1/100^b and 100^(1-b) of b_k
   int slot, P;
 
-  // one-hot weights of (slice i, slot): [wm0..3][og0..3], 32 bytes per entry
+  // table entry of (slice i, slot): [wm0..3][og0..3][n0 y0 n1 y1][ss - - -], 64 bytes
+  static constexpr int kEntry = 16;
   static ARP_DEV float* onehot_table() {
-    __shared__ __attribute__((aligned(16))) float tab[NL * K * 8];
+    __shared__ __attribute__((aligned(16))) float tab[NL * K * kEntry];
     return tab;
   }
+  // the entry's index is laundered: the table is loop invariant, and left to itself the compiler hoists every read out
+  // of the leapfrog loop into registers -- the very registers the table is there to save
+  ARP_DEV int entry(int i) const {
+    int e = (i * K + slot) * kEntry;
+    asm volatile("" : "+v"(e));
+    return e;
+  }
   ARP_DEV void onehot(int i, float (&wm)[kElG], float (&og)[kElG]) const {
-    const float4* t = reinterpret_cast<const float4*>(onehot_table() + (i * K + slot) * 8);
+    const float4* t = reinterpret_cast<const float4*>(onehot_table() + entry(i));
     const float4 a = t[0], b = t[1];
     wm[0] = a.x; wm[1] = a.y; wm[2] = a.z; wm[3] = a.w;
     og[0] = b.x; og[1] = b.y; og[2] = b.z; og[3] = b.w;
+  }
+  // the pair's two cells: counts and means of the control / treated scores, pooled within-cell sum of squares
+  ARP_DEV void cells(int i, float& n0, float& y0, float& n1, float& y1, float& ss) const {
+    const float* e = onehot_table() + entry(i);
+    const float4 c = reinterpret_cast<const float4*>(e)[2];
+    n0 = c.x; y0 = c.y; n1 = c.z; y1 = c.w;
+    ss = e[12];
   }
 
   // flattened index of replicated scalar i: mua, sigma_y in front of a[P], b behind it
@@ -93,13 +108,13 @@ struct ElectricLane {
       if ((int)threadIdx.x < K) {   // the first chain of the workgroup fills the table for everybody
 #pragma unroll
         for (int k = 0; k < kElG; ++k) {
-          tab[(i * K + slot) * 8 + k] = has ? A.wm[k * stride + j] : 0.0f;
-          tab[(i * K + slot) * 8 + 4 + k] = has ? A.og[k * stride + j] : 0.0f;
+          tab[(i * K + slot) * kEntry + k] = has ? A.wm[k * stride + j] : 0.0f;
+          tab[(i * K + slot) * kEntry + 4 + k] = has ? A.og[k * stride + j] : 0.0f;
         }
+        float* e = tab + (i * K + slot) * kEntry + 8;
+        e[0] = has ? A.n0[j] : 0.0f; e[1] = has ? A.y0[j] : 0.0f; e[2] = has ? A.n1[j] : 0.0f; e[3] = has ? A.y1[j] : 0.0f;
+        e[4] = has ? A.ss[j] : 0.0f; e[5] = 0.0f; e[6] = 0.0f; e[7] = 0.0f;
       }
-      n0[i] = has ? A.n0[j] : 0.0f; y0[i] = has ? A.y0[j] : 0.0f;
-      n1[i] = has ? A.n1[j] : 0.0f; y1[i] = has ? A.y1[j] : 0.0f;
-      ss[i] = has ? A.ss[j] : 0.0f;
     }
     lat_last = slot + K * (NL - 1) < P ? 1.0f : 0.0f;
     __syncthreads();
@@ -136,11 +151,13 @@ struct ElectricLane {
       const float r = fmaf(-al[i], mu, q[NG + i]);   // group P / padding: q = 0, al = 0, wm = 0 -> r = 0
       const float aj = r + mu;
       const float w = fast_exp(-2.0f * sg);
-      const float r0 = y0[i] - aj, r1 = (y1[i] - aj) - bg;
-      const float e0 = n0[i] * r0, e1 = n1[i] * r1;
+      float n0, y0, n1, y1, ss;
+      cells(i, n0, y0, n1, y1, ss);
+      const float r0 = y0 - aj, r1 = (y1 - aj) - bg;
+      const float e0 = n0 * r0, e1 = n1 * r1;
       const float dA = w * (e0 + e1);
-      const float Q = fmaf(e0, r0, fmaf(e1, r1, ss[i]));
-      const float nn = n0[i] + n1[i];
+      const float Q = fmaf(e0, r0, fmaf(e1, r1, ss));
+      const float nn = n0 + n1;
       const float dSv = fmaf(w, Q, -nn);
       const float dBv = w * e1;
       const float ga = lat(i) * (dA - r);

@@ -29,6 +29,12 @@ ARP_DEV float group_bcast_from(float v, int) {
 
 ARP_DEV v2f splat(float x) { return v2f{x, x}; }
 
+// Lane models with an odd number of slices per lane may treat the last "pair" (one slice and a padding slot) as scalar
+// operations on the pair's first element everywhere (SCALAR_TAIL = true; radon: the padding half of a v_pk_*_f32 costs
+// as much as the real one).  The pair's second registers are then never read by the transition.
+template <class T, class = void> struct pk_scalar_tail { static constexpr bool value = false; };
+template <class T> struct pk_scalar_tail<T, std::void_t<decltype(T::SCALAR_TAIL)>> { static constexpr bool value = T::SCALAR_TAIL && (T::NL & 1); };
+
 // interior leapfrog passes per block of the transition loop: 3 unless the lane model says otherwise (PASS_BLOCK = 1:
 // election's passes are long enough that the copies do not matter and a three-pass block costs it registers)
 template <class T, class = void> struct pk_pass_block { static constexpr int value = 3; };
@@ -59,13 +65,16 @@ ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const floa
                                float (&qg)[T::NG], v2f (&qc)[T::NP], float (&gg_)[T::NG], v2f (&gc)[T::NP], float& lp,
                                bool& accepted, float* __restrict__ save) {
   constexpr int K = T::K, NP = T::NP, NL = T::NL, NG = T::NG;
+  constexpr bool TAIL = pk_scalar_tail<T>::value;
+  constexpr int NPF = TAIL ? NP - 1 : NP;       // pairs handled as pairs
   // step sizes: base steps from LDS (zero beyond D, so padding elements never move) times the chain's multiplier
   float eg[NG]; v2f ec[NP];
   {
     const float* e = s_eps + T::LBASE + M.slot;
     const v2f vk = splat(kappa);
 #pragma unroll
-    for (int k = 0; k < NP; ++k) ec[k] = v2f{e[K * 2 * k], e[K * (2 * k + 1)]} * vk;
+    for (int k = 0; k < NPF; ++k) ec[k] = v2f{e[K * 2 * k], e[K * (2 * k + 1)]} * vk;
+    if constexpr (TAIL) ec[NP - 1] = v2f{e[K * 2 * (NP - 1)] * kappa, 0.0f};
 #pragma unroll
     for (int i = 0; i < NG; ++i) eg[i] = s_eps[M.gg(i)] * kappa;
   }
@@ -73,7 +82,11 @@ ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const floa
   {
     v2f* s2 = reinterpret_cast<v2f*>(save);
 #pragma unroll
-    for (int k = 0; k < NP; ++k) { s2[k * 64] = qc[k]; s2[(NP + k) * 64] = gc[k]; }
+    for (int k = 0; k < NPF; ++k) { s2[k * 64] = qc[k]; s2[(NP + k) * 64] = gc[k]; }
+    if constexpr (TAIL) {
+      reinterpret_cast<float*>(s2 + (NP - 1) * 64)[0] = qc[NP - 1][0];
+      reinterpret_cast<float*>(s2 + (2 * NP - 1) * 64)[0] = gc[NP - 1][0];
+    }
     float* s1 = save + 4 * NP * 64 - 2 * (threadIdx.x & 63) + (threadIdx.x & 63) / K;   // chain columns behind the pair columns
 #pragma unroll
     for (int i = 0; i < NG; ++i) { s1[i * (64 / K)] = qg[i]; s1[(NG + i) * (64 / K)] = gg_[i]; }
@@ -82,17 +95,24 @@ ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const floa
   float pg[NG]; v2f pc[NP];
   float extra;
 #pragma unroll
-  for (int k = 0; k < NP; ++k) {
+  for (int k = 0; k < NPF; ++k) {
     const uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
     pc[k] = normal_pair2(w0, w1);
   }
-  if (NL & 1) {
-    extra = pc[NP - 1][1];
-  } else {
+  if constexpr (TAIL) {
     const uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
-    extra = normal_pair2(w0, w1)[0];
+    const v2f z = normal_pair2(w0, w1);
+    extra = z[1];
+    pc[NP - 1] = v2f{z[0] * M.mlast[0], 0.0f};
+  } else {
+    if (NL & 1) {
+      extra = pc[NP - 1][1];
+    } else {
+      const uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
+      extra = normal_pair2(w0, w1)[0];
+    }
+    pc[NP - 1] *= M.mlast;
   }
-  pc[NP - 1] *= M.mlast;
   float u = u01_open0(rng_next(rng));
   u = group_bcast_from<K, 0>(u, M.slot);
   static_assert(NG <= 4 && NG <= K, "one extra normal per slot covers the top-level scalars");
@@ -105,11 +125,20 @@ ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const floa
     v2f a = pc[0] * pc[0];
     const v2f half = splat(0.5f);
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
+    for (int k = 0; k < NPF; ++k) {
       if (k > 0) a = vfma(pc[k], pc[k], a);
       // first half kick and first drift
       pc[k] = vfma(half, ec[k] * gc[k], pc[k]);
       qc[k] = vfma(ec[k], pc[k], qc[k]);
+    }
+    float at = 0.0f;
+    if constexpr (TAIL) {
+      constexpr int k = NP - 1;
+      const float p0 = pc[k][0], e0 = ec[k][0];
+      at = p0 * p0;
+      const float pn = fmaf(0.5f, e0 * gc[k][0], p0);
+      pc[k][0] = pn;
+      qc[k][0] = fmaf(e0, pn, qc[k][0]);
     }
     float kg = 0.0f;
 #pragma unroll
@@ -118,7 +147,7 @@ ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const floa
       pg[i] = fmaf(0.5f * eg[i], gg_[i], pg[i]);
       qg[i] = fmaf(eg[i], pg[i], qg[i]);
     }
-    ke0 = 0.5f * (group_sum<K>(a[0] + a[1]) + kg);
+    ke0 = 0.5f * (group_sum<K>(TAIL ? (a[0] + a[1]) + at : a[0] + a[1]) + kg);
   }
   float dlp, dke;
   // interior steps three at a time (the reference's num_leapfrog_steps = 4 is one such block): a loop around a single
@@ -144,7 +173,11 @@ ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const floa
   if (!accepted) {
     const v2f* s2 = reinterpret_cast<const v2f*>(save);
 #pragma unroll
-    for (int k = 0; k < NP; ++k) { qc[k] = s2[k * 64]; gc[k] = s2[(NP + k) * 64]; }
+    for (int k = 0; k < NPF; ++k) { qc[k] = s2[k * 64]; gc[k] = s2[(NP + k) * 64]; }
+    if constexpr (TAIL) {
+      qc[NP - 1][0] = reinterpret_cast<const float*>(s2 + (NP - 1) * 64)[0];
+      gc[NP - 1][0] = reinterpret_cast<const float*>(s2 + (2 * NP - 1) * 64)[0];
+    }
     const float* s1 = save + 4 * NP * 64 - 2 * (threadIdx.x & 63) + (threadIdx.x & 63) / K;
 #pragma unroll
     for (int i = 0; i < NG; ++i) { qg[i] = s1[i * (64 / K)]; gg_[i] = s1[(NG + i) * (64 / K)]; }

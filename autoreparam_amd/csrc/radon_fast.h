@@ -29,9 +29,10 @@ struct RadonPk {
   static constexpr int NP = (NL_ + 1) / 2;          // county pairs (the last one half padding when NL is odd)
   static constexpr int DCAP = NG + K_ * NL_;
   static constexpr int LBASE = 3;
-  static_assert(NL_ >= 3, "at least two county pairs per lane");
+  static_assert(NL_ >= 4, "at least two full county pairs per lane");
   static_assert(K_ >= 4, "the packed kernels deal the top-level momenta out over the first slots of a chain");
   static constexpr int MINW = 2;
+  static constexpr bool SCALAR_TAIL = true;   // pk_chain.h: an odd last county is taken as scalar operations
   using Args = RadonArgs;
 
   v2f n2[NP], sx2[NP], sy2[NP], u2[NP];
@@ -88,11 +89,16 @@ struct RadonPk {
     const float mua = qg[0], b1 = qg[1], b2 = qg[2];
     const v2f vb1 = splat(b1), vnb2 = splat(-b2), vmua = splat(mua);
     const v2f vmua_last = vmua * mlast;     // padding: mu = 0 there (its u is 0), so r = m = 0
+    // With an odd number of counties per lane (PA at 4 lanes: 17) the last "pair" is one county and a padding slot: it
+    // is taken as SCALAR operations on the pair's first element (a v_fma_f32 issues in 2.5 cycles against 4.4 for the
+    // v_pk_fma_f32 whose second half would be padding); the pair's second registers are never read.
+    constexpr bool TAIL = (NL & 1) != 0;
+    constexpr int NPF = NL / 2;               // full pairs
     v2f ah[1], auh[1], ams[1];      // accumulators, seeded by the first pair's terms
     v2f alp = splat(0.0f), ake = splat(0.0f);
     const v2f half = splat(0.5f);
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
+    for (int k = 0; k < NPF; ++k) {
       const v2f mt = qc[k];
       const v2f mu = vfma(u2[k], vb1, (k == NP - 1 && MODE == kModeCP) ? vmua_last : vmua);
       const v2f t = vfma(vnb2, sx2[k], sy2[k]);
@@ -121,10 +127,35 @@ struct RadonPk {
         }
       }
     }
+    float th_t = 0.0f, tuh_t = 0.0f, tms_t = 0.0f, alp_t = 0.0f, ake_t = 0.0f;
+    if constexpr (TAIL) {
+      constexpr int k = NP - 1;
+      const float mt = qc[k][0], uk = u2[k][0], sxk = sx2[k][0], syk = sy2[k][0], ek = ec[k][0];
+      const float mu = fmaf(uk, b1, MODE == kModeCP ? vmua_last[0] : mua);
+      const float t = fmaf(-b2, sxk, syk);
+      float r, m;
+      if (MODE == kModeCP) { r = mt - mu; m = mt; } else { r = mt; m = mt + mu; }
+      const float l = fmaf(-n2[k][0], m, t);
+      const float gm = l - r;
+      const float h = (MODE == kModeCP) ? r : l;
+      th_t = h; tuh_t = uk * h; tms_t = m * sxk;
+      if (PASS == 0) {
+        const float pn = fmaf(ek, gm, pc[k][0]);
+        pc[k][0] = pn;
+        qc[k][0] = fmaf(ek, pn, mt);
+      } else {
+        gc[k] = v2f{gm, 0.0f};
+        alp_t = mt * (gm + syk);
+        if (PASS == 1) {
+          const float pf = fmaf(0.5f, ek * gm, pc[k][0]);
+          ake_t = pf * pf;
+        }
+      }
+    }
     const v2f th = ah[0], tuh = auh[0], tms = ams[0];
-    const float s_h = group_sum<K>(th[0] + th[1]);
-    const float s_uh = group_sum<K>(tuh[0] + tuh[1]);
-    const float s_ms = group_sum<K>(tms[0] + tms[1]);
+    const float s_h = group_sum<K>(TAIL ? (th[0] + th[1]) + th_t : th[0] + th[1]);
+    const float s_uh = group_sum<K>(TAIL ? (tuh[0] + tuh[1]) + tuh_t : tuh[0] + tuh[1]);
+    const float s_ms = group_sum<K>(TAIL ? (tms[0] + tms[1]) + tms_t : tms[0] + tms[1]);
     const float g0 = s_h - mua, g1 = s_uh - b1, g2 = fmaf(-b2, sxx, sxy) - s_ms - b2;
     if (PASS == 0) {
       pg[0] = fmaf(eg[0], g0, pg[0]); qg[0] = fmaf(eg[0], pg[0], mua);
@@ -137,7 +168,7 @@ struct RadonPk {
       float top = mua * (g0 + c0);
       top = fmaf(b1, g1 + c1, top);
       top = fmaf(b2, g2 + sxy, top);
-      lp = 0.5f * (group_sum<K>(alp[0] + alp[1]) + top);
+      lp = 0.5f * (group_sum<K>(TAIL ? (alp[0] + alp[1]) + alp_t : alp[0] + alp[1]) + top);
       if (PASS == 1) {
         float kg = 0.0f;
 #pragma unroll
@@ -145,7 +176,7 @@ struct RadonPk {
           const float pf = fmaf(0.5f * eg[i], gg_[i], pg[i]);
           kg = fmaf(pf, pf, kg);
         }
-        ke = 0.5f * (group_sum<K>(ake[0] + ake[1]) + kg);
+        ke = 0.5f * (group_sum<K>(TAIL ? (ake[0] + ake[1]) + ake_t : ake[0] + ake[1]) + kg);
       }
     }
   }
@@ -154,16 +185,26 @@ struct RadonPk {
   // FROM == kModeCP: CP -> NCP, FROM == kModeNCP: NCP -> CP.
   template <int FROM>
   ARP_DEV void carry(float (&qg)[3], v2f (&qc)[NP], float (&gg_)[3], const v2f (&gc)[NP]) const {
+    constexpr bool TAIL = (NL & 1) != 0;
+    constexpr int NPF = NL / 2;
     const v2f vb1 = splat(qg[1]), vmua = splat(qg[0]);
     const v2f vmua_last = vmua * mlast;
     v2f s = gc[0], su = u2[0] * gc[0];             // gradients of padding elements are 0
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
+    for (int k = 0; k < NPF; ++k) {
       const v2f mu = vfma(u2[k], vb1, k == NP - 1 ? vmua_last : vmua);
       if (k > 0) { s += gc[k]; su = vfma(u2[k], gc[k], su); }
       qc[k] = (FROM == kModeCP) ? qc[k] - mu : qc[k] + mu;
     }
-    const float ts = group_sum<K>(s[0] + s[1]), tsu = group_sum<K>(su[0] + su[1]);
+    float st = 0.0f, sut = 0.0f;
+    if constexpr (TAIL) {
+      constexpr int k = NP - 1;
+      const float mu = fmaf(u2[k][0], qg[1], vmua_last[0]);
+      st = gc[k][0]; sut = u2[k][0] * gc[k][0];
+      qc[k][0] = (FROM == kModeCP) ? qc[k][0] - mu : qc[k][0] + mu;
+    }
+    const float ts = group_sum<K>(TAIL ? (s[0] + s[1]) + st : s[0] + s[1]);
+    const float tsu = group_sum<K>(TAIL ? (su[0] + su[1]) + sut : su[0] + su[1]);
     gg_[0] += (FROM == kModeCP) ? ts : -ts;
     gg_[1] += (FROM == kModeCP) ? tsu : -tsu;
   }
