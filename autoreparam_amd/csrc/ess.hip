@@ -33,7 +33,14 @@ namespace arp {
 #endif
 constexpr int kEssWin = ARP_ESS_WIN;      // lags per sweep
 constexpr int kEssFar = 16;               // lags per sweep past the first
-constexpr int kEssLoad = kEssWin % 16 == 0 ? 16 : 8;   // samples per load batch of the first sweep (two batches in flight)
+#ifndef ARP_ESS_LOAD
+#define ARP_ESS_LOAD (ARP_ESS_WIN % 16 == 0 ? 16 : 8)
+#endif
+#ifndef ARP_ESS_DEPTH
+#define ARP_ESS_DEPTH 2
+#endif
+constexpr int kEssLoad = ARP_ESS_LOAD;    // samples per load batch of the first sweep
+constexpr int kEssDepth = ARP_ESS_DEPTH;  // load buffers: kEssDepth - 1 batches are in flight while one is consumed
 
 // Accuracy: blocked float summation -- window sums of <= 128 products, added into float running totals (S / 128 of them
 // per lag): relative error ~ sqrt(128 + S / 128) x 2^-24 ~ 1e-6 typical, (128 + S / 128) x 2^-24 <= 4e-5 worst case at
@@ -111,24 +118,24 @@ __device__ __forceinline__ void ess_sweep_first(const EssSeries& x, long long S,
       w[tt] = y;
     }
   };
-  float a[LB], b[LB];
-  ess_load<LB>(x, 0, S, r, a);
+  // kEssDepth load buffers rotate: batch P is consumed from buffer P mod kEssDepth while the batches up to
+  // kEssDepth - 1 ahead of it are in flight.  The time loop is unrolled by a number of batches that is a whole number of
+  // buffer rotations AND of ring lengths, so buffers and ring positions are compile-time constants.
+  constexpr int DEPTH = kEssDepth, RB = W / LB;
+  constexpr int NB = (RB % DEPTH == 0) ? RB : RB * DEPTH;
+  float buf[DEPTH][LB];
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; ++d)
+    if ((long long)d * LB < S) ess_load<LB>(x, (long long)d * LB, S, r, buf[d]);
   int nb = 0;
-  // the time loop is unrolled by an even number of batches that is a whole number of ring lengths: the two load buffers
-  // alternate, and every ring position is a compile-time constant
-  constexpr int NB = (W / LB) % 2 == 0 ? W / LB : 2 * (W / LB);
   for (long long t0 = 0; t0 < S; t0 += NB * LB) {
     ess_unrolled_batches<NB>([&](auto ph) {
       constexpr int P = decltype(ph)::value;
       const long long tb = t0 + P * LB;            // first sample of this batch
       if (tb >= S) return;
-      if (P % 2 == 0) {
-        if (tb + LB < S) ess_load<LB>(x, tb + LB, S, r, b);        // one batch ahead
-        block(a, ph);
-      } else {
-        if (tb + LB < S) ess_load<LB>(x, tb + LB, S, r, a);
-        block(b, ph);
-      }
+      const long long ta = tb + (DEPTH - 1) * LB;  // the batch that goes in flight now
+      if (ta < S) ess_load<LB>(x, ta, S, r, buf[(P + DEPTH - 1) % DEPTH]);
+      block(buf[P % DEPTH], ph);
       if (++nb == 128 / LB) { flush(); nb = 0; }
     });
   }

@@ -470,6 +470,47 @@ def main():
         extras["election"] = {"kernel": "pk_hmc_kernel<ElectionPk<4,13>>", "chains": Ce, "num_leapfrog_steps": Le, "forms": el}
         del eeng
 
+    # BASELINE configs[1] (radon MN, CP, 4 096 chains, L = 4) and the SURVEY 8f-3 models on the same fused HMC kernel
+    # family, each priced on its own algorithmic flop count (SURVEY 8(d) style: per logp+grad, + 4 D for the leapfrog update)
+    if secondary:
+        others = {}
+
+        def time_model(tag, mspec, reparam, Cm, Lm, Tm, step, flop_lf, note):
+            try:
+                me = engine.Engine(mspec, dev)
+                me.set_param(0, reparam)
+                rsm = np.random.RandomState(3)
+                stm = engine.ChainState(torch.as_tensor((0.1 * rsm.randn(Cm, mspec.D)).astype(np.float32), device=dev))
+                epm = np.full(mspec.D, step, np.float32)
+                kwm = dict(seed=5, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9)
+                msm = _time_launches(lambda: me.hmc_run(stm, epm, Lm, Tm, **kwm), 3, 1)
+                rate = Cm * Tm * Lm / (msm * 1e-3)
+                others[tag] = {"chains": Cm, "num_leapfrog_steps": Lm, "transitions_per_launch": Tm, "kernel_ms": msm,
+                               "leapfrog_steps_per_s": rate, "accept_rate": float(stm.accept_count.float().mean().item() / stm.step),
+                               "roofline": {"bound": "valu", "achieved": rate * flop_lf / 1e12, "peak": FP32_PEAK_TFLOPS,
+                                            "unit": "TFLOP/s", "frac": rate * flop_lf / 1e12 / FP32_PEAK_TFLOPS,
+                                            "algorithmic_flop_per_leapfrog": flop_lf}, "note": note}
+                del me, stm
+            except Exception as e:
+                others[tag] = {"error": repr(e)}
+
+        mn = models._spec_radon("MN")
+        Jm = mn.D - 3
+        time_model("config2_radon_MN_CP_4096", mn, "CP", 4096, 4, 256, 0.05, radon_flop_per_leapfrog(Jm, mn.D),
+                   "BASELINE configs[1]: 4 096 chains fill a quarter of the lanes a 256-CU device wants (16 lanes per chain: one wave per SIMD)")
+        time_model("radon_MN_CP_65536", mn, "CP", 65536, 4, 64, 0.05, radon_flop_per_leapfrog(Jm, mn.D),
+                   "4 lanes per chain, 22 counties per lane: the packed kernel spills 4 - 21 values (DESIGN.md section 9)")
+        sd = models._spec_radon_stddvs("MN")
+        time_model("radon_stddvs_MN_NCP_65536", sd, "NCP", 65536, 8, 16, 0.01, 45.0 * Jm + 20.0 + 4.0 * sd.D,
+                   "per county 6 sufficient statistics and one exp: ~45 flop per county and gradient")
+        el = models._spec_electric()
+        time_model("electric_NCP_65536", el, "NCP", 65536, 8, 16, 0.01, 97 * 60.0 + 12 * 10.0 + 4.0 * el.D,
+                   "97 groups x ~60 flop (two cells, one-hot grade look-ups as 12 FMAs, one exp) + 12 grade scalars")
+        ts = models._spec_time_series()
+        time_model("time_series_NCP_65536", ts, "NCP", 65536, 8, 16, 0.05, 60 * 80.0 + 4.0 * ts.D,
+                   "60 time steps x ~80 flop (centring recurrence and its adjoint as block scans); one wave per SIMD")
+        extras["other_models"] = others
+
     # arp_ess on its own: the [S, C, D] trace of a sampling run at the headline size (1 000 recorded samples = 18.6 GB),
     # priced against HBM: the kernel is a strided stream of the trace (algorithmic bytes = one read of it)
     if secondary and inter and not args.no_ess:
