@@ -60,23 +60,94 @@ template <class T> constexpr int pk_save_floats() { return (kBlock / 64) * pk_sa
 // kernels.h: hmc_transition with the state in pairs.  Random stream layout 1 (DESIGN.md "Randomness"): a slot
 // draws one normal per county it owns, then one more, which is the momentum of top-level scalar `slot`
 // (slots 0..2), then the Metropolis word (slot 0's is used).
-template <int MODE, class T>
-ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const float* __restrict__ s_eps,
-                               float (&qg)[T::NG], v2f (&qc)[T::NP], float (&gg_)[T::NG], v2f (&gc)[T::NP], float& lp,
-                               bool& accepted, float* __restrict__ save) {
+//
+// The transition comes in two halves, the state-independent DRAW and the rest.  (Round 3 tried the draw of the next
+// transition between the LDS reads that end a transition -- the parked state of the rejecting lanes, the next base step
+// sizes -- and their first use, SQ_WAIT_INST_LDS being 12 % of a wave's time: same 3.38 - 3.41 ms per headline launch,
+// six spilled registers.  The other wave of the SIMD already covers those waits.)
+template <class T>
+struct PkDraw {
+  v2f pc[T::NP];       // momenta of the county pairs (padding masked)
+  float pg[T::NG];     // momenta of the top-level scalars, replicated
+  float logu, ke0;     // log of the Metropolis uniform; kinetic energy of the draw
+  v2f ec[T::NP];       // BASE step sizes of the coming transition (pk_eps_load), scaled by the chain's multiplier in pk_run
+  float eg[T::NG];
+};
+
+// base step sizes from LDS (zero beyond D, so padding elements never move)
+template <class T>
+ARP_DEV void pk_eps_load(const T& M, const float* __restrict__ s_eps, PkDraw<T>& d) {
+  constexpr int K = T::K, NP = T::NP, NG = T::NG;
+  constexpr bool TAIL = pk_scalar_tail<T>::value;
+  constexpr int NPF = TAIL ? NP - 1 : NP;
+  const float* e = s_eps + T::LBASE + M.slot;
+#pragma unroll
+  for (int k = 0; k < NPF; ++k) d.ec[k] = v2f{e[K * 2 * k], e[K * (2 * k + 1)]};
+  if constexpr (TAIL) d.ec[NP - 1] = v2f{e[K * 2 * (NP - 1)], 0.0f};
+#pragma unroll
+  for (int i = 0; i < NG; ++i) d.eg[i] = s_eps[M.gg(i)];
+}
+
+template <class T>
+ARP_DEV void pk_draw(const T& M, Rng& rng, PkDraw<T>& d) {
   constexpr int K = T::K, NP = T::NP, NL = T::NL, NG = T::NG;
   constexpr bool TAIL = pk_scalar_tail<T>::value;
   constexpr int NPF = TAIL ? NP - 1 : NP;       // pairs handled as pairs
-  // step sizes: base steps from LDS (zero beyond D, so padding elements never move) times the chain's multiplier
-  float eg[NG]; v2f ec[NP];
+  float extra;
+#pragma unroll
+  for (int k = 0; k < NPF; ++k) {
+    const uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
+    d.pc[k] = normal_pair2(w0, w1);
+  }
+  if constexpr (TAIL) {
+    const uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
+    const v2f z = normal_pair2(w0, w1);
+    extra = z[1];
+    d.pc[NP - 1] = v2f{z[0] * M.mlast[0], 0.0f};
+  } else {
+    if (NL & 1) {
+      extra = d.pc[NP - 1][1];
+    } else {
+      const uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
+      extra = normal_pair2(w0, w1)[0];
+    }
+    d.pc[NP - 1] *= M.mlast;
+  }
+  float u = u01_open0(rng_next(rng));
+  u = group_bcast_from<K, 0>(u, M.slot);
+  d.logu = fast_log(u);
+  static_assert(NG <= 4 && NG <= K, "one extra normal per slot covers the top-level scalars");
+  d.pg[0] = group_bcast_from<K, 0>(extra, M.slot);
+  if constexpr (NG > 1) d.pg[1] = group_bcast_from<K, 1>(extra, M.slot);
+  if constexpr (NG > 2) d.pg[2] = group_bcast_from<K, 2>(extra, M.slot);
+  if constexpr (NG > 3) d.pg[3] = group_bcast_from<K, 3>(extra, M.slot);
+  v2f a = d.pc[0] * d.pc[0];
+#pragma unroll
+  for (int k = 1; k < NPF; ++k) a = vfma(d.pc[k], d.pc[k], a);
+  float at = 0.0f;
+  if constexpr (TAIL) at = d.pc[NP - 1][0] * d.pc[NP - 1][0];
+  float kg = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NG; ++i) kg = fmaf(d.pg[i], d.pg[i], kg);
+  d.ke0 = 0.5f * (group_sum<K>(TAIL ? (a[0] + a[1]) + at : a[0] + a[1]) + kg);
+}
+
+// the rest of the transition, with the draw and the base step sizes in `d`
+template <int MODE, class T>
+ARP_DEV float pk_run(const T& M, PkDraw<T>& d, int L, float kappa, float (&qg)[T::NG], v2f (&qc)[T::NP],
+                     float (&gg_)[T::NG], v2f (&gc)[T::NP], float& lp, bool& accepted, float* __restrict__ save) {
+  constexpr int K = T::K, NP = T::NP, NG = T::NG;
+  constexpr bool TAIL = pk_scalar_tail<T>::value;
+  constexpr int NPF = TAIL ? NP - 1 : NP;
+  v2f (&pc)[NP] = d.pc; float (&pg)[NG] = d.pg;
+  v2f (&ec)[NP] = d.ec; float (&eg)[NG] = d.eg;
   {
-    const float* e = s_eps + T::LBASE + M.slot;
     const v2f vk = splat(kappa);
 #pragma unroll
-    for (int k = 0; k < NPF; ++k) ec[k] = v2f{e[K * 2 * k], e[K * (2 * k + 1)]} * vk;
-    if constexpr (TAIL) ec[NP - 1] = v2f{e[K * 2 * (NP - 1)] * kappa, 0.0f};
+    for (int k = 0; k < NPF; ++k) ec[k] *= vk;
+    if constexpr (TAIL) ec[NP - 1][0] *= kappa;
 #pragma unroll
-    for (int i = 0; i < NG; ++i) eg[i] = s_eps[M.gg(i)] * kappa;
+    for (int i = 0; i < NG; ++i) eg[i] *= kappa;
   }
   // park the start state
   {
@@ -91,63 +162,25 @@ ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const floa
 #pragma unroll
     for (int i = 0; i < NG; ++i) { s1[i * (64 / K)] = qg[i]; s1[(NG + i) * (64 / K)] = gg_[i]; }
   }
-  // momenta
-  float pg[NG]; v2f pc[NP];
-  float extra;
-#pragma unroll
-  for (int k = 0; k < NPF; ++k) {
-    const uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
-    pc[k] = normal_pair2(w0, w1);
-  }
-  if constexpr (TAIL) {
-    const uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
-    const v2f z = normal_pair2(w0, w1);
-    extra = z[1];
-    pc[NP - 1] = v2f{z[0] * M.mlast[0], 0.0f};
-  } else {
-    if (NL & 1) {
-      extra = pc[NP - 1][1];
-    } else {
-      const uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
-      extra = normal_pair2(w0, w1)[0];
-    }
-    pc[NP - 1] *= M.mlast;
-  }
-  float u = u01_open0(rng_next(rng));
-  u = group_bcast_from<K, 0>(u, M.slot);
-  static_assert(NG <= 4 && NG <= K, "one extra normal per slot covers the top-level scalars");
-  pg[0] = group_bcast_from<K, 0>(extra, M.slot);
-  if constexpr (NG > 1) pg[1] = group_bcast_from<K, 1>(extra, M.slot);
-  if constexpr (NG > 2) pg[2] = group_bcast_from<K, 2>(extra, M.slot);
-  if constexpr (NG > 3) pg[3] = group_bcast_from<K, 3>(extra, M.slot);
-  float ke0;
-  {
-    v2f a = pc[0] * pc[0];
+  {   // first half kick and first drift
     const v2f half = splat(0.5f);
 #pragma unroll
     for (int k = 0; k < NPF; ++k) {
-      if (k > 0) a = vfma(pc[k], pc[k], a);
-      // first half kick and first drift
       pc[k] = vfma(half, ec[k] * gc[k], pc[k]);
       qc[k] = vfma(ec[k], pc[k], qc[k]);
     }
-    float at = 0.0f;
     if constexpr (TAIL) {
       constexpr int k = NP - 1;
-      const float p0 = pc[k][0], e0 = ec[k][0];
-      at = p0 * p0;
-      const float pn = fmaf(0.5f, e0 * gc[k][0], p0);
+      const float e0 = ec[k][0];
+      const float pn = fmaf(0.5f, e0 * gc[k][0], pc[k][0]);
       pc[k][0] = pn;
       qc[k][0] = fmaf(e0, pn, qc[k][0]);
     }
-    float kg = 0.0f;
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
-      kg = fmaf(pg[i], pg[i], kg);
       pg[i] = fmaf(0.5f * eg[i], gg_[i], pg[i]);
       qg[i] = fmaf(eg[i], pg[i], qg[i]);
     }
-    ke0 = 0.5f * (group_sum<K>(TAIL ? (a[0] + a[1]) + at : a[0] + a[1]) + kg);
   }
   float dlp, dke;
   // interior steps three at a time (the reference's num_leapfrog_steps = 4 is one such block): a loop around a single
@@ -167,9 +200,9 @@ ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const floa
   M.template pass<MODE, 1>(qg, qc, pg, pc, eg, ec, gg_, gc, lp1, ke1);
 
   // log accept ratio; any non-finite energy error rejects (TFP safe_sum semantics)
-  float la = (lp1 - lp) + (ke0 - ke1);
+  float la = (lp1 - lp) + (d.ke0 - ke1);
   if (!(fabsf(la) <= 3.0e38f)) la = -INFINITY;
-  accepted = fast_log(u) < la;
+  accepted = d.logu < la;
   if (!accepted) {
     const v2f* s2 = reinterpret_cast<const v2f*>(save);
 #pragma unroll
@@ -184,6 +217,17 @@ ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const floa
   }
   lp = accepted ? lp1 : lp;
   return la;
+}
+
+// draw + run in one piece (kernels that do not interleave the draw with anything)
+template <int MODE, class T>
+ARP_DEV float pk_transition(const T& M, Rng& rng, int L, float kappa, const float* __restrict__ s_eps,
+                               float (&qg)[T::NG], v2f (&qc)[T::NP], float (&gg_)[T::NG], v2f (&gc)[T::NP], float& lp,
+                               bool& accepted, float* __restrict__ save) {
+  PkDraw<T> d;
+  pk_eps_load(M, s_eps, d);
+  pk_draw(M, rng, d);
+  return pk_run<MODE>(M, d, L, kappa, qg, qc, gg_, gc, lp, accepted, save);
 }
 
 // the copy half of kernels.h: store_row_wave as a real call (cold path; keeps its address arithmetic out of the callers)
