@@ -32,7 +32,9 @@ namespace arp {
 #define ARP_ESS_MINB 4
 #endif
 constexpr int kEssWin = ARP_ESS_WIN;      // lags per sweep
-constexpr int kEssFar = 16;               // lags per sweep past the first
+constexpr int kEssFar = 16;               // lags per sweep past the first (series too long for the LDS block)
+constexpr int kEssDenseLags = 32;         // lags of the dense continuation sweep (ring = kEssWin + 32 = 48 values)
+constexpr int kEssDenseAbove = 3;         // ... taken by a wave with more than this many series still positive
 #ifndef ARP_ESS_LOAD
 #define ARP_ESS_LOAD (ARP_ESS_WIN % 16 == 0 ? 16 : 8)
 #endif
@@ -183,6 +185,43 @@ __device__ __forceinline__ void ess_sweep_far(const EssSeries& x, long long S, f
   for (int j = 1; j <= W; ++j) dacc[j] += (double)acc[j];
 }
 
+// Dense continuation: lags KB+1 .. KB+W2 of ALL the wave's series in one more coalesced pass, about the mean, from a
+// ring of the last KB + W2 values (positions addressed at compile time: the time loop is unrolled by the ring length).
+// Taken by a wave when MANY of its series are still positive at lag KB -- long-trajectory HMC decorrelates slowly but
+// evenly: on the headline flow's kept candidate (8 + 8 leapfrogs) the median series is cut at lag 10 and 27 % run past 16,
+// i.e. ~ 17 of a wave's 64; one series at a time (below) that was 20 of the kernel's 24 ms.
+template <int KB, int W2>
+__device__ __forceinline__ void ess_sweep_dense(const EssSeries& x, long long S, float mean, float (&acc)[W2 + 1]) {
+  constexpr int R = KB + W2, LB = 8;
+  static_assert(R % LB == 0 && (R / LB) % 2 == 0, "load batches tile the ring, the two buffers alternate evenly");
+  float ring[R];
+#pragma unroll
+  for (int j = 0; j <= W2; ++j) acc[j] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < R; ++j) ring[j] = 0.0f;
+  // float sums: lags this far out only decide where the sum is cut and add a few per cent to it; W2 x S / 2 products
+  // of a centred series (relative error ~ sqrt(S) 2^-24) need no double accumulation
+  float buf[2][LB];
+  ess_load<LB>(x, 0, S, mean, buf[0]);
+  for (long long t0 = 0; t0 < S; t0 += R) {
+    ess_unrolled_batches<R / LB>([&](auto ph) {
+      constexpr int P = decltype(ph)::value;
+      const long long tb = t0 + P * LB;
+      if (tb >= S) return;
+      if (tb + LB < S) ess_load<LB>(x, tb + LB, S, mean, buf[(P + 1) % 2]);
+#pragma unroll
+      for (int tl = 0; tl < LB; ++tl) {
+        constexpr int dummy = 0; (void)dummy;
+        const int tt = P * LB + tl;
+        const float y = buf[P % 2][tl] - mean;
+#pragma unroll
+        for (int j = 1; j <= W2; ++j) acc[j] = fmaf(y, ring[(tt - KB - j + 2 * R) % R], acc[j]);
+        ring[tt] = y;
+      }
+    });
+  }
+}
+
 // Lags beyond W of ONE series, by the whole wave.  After the first sweep a wave typically holds a few series that are
 // still positive at lag W (a chain's slowly mixing elements) next to sixty that are finished; sweeping on per lane would
 // issue a full wave's instructions for three live lanes.  Instead the wave copies the series into its LDS block once
@@ -293,6 +332,21 @@ __global__ __launch_bounds__(256, ARP_ESS_MINB) void ess_kernel(const float* __r
     }
   }
   done = done || S <= W;
+  int tail_from = W;                          // first lag not yet taken
+  if (__builtin_popcountll(__ballot(!done)) > kEssDenseAbove && S > W + kEssDenseLags) {
+    // many of the wave's series go on: the next kEssDenseLags lags of all of them in one more coalesced pass
+    float acc2[kEssDenseLags + 1];
+    ess_sweep_dense<W, kEssDenseLags>(x, S, mean, acc2);
+#pragma unroll
+    for (int j = 1; j <= kEssDenseLags; ++j) {
+      const long long k = W + j;
+      const bool in_range = k < S;
+      const double rho = (double)acc2[j] / (double)(in_range ? S - k : 1) / c0;
+      done = done || !in_range || rho < 0.0;
+      total += done ? 0.0 : (double)(S - k) / (double)S * rho;
+    }
+    tail_from = W + kEssDenseLags;
+  }
   if (S + 72 <= kEssRows * 64) {
     // the wave's unfinished series, one after the other, 64 lags at a time by all lanes
     __builtin_amdgcn_wave_barrier();          // every lane has consumed its totals: the block is free
@@ -305,12 +359,12 @@ __global__ __launch_bounds__(256, ARP_ESS_MINB) void ess_kernel(const float* __r
       const unsigned long long c0b = __builtin_bit_cast(unsigned long long, c0);
       const unsigned long long c0u = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(c0b >> 32), u) << 32) |
                                      (unsigned)__builtin_amdgcn_readlane((int)c0b, u);
-      const double add = ess_tail_cooperative(trace, stride, S, idx_u, mean_u, __builtin_bit_cast(double, c0u), W, wbuf, lane);
+      const double add = ess_tail_cooperative(trace, stride, S, idx_u, mean_u, __builtin_bit_cast(double, c0u), tail_from, wbuf, lane);
       if (lane == u) total += add;
     }
   } else {
     // a series too long for the wave's LDS block: per lane, lags kb+1 .. kb+16 per sweep, leading and lagged stream read
-    for (long long kb = W; kb < S && !done; kb += WF) {
+    for (long long kb = tail_from; kb < S && !done; kb += WF) {
       double dacc[WF + 1];
       ess_sweep_far<WF>(x, S, mean, kb, dacc);
 #pragma unroll

@@ -203,6 +203,15 @@ def reference_flow_ess(dataset, chains, dev_index, samples=1000, burnin=1000, ad
                                "--num_samples=%d" % samples, "--num_burnin_steps=%d" % burnin,
                                "--num_adaptation_steps=%d" % adapt], flags=fl)
         ess_norm, sem_norm, acc_cp, acc_ncp, mcmc_time = res[0], res[1], res[2], res[3], res[4]
+        # arp_ess on the flow's own trace (the kept candidate's [S, C, D]): HIP events around the last call
+        from autoreparam_amd import util as _util
+        ess_call = None
+        ev = getattr(_util.effective_sample_size, "last_events", None)
+        if ev is not None:
+            torch.cuda.synchronize(dev)
+            ems = float(ev[0].elapsed_time(ev[1]))
+            ess_call = {"kernel_ms": ems, "trace_bytes": ev[2], "algorithmic_GBps": ev[2] / (ems * 1e-3) / 1e9,
+                        "frac_of_8TBps": ev[2] / (ems * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         with open(os.path.join(tmp, "i_tied.json")) as f:
             saved = json.load(f)
         num_ls = int(saved["num_leapfrog_steps"][-1])
@@ -215,7 +224,7 @@ def reference_flow_ess(dataset, chains, dev_index, samples=1000, burnin=1000, ad
                 "ess_min_per_1000_gradients": float(ess_norm), "sem_min_per_1000_gradients": float(sem_norm),
                 "acceptance_rate_cp": float(acc_cp), "acceptance_rate_ncp": float(acc_ncp),
                 "mcmc_time_sec": float(mcmc_time), "vi_time_sec": t_vi, "tuning_time_sec": t_tune,
-                "trace_first_alloc_sec": t_alloc,
+                "trace_first_alloc_sec": t_alloc, "arp_ess_on_this_trace": ess_call,
                 "ess_per_sec": ess / float(mcmc_time),
                 # what a fresh process would see: the first device allocation of the trace block inside the clock
                 "ess_per_sec_cold": ess / (float(mcmc_time) + t_alloc),
