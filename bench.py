@@ -112,10 +112,29 @@ def cpu_baseline(spec, L, n_chains, n_trans, eps0, lanes, inter):
     dt = time.time() - t0
     cores = len(os.sched_getaffinity(0))
     LL = 2 * L if inter else L
-    return {"value": n_chains * n_trans * LL / dt, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d chains x %d %s x %d leapfrogs, float32 C oracle (oracle/oracle.c) with OpenMP over chains "
-                      "on %d threads, %.1f s" % (n_chains, n_trans, "interleaved steps" if inter else "transitions",
-                                                 LL, cores, dt)}
+    out = {"value": n_chains * n_trans * LL / dt, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+           "sample": "%d chains x %d %s x %d leapfrogs, float32 C oracle (oracle/oracle.c) with OpenMP over chains "
+                     "on %d threads, %.1f s" % (n_chains, n_trans, "interleaved steps" if inter else "transitions",
+                                                LL, cores, dt)}
+    # the same port on ONE core (XLA:CPU's elementwise code is effectively single-threaded)
+    try:
+        import ctypes
+        omp = ctypes.CDLL("libgomp.so.1")
+        omp.omp_set_num_threads(1)
+        st1 = oracle.new_state(q0[:256], np.float32)
+        n1 = 1024
+        t0 = time.time()
+        if inter:
+            orc.interleaved_run(st1, cp, ncp, eps0, eps0, L, L, n1, seed=1, adapt_kind=2, n_adapt=10 ** 6, lanes=lanes)
+        else:
+            orc.hmc_run(st1, cp[0], cp[1], eps0, L, n1, seed=1, adapt_kind=1, n_adapt=10 ** 6, lanes=lanes)
+        d1 = time.time() - t0
+        omp.omp_set_num_threads(cores)
+        out["single_core"] = {"value": 256 * n1 * LL / d1, "unit": "leapfrog-steps/s", "cores": 1,
+                              "sample": "256 chains x %d steps x %d leapfrogs on one thread, %.1f s" % (n1, LL, d1)}
+    except Exception as e:
+        out["single_core"] = {"value": None, "error": repr(e)}
+    return out
 
 
 def cpu_baseline_reference_shaped(spec, L, n_chains=128, budget_s=6.0, min_transitions=100, cap_s=30.0):

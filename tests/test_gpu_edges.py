@@ -34,6 +34,24 @@ def test_bad_arguments_raise(gpu):
         eng.hmc_run(st, eps, 2, 1, lanes=3)
     eng.hmc_run(st, eps, 2, 0)                          # zero transitions: a no-op
     assert st.step == 0 and torch.equal(st.q, torch.zeros_like(st.q))
+    # the step-size recurrences compare log alpha with log(target): a target outside (0, 1) is refused, not mis-adapted
+    for bad in (0.0, 1.0, 1.5, float("nan")):
+        with pytest.raises(RuntimeError, match="adapt_target"):
+            eng.hmc_run(st, eps, 2, 1, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=5, adapt_target=bad)
+        with pytest.raises(RuntimeError, match="adapt_target"):
+            eng.adapt_probe(np.zeros((2, 3), np.float32), torch.ones(3, 4, device=gpu), _lib.ADAPT_DUAL, 2, target=bad)
+    with pytest.raises(RuntimeError, match="adapt_rate"):
+        eng.hmc_run(st, eps, 2, 1, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=5, adapt_rate=0.0)
+    eng.hmc_run(st, eps, 2, 1, adapt_kind=_lib.ADAPT_NONE, adapt_target=7.0)      # not adapting: the field is not read
+    # shared-parameter groups of the untied VI: every element must point at the first element of a contiguous group
+    lr = [0.1]
+    loc = torch.zeros(1, sp.D, device=gpu); rho = torch.full((1, sp.D), -2.0, device=gpu)
+    w = torch.zeros(1, sp.D, device=gpu); wb = torch.zeros(1, sp.D, device=gpu)
+    good = np.arange(sp.D); good[4:9] = 4
+    eng.vi_run(lr, loc, rho, 2, 16, w=w, wb=wb, a_group=good, b_group=np.arange(sp.D))
+    for grp in (np.full(sp.D, sp.D + 3), np.roll(np.arange(sp.D), 1), np.where(np.arange(sp.D) == 6, 4, np.arange(sp.D))):
+        with pytest.raises(RuntimeError, match="a_group"):
+            eng.vi_run(lr, loc, rho, 2, 16, w=w, wb=wb, a_group=grp, b_group=np.arange(sp.D))
 
 
 @pytest.mark.parametrize("mname", ["8schools", "radon_PA", "election", "german", "electric"])
