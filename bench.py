@@ -116,22 +116,28 @@ def cpu_baseline(spec, L, n_chains, n_trans, eps0, lanes, inter):
            "sample": "%d chains x %d %s x %d leapfrogs, float32 C oracle (oracle/oracle.c) with OpenMP over chains "
                      "on %d threads, %.1f s" % (n_chains, n_trans, "interleaved steps" if inter else "transitions",
                                                 LL, cores, dt)}
-    # the same port on ONE core (XLA:CPU's elementwise code is effectively single-threaded)
+    # the same port on ONE core (XLA:CPU's elementwise code is effectively single-threaded), in a child
+    # process with OMP_NUM_THREADS=1 -- the thread count of this process (torch's pool included) is left alone
     try:
-        import ctypes
-        omp = ctypes.CDLL("libgomp.so.1")
-        omp.omp_set_num_threads(1)
-        st1 = oracle.new_state(q0[:256], np.float32)
-        n1 = 1024
-        t0 = time.time()
-        if inter:
-            orc.interleaved_run(st1, cp, ncp, eps0, eps0, L, L, n1, seed=1, adapt_kind=2, n_adapt=10 ** 6, lanes=lanes)
-        else:
-            orc.hmc_run(st1, cp[0], cp[1], eps0, L, n1, seed=1, adapt_kind=1, n_adapt=10 ** 6, lanes=lanes)
-        d1 = time.time() - t0
-        omp.omp_set_num_threads(cores)
-        out["single_core"] = {"value": 256 * n1 * LL / d1, "unit": "leapfrog-steps/s", "cores": 1,
-                              "sample": "256 chains x %d steps x %d leapfrogs on one thread, %.1f s" % (n1, LL, d1)}
+        import subprocess
+        code = ("import sys, time, json, numpy as np; sys.path.insert(0, %r)\n"
+                "import oracle\nfrom autoreparam_amd import models\n"
+                "spec = models._spec_radon(%r); orc = oracle.OracleModel(spec)\n"
+                "cp, ncp = spec.ab_from_reparam('CP'), spec.ab_from_reparam('NCP')\n"
+                "q0 = (0.1 * np.random.RandomState(0).randn(256, spec.D)).astype(np.float32)\n"
+                "st = oracle.new_state(q0, np.float32); e = np.asarray(%r, np.float32)\n"
+                "t0 = time.time()\n"
+                "%s\n"
+                "print(json.dumps(time.time() - t0))\n") % (
+                    ROOT, "PA" if spec.D == 71 else "MN", [float(v) for v in eps0],
+                    ("orc.interleaved_run(st, cp, ncp, e, e, %d, %d, 1024, seed=1, adapt_kind=2, n_adapt=10**6, lanes=%d)" % (L, L, lanes))
+                    if inter else
+                    ("orc.hmc_run(st, cp[0], cp[1], e, %d, 1024, seed=1, adapt_kind=1, n_adapt=10**6, lanes=%d)" % (L, lanes)))
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        r1 = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        d1 = float(json.loads(r1.stdout.strip().splitlines()[-1]))
+        out["single_core"] = {"value": 256 * 1024 * LL / d1, "unit": "leapfrog-steps/s", "cores": 1,
+                              "sample": "256 chains x 1024 steps x %d leapfrogs on one thread (child process, OMP_NUM_THREADS=1), %.1f s" % (LL, d1)}
     except Exception as e:
         out["single_core"] = {"value": None, "error": repr(e)}
     return out
