@@ -170,9 +170,6 @@ struct ElectricLane {
         dB[k] = fmaf(og[k], dBv, dB[k]);
       }
       if (LOGP) lp += fmaf(-0.5f * r, r, fmaf(-0.5f * w, Q, -nn * sg));
-      // keep the table reads of the next pairs from being hoisted over this one (they would sit in
-      // registers for the whole pass -- the very registers the LDS table is there to save)
-      if (i & 1) __builtin_amdgcn_sched_barrier(0);
     }
     float pri = 0.0f;
 #pragma unroll

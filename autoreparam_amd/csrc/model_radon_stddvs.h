@@ -33,12 +33,32 @@ struct RadonSdLane {
   static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = false;
   static constexpr bool HAS_VI = true;
-  static constexpr int MINW = 1;
+  static constexpr int MINW = 2;   // waves per SIMD the register allocator must leave room for (the tables are in LDS)
   using Args = RadonSdArgs;
 
-  float n[NLS], sx[NLS], sy[NLS], sxx[NLS], sxy[NLS], syy[NLS], u[NLS], a[NLS];
+  float a[NLS];
   int J, slot;
   bool last_ok;
+
+  // The seven per-county statistics depend on (slot, slice) only, not on the chain: they live in an LDS table shared by
+  // the workgroup (two ds_read_b128 per county and gradient; a wave's 64 lanes read K distinct entries, a broadcast)
+  // instead of 7 NLS registers per lane -- what lets two waves share a SIMD at 8 lanes per chain.
+  //   entry (slice i, slot) = [n sx sy sxx][sxy syy u -]
+  static constexpr int kEntry = 8;
+  static ARP_DEV float* county_table() {
+    __shared__ __attribute__((aligned(16))) float tab[NLS * K * kEntry];
+    return tab;
+  }
+  struct County { float n, sx, sy, sxx, sxy, syy, u; };
+  // the entry's index is laundered: the table is loop invariant, and left to itself the compiler hoists every read out of
+  // the leapfrog loop into registers -- the very registers the table is there to save
+  ARP_DEV County county(int i) const {
+    int e = (i * K + slot) * kEntry;
+    asm volatile("" : "+v"(e));
+    const float4* t = reinterpret_cast<const float4*>(county_table() + e);
+    const float4 p = t[0], r = t[1];
+    return County{p.x, p.y, p.z, p.w, r.x, r.y, r.z};
+  }
 
   static ARP_DEV int gg(int i) { return i; }
   ARP_DEV int lbase(int i) const { return i < NLS ? NG + slot : NG + J + slot; }
@@ -51,14 +71,19 @@ struct RadonSdLane {
     slot = slot_;
     J = A.J;
     last_ok = slot + K * (NLS - 1) < J;
-#pragma unroll
-    for (int i = 0; i < NLS; ++i) {
-      int j = slot + K * i;
-      bool ok = j < J;
-      n[i] = ok ? A.n[j] : 0.0f;  sx[i] = ok ? A.sx[j] : 0.0f;  sy[i] = ok ? A.sy[j] : 0.0f;
-      sxx[i] = ok ? A.sxx[j] : 0.0f;  sxy[i] = ok ? A.sxy[j] : 0.0f;  syy[i] = ok ? A.syy[j] : 0.0f;
-      u[i] = ok ? A.u[j] : 0.0f;
+    float* tab = county_table();
+    __syncthreads();   // a previous user of the table (none inside one kernel) is done
+    if ((int)threadIdx.x < K) {   // the first chain of the workgroup fills the table for everybody
+#pragma unroll 1
+      for (int i = 0; i < NLS; ++i) {
+        const int j = slot + K * i;
+        const bool ok = j < J;
+        float* e = tab + (i * K + slot) * kEntry;
+        e[0] = ok ? A.n[j] : 0.0f;  e[1] = ok ? A.sx[j] : 0.0f;  e[2] = ok ? A.sy[j] : 0.0f;  e[3] = ok ? A.sxx[j] : 0.0f;
+        e[4] = ok ? A.sxy[j] : 0.0f;  e[5] = ok ? A.syy[j] : 0.0f;  e[6] = ok ? A.u[j] : 0.0f;  e[7] = 0.0f;
+      }
     }
+    __syncthreads();
     set_param(av, bv);
   }
   ARP_DEV void set_param(const float* av, const float* /*bv*/) {
@@ -73,23 +98,25 @@ struct RadonSdLane {
 #pragma unroll
     for (int i = 0; i < NLS; ++i) {
       const float mt = q[NG + i], s = q[NG + NLS + i];
-      const float mu = fmaf(u[i], b1, mua);
+      const County c_ = county(i);
+      const float n_i = c_.n, sx_i = c_.sx, sy_i = c_.sy, sxx_i = c_.sxx, sxy_i = c_.sxy, syy_i = c_.syy, u_i = c_.u;
+      const float mu = fmaf(u_i, b1, mua);
       const float r = fmaf(-a[i], mu, mt);
       const float m = r + mu;
       const float w = fast_exp(-2.0f * s);
-      const float t = fmaf(-b2, sx[i], sy[i]);
-      const float resid = fmaf(-n[i], m, t);
-      const float c = fmaf(b2, fmaf(b2, sxx[i], -2.0f * sxy[i]), syy[i]);
+      const float t = fmaf(-b2, sx_i, sy_i);
+      const float resid = fmaf(-n_i, m, t);
+      const float c = fmaf(b2, fmaf(b2, sxx_i, -2.0f * sxy_i), syy_i);
       const float Q = fmaf(-m, resid + t, c);
       const float l = w * resid;                       // d loglik / d m
       const float gm = l - r;
       g[NG + i] = gm;
-      g[NG + NLS + i] = fmaf(w, Q, -n[i]) - s;          // padding: n = Q = s = 0
+      g[NG + NLS + i] = fmaf(w, Q, -n_i) - s;          // padding: n = Q = s = 0
       const float h = fmaf(-a[i], gm, l);
       acc_h += h;
-      acc_uh = fmaf(u[i], h, acc_uh);
-      acc_b2 = fmaf(w, fmaf(-b2, sxx[i], fmaf(-m, sx[i], sxy[i])), acc_b2);
-      if (LOGP) lp += fmaf(-0.5f * r, r, fmaf(-0.5f * w, Q, fmaf(-n[i], s, -0.5f * s * s)));
+      acc_uh = fmaf(u_i, h, acc_uh);
+      acc_b2 = fmaf(w, fmaf(-b2, sxx_i, fmaf(-m, sx_i, sxy_i)), acc_b2);
+      if (LOGP) lp += fmaf(-0.5f * r, r, fmaf(-0.5f * w, Q, fmaf(-n_i, s, -0.5f * s * s)));
     }
     acc_h = group_sum<K>(acc_h);
     acc_uh = group_sum<K>(acc_uh);
@@ -105,7 +132,7 @@ struct RadonSdLane {
 #pragma unroll
     for (int i = 0; i < ND; ++i) { da[i] = 0.0f; db[i] = 0.0f; }
 #pragma unroll
-    for (int i = 0; i < NLS; ++i) da[NG + i] = -fmaf(u[i], q[1], q[0]) * g[NG + i];
+    for (int i = 0; i < NLS; ++i) da[NG + i] = -fmaf(county(i).u, q[1], q[0]) * g[NG + i];
   }
 
   ARP_DEV void to_centered(const float (&q)[ND], float (&x)[ND]) const {
@@ -113,7 +140,7 @@ struct RadonSdLane {
     for (int i = 0; i < ND; ++i) x[i] = q[i];
 #pragma unroll
     for (int i = 0; i < NLS; ++i) {
-      float mu = fmaf(u[i], q[1], q[0]);
+      float mu = fmaf(county(i).u, q[1], q[0]);
       x[NG + i] = fmaf(-a[i], mu, q[NG + i]) + mu;
     }
   }
@@ -122,7 +149,7 @@ struct RadonSdLane {
     for (int i = 0; i < ND; ++i) q[i] = x[i];
 #pragma unroll
     for (int i = 0; i < NLS; ++i) {
-      float mu = fmaf(u[i], x[1], x[0]);
+      float mu = fmaf(county(i).u, x[1], x[0]);
       q[NG + i] = lvalid(i) ? x[NG + i] - (1.0f - a[i]) * mu : 0.0f;
       q[NG + NLS + i] = lvalid(i) ? x[NG + NLS + i] : 0.0f;
     }

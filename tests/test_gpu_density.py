@@ -10,7 +10,7 @@ import helpers
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "density_golden.npz")
 MODELS = ["8schools", "radon_MN", "radon_PA", "election", "german", "radon_sd_MN", "funnel", "electric", "time_series"]
-LANES = {"8schools": [1, 2, 4, 8], "radon_MN": [4, 8, 16], "radon_PA": [4, 8, 16], "election": [4, 8, 16], "german": [4, 8, 16], "radon_sd_MN": [8, 16], "funnel": [1], "electric": [16], "time_series": [4]}
+LANES = {"8schools": [1, 2, 4, 8], "radon_MN": [4, 8, 16], "radon_PA": [4, 8, 16], "election": [4, 8, 16], "german": [4, 8, 16], "radon_sd_MN": [8, 16], "funnel": [1], "electric": [8, 16], "time_series": [4]}
 
 
 @pytest.fixture(scope="module")

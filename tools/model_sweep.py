@@ -32,7 +32,8 @@ def main():
     only = sys.argv[1:]
     if only:   # e.g. `model_sweep.py electric radon_stddvs`
         if "electric" in only:
-            run("electric", models._spec_electric(), 65536, 8, 16, "NCP", eps=0.01)
+            for lanes in (8, 16):
+                run("electric", models._spec_electric(), 65536, 8, lanes, "NCP", eps=0.01)
             run("electric", models._spec_electric(), 16384, 8, 16, "NCP", eps=0.01)
         if "election" in only:
             for rep in ("NCP", "CP", "VIP"):
