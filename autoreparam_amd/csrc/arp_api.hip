@@ -15,13 +15,15 @@ static const double kHalfLog2Pi = 0.9189385332046727;
 
 // pick the instantiation: requested lanes-per-chain (or a default from the chain
 // count) and the smallest slice size that covers `groups`.
-// `exact`: the family needs NL == ceil(groups / K) (only a lane's last slice may be padding).
+// `exact`: the family needs NL == ceil(groups / K), rounded up to a multiple of `unit` (only a lane's last slice may be
+// padding; time_series: a lane owns whole time steps, unit = 2) -- the random-stream partition depends on it.
 static const LaneOps* pick(const std::vector<LaneOps>& ops, int groups, int K_req, int C, bool exact,
-                           long long fill_lanes = 131072) {
+                           long long fill_lanes = 131072, int unit = 1) {
   auto best_for = [&](int K) -> const LaneOps* {
     const LaneOps* best = nullptr;
+    const int need = ((groups + K - 1) / K + unit - 1) / unit * unit;
     for (const auto& o : ops)
-      if (o.K == K && (long long)o.NL * K >= groups && (!exact || (o.NL - 1) * K < groups) &&
+      if (o.K == K && (long long)o.NL * K >= groups && (!exact || o.NL == need) &&
           (!best || o.NL < best->NL)) best = &o;
     return best;
   };
@@ -299,9 +301,9 @@ static int build_electric(arp_model* m, const arp_dataset* d) {
 static int build_time_series(arp_model* m, const arp_dataset* d) {
   const int T = d->n_obs;
   if (!d->x_host || !d->y_host || T <= 0) { set_error("time_series: x, y and n_obs are required"); return 1; }
-  // the block scan splits the T steps evenly over the 4 lanes of a chain; the one instantiation
-  // (inst_time_series.hip) holds 15 steps per lane, the reference's T = 60
-  if (T != 60) { set_error("time_series: n_obs must be 60 (add TimeSeriesLane<4, T/2> to inst_time_series.hip for another length)"); return 1; }
+  // the block scan splits the T steps over the lanes of a chain in blocks of ceil(T / K) (the last lanes padded); the
+  // instantiations of inst_time_series.hip are those of the reference's T = 60
+  if (T != kTsSteps) { set_error("time_series: n_obs must be 60 (add TimeSeriesLane<K, 2 ceil(T / K)> to inst_time_series.hip for another length)"); return 1; }
   m->D = 3 + 2 * T; m->n_groups = 2 * T;
   m->host_tables.assign(d->x_host, d->x_host + T);
   m->host_tables.insert(m->host_tables.end(), d->y_host, d->y_host + T);
@@ -421,10 +423,14 @@ static const LaneOps* select_ops(arp_model* m, int K_req, int C) {
   // german credit: the 4-lane instantiation runs its likelihood on the matrix cores and beats the
   // wider ones at every chain count (per workgroup 4x the 8-lane and 17x the 16-lane rate)
   if (K_req == 0 && m->model == ARP_MODEL_GERMAN_CREDIT) K_req = 4;
+  // local linear trend: 8 lanes per chain (two waves per SIMD) beat 4 (one wave, 500+ registers) at every chain count
+  // that fills the device (tools/model_sweep.py time_series: 1.50 vs 1.57 ms at 65 536 chains); 16 below that
+  if (K_req == 0 && m->model == ARP_MODEL_TIME_SERIES) K_req = (long long)C * 8 >= 131072 ? 8 : 16;
   // radon: a wider split costs more replicated work than a second wave per SIMD returns (bench.py --chains 8192:
   // 1.21e10 leapfrog-steps/s at 8 lanes per chain, 1.07e10 at 16), so one wave per SIMD is enough
   const long long fill = m->model == ARP_MODEL_RADON ? 65536 : 131072;
-  const LaneOps* o = pick(*fam, m->n_groups, K_req, C, m->model != ARP_MODEL_GERMAN_CREDIT, fill);
+  const LaneOps* o = pick(*fam, m->n_groups, K_req, C, m->model != ARP_MODEL_GERMAN_CREDIT, fill,
+                          m->model == ARP_MODEL_TIME_SERIES ? 2 : 1);
   if (!o) set_error("no kernel instantiation for this (lanes_per_chain, group count): add <Model>Lane<K, ceil(groups/K)> to the model's inst_*.hip");
   return o;
 }
@@ -569,7 +575,8 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   int Kmax = 0;
   for (const auto& o : *fam) if (o.vi) Kmax = std::max(Kmax, o.K);
   if (m->model == ARP_MODEL_GERMAN_CREDIT) Kmax = 4;
-  const LaneOps* o = pick(*fam, m->n_groups, Kmax, 1 << 30, m->model != ARP_MODEL_GERMAN_CREDIT);
+  const LaneOps* o = pick(*fam, m->n_groups, Kmax, 1 << 30, m->model != ARP_MODEL_GERMAN_CREDIT, 131072,
+                          m->model == ARP_MODEL_TIME_SERIES ? 2 : 1);
   if (!o || !o->vi) { set_error("no VI kernel instantiation covers this group count"); return 1; }
   ViParams P;
   P.n_steps = cfg->n_steps; P.n_mc = cfg->n_mc; P.learn_a = cfg->learn_a; P.tied_b = cfg->tied_b; P.a_prior = cfg->a_prior; P.D = m->D;

@@ -8,20 +8,28 @@
 //   mu_t ~ N(mu_{t-1}, Sm) (mu_{-1} = 0):  mt_t likewise with (a', b', c', f')
 //   y_t ~ N(alpha_t + beta x_t, 0.12)
 //
-// The centred values form a chain in t, so the K = 4 lanes of a chain own consecutive blocks of
-// B = T/4 time steps and the two recurrences are block scans:
+// The centred values form a chain in t, so the K lanes of a chain own consecutive blocks of B time steps
+// (K B >= T; steps beyond T are padding that carries no latent, no observation and a = b = 0) and the two
+// recurrences are block scans:
 //   forward   (alpha, mu)_t = [[f, f], [0, f']] (alpha, mu)_{t-1} + (c at_t, c' mt_t)
 //   backward  with e_t = d loglik / d alpha_t, z = (at - a m) / Sa^b and the messages
 //             G_t = d logp / d m_t, H_t = d logp / d mu_{t-1} (through mu_t's prior):
 //             Abar_t = e_t + G_{t+1},  Mbar_t = G_{t+1} + H_{t+1},
 //             G_t = f Abar_t + a z / Sa^b,  H_t = f' Mbar_t + a' z' / Sm^b'
 // Both are affine in the incoming pair, so a lane first runs its block with a zero input while
-// composing the block's 2x2 (triangular) map, the three block maps are chained across the quad
-// with DPP broadcasts, and the lane reruns its block with the right input.
+// composing the block's 2x2 (triangular) map, the chain's value is rippled through the block maps
+// lane by lane (K - 1 rounds of DPP row shifts, masked at the chain's ends so that a chain never
+// reads a neighbour's values; no map is multiplied into another, which would cost accuracy), and
+// the lane reruns its block with the right input.
+//
+// Lanes per chain: 8 (B = 8, T = 60 padded to 64) keeps a lane at ~200 registers, two waves per
+// SIMD; 4 (B = 15) needs more than 256 and runs one wave per SIMD (round 2's only form).
 #pragma once
 #include "arp_device.h"
 
 namespace arp {
+
+constexpr int kTsSteps = 60;   // the reference's series length: the only T the host accepts (arp_api.hip: build_time_series)
 
 struct TimeSeriesArgs {
   const float* x;   // [T] regressor (years)
@@ -31,7 +39,8 @@ struct TimeSeriesArgs {
 
 template <int K_, int NL_>
 struct TimeSeriesLane {
-  static_assert(K_ == 4, "the block scan is written for the four lanes of a quad");
+  static_assert(K_ == 4 || K_ == 8 || K_ == 16, "a chain is 4, 8 or 16 lanes of one DPP row");
+  static_assert(NL_ % 2 == 0, "a lane owns whole time steps");
   static constexpr int K = K_;
   static constexpr int NG = 3;          // sigma_alpha, sigma_mu, beta
   static constexpr int NL = NL_;        // trend latents owned by this lane: (alpha, mu) of B consecutive steps
@@ -43,10 +52,11 @@ struct TimeSeriesLane {
   static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = false;
   static constexpr bool HAS_VI = true;
-  static constexpr int MINW = 1;   // waves per SIMD the register allocator must leave room for
+  static constexpr int MINW = NL_ <= 16 ? 2 : 1;   // waves per SIMD the register allocator must leave room for
   using Args = TimeSeriesArgs;
 
   float xt[B], yt[B], aA[B], bA[B], aM[B], bM[B];
+  ARP_DEV bool real_step(int tl) const { return !PADDED || slot * B + tl < T; }
   int slot, T;
 
   // flattened indices: the lane's latents are one consecutive run; beta sits behind all of them
@@ -54,28 +64,43 @@ struct TimeSeriesLane {
   ARP_DEV int lbase(int) const { return 2 + slot * NL; }
   static constexpr ARP_DEV int loff(int i) { return i; }
   ARP_DEV int lidx(int i) const { return 2 + slot * NL + i; }
-  ARP_DEV bool lvalid(int) const { return true; }   // the host only accepts T == K * B
+  static constexpr bool PADDED = K_ * B > kTsSteps;   // the last lanes own steps beyond T
+  ARP_DEV bool lvalid(int i) const { return PADDED ? slot * NL + i < 2 * T : true; }
 
   ARP_DEV void init(const Args& A, const float* av, const float* bv, int slot_) {
     slot = slot_;
     T = A.T;
 #pragma unroll
-    for (int tl = 0; tl < B; ++tl) { xt[tl] = A.x[slot * B + tl]; yt[tl] = A.y[slot * B + tl]; }
+    for (int tl = 0; tl < B; ++tl) {
+      const int t = slot * B + tl;
+      xt[tl] = real_step(tl) ? A.x[t] : 0.0f; yt[tl] = real_step(tl) ? A.y[t] : 0.0f;
+    }
     set_param(av, bv);
   }
   ARP_DEV void set_param(const float* av, const float* bv) {
 #pragma unroll
     for (int tl = 0; tl < B; ++tl) {
       const int i = 2 + slot * NL + 2 * tl;
-      aA[tl] = av[i]; bA[tl] = bv[i]; aM[tl] = av[i + 1]; bM[tl] = bv[i + 1];
+      const bool ok = real_step(tl);
+      aA[tl] = ok ? av[i] : 0.0f; bA[tl] = ok ? bv[i] : 0.0f; aM[tl] = ok ? av[i + 1] : 0.0f; bM[tl] = ok ? bv[i + 1] : 0.0f;
     }
   }
 
-  // value held by slot S of the chain's quad, in every lane
-  template <int S>
-  static ARP_DEV float from_slot(float v) { return dpp_mov<S | (S << 2) | (S << 4) | (S << 6)>(v); }
-  // value held by the previous slot (slot 0 receives its own; callers mask it)
-  static ARP_DEV float from_prev(float v) { return dpp_mov<0x90>(v); }   // quad_perm [0,0,1,2]
+  // Value held by the lane D slots EARLIER in the chain; `old` where the chain has no such lane (a row shift of the DPP
+  // row of 16 lanes, then a select on the slot).
+  template <int D>
+  ARP_DEV float from_earlier(float old, float v) const {
+    static_assert(D == 1, "row_shr:1; a wider shift would want a bank mask instead of the select");
+    const float r = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x110 + D, 0xF, 0xF, false));
+    return slot >= D ? r : old;
+  }
+  // ... D slots LATER in the chain
+  template <int D>
+  ARP_DEV float from_later(float old, float v) const {
+    static_assert(D == 1, "row_shl:1");
+    const float r = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x100 + D, 0xF, 0xF, false));
+    return slot + D < K ? r : old;
+  }
 
   struct Scales { float Sa, Sm, lSa, lSm; };
   ARP_DEV Scales scales(float sa, float sm) const {
@@ -100,14 +125,14 @@ struct TimeSeriesLane {
       da = fmaf(fA, da + dm, cA * q[NG + 2 * tl]);
       dm = fmaf(fM, dm, cM * q[NG + 2 * tl + 1]);
     }
-    // chain the maps of slots 0, 1, 2: the input of slot s is the output of slots 0 .. s-1 applied to (0, 0)
-    const float a1 = from_slot<0>(da), m1 = from_slot<0>(dm);
-    const float a2 = fmaf(from_slot<1>(p11), a1, fmaf(from_slot<1>(p12), m1, from_slot<1>(da)));
-    const float m2 = fmaf(from_slot<1>(p22), m1, from_slot<1>(dm));
-    const float a3 = fmaf(from_slot<2>(p11), a2, fmaf(from_slot<2>(p12), m2, from_slot<2>(da)));
-    const float m3 = fmaf(from_slot<2>(p22), m2, from_slot<2>(dm));
-    float ap = slot == 0 ? 0.0f : (slot == 1 ? a1 : (slot == 2 ? a2 : a3));
-    float mp = slot == 0 ? 0.0f : (slot == 1 ? m1 : (slot == 2 ? m2 : m3));
+    // ripple the chain's value through the block maps: after j rounds the lanes 0 .. j hold their true input (the output
+    // of the lane before them; (0, 0) for the first), K - 1 rounds of three FMAs and two row shifts
+    float ap = 0.0f, mp = 0.0f;
+#pragma unroll
+    for (int j = 1; j < K; ++j) {
+      const float ao = fmaf(p11, ap, fmaf(p12, mp, da)), mo = fmaf(p22, mp, dm);
+      ap = from_earlier<1>(0.0f, ao); mp = from_earlier<1>(0.0f, mo);
+    }
     // pass 2: the block with its real input
 #pragma unroll
     for (int tl = 0; tl < B; ++tl) {
@@ -121,8 +146,7 @@ struct TimeSeriesLane {
 
   // (alpha, mu) at the step before this lane's first (zero for slot 0)
   ARP_DEV void incoming(const float (&al)[B], const float (&mu)[B], float& ap, float& mp) const {
-    ap = from_prev(al[B - 1]); mp = from_prev(mu[B - 1]);
-    ap = slot == 0 ? 0.0f : ap; mp = slot == 0 ? 0.0f : mp;
+    ap = from_earlier<1>(0.0f, al[B - 1]); mp = from_earlier<1>(0.0f, mu[B - 1]);
   }
 
   template <bool LOGP>
@@ -140,7 +164,7 @@ struct TimeSeriesLane {
     for (int tl = 0; tl < B; ++tl) {
       const float mA = ap + mp, alpha = al[tl], mut = mu[tl];
       const float res = (yt[tl] - alpha) - beta * xt[tl];
-      e[tl] = res * s2i;
+      e[tl] = real_step(tl) ? res * s2i : 0.0f;   // a padding step has no observation
       g_beta = fmaf(e[tl], xt[tl], g_beta);
       const float zA = fmaf(-aA[tl], mA, q[NG + 2 * tl]) * eA[tl];
       const float zM = fmaf(-aM[tl], mp, q[NG + 2 * tl + 1]) * eM[tl];
@@ -160,14 +184,13 @@ struct TimeSeriesLane {
       oG = fmaf(fA, e[tl] + oG, kA);
       oH = nH;
     }
-    // chain from the last slot down: the input of slot s is the output of slots 3 .. s+1 applied to (0, 0)
-    const float G2 = from_slot<3>(oG), H2 = from_slot<3>(oH);
-    const float G1 = fmaf(from_slot<2>(r11), G2, from_slot<2>(oG));
-    const float H1 = fmaf(from_slot<2>(r21), G2, fmaf(from_slot<2>(r22), H2, from_slot<2>(oH)));
-    const float G0 = fmaf(from_slot<1>(r11), G1, from_slot<1>(oG));
-    const float H0 = fmaf(from_slot<1>(r21), G1, fmaf(from_slot<1>(r22), H1, from_slot<1>(oH)));
-    float G = slot == 3 ? 0.0f : (slot == 2 ? G2 : (slot == 1 ? G1 : G0));
-    float H = slot == 3 ? 0.0f : (slot == 2 ? H2 : (slot == 1 ? H1 : H0));
+    // the same ripple from the chain's end: a lane's input is the output of the lane after it, (0, 0) for the last
+    float G = 0.0f, H = 0.0f;
+#pragma unroll
+    for (int j = 1; j < K; ++j) {
+      const float Go = fmaf(r11, G, oG), Ho = fmaf(r21, G, fmaf(r22, H, oH));
+      G = from_later<1>(0.0f, Go); H = from_later<1>(0.0f, Ho);
+    }
     // backward pass 2: gradients
     float g_lSa = 0.0f, g_lSm = 0.0f;
 #pragma unroll
@@ -206,8 +229,9 @@ struct TimeSeriesLane {
       const float mA = ap + mp;
       da[NG + 2 * tl] = -mA * g[NG + 2 * tl];
       da[NG + 2 * tl + 1] = -mp * g[NG + 2 * tl + 1];
-      db[NG + 2 * tl] = -S.lSa * fmaf(fmaf(-aA[tl], mA, q[NG + 2 * tl]), g[NG + 2 * tl], 1.0f);
-      db[NG + 2 * tl + 1] = -S.lSm * fmaf(fmaf(-aM[tl], mp, q[NG + 2 * tl + 1]), g[NG + 2 * tl + 1], 1.0f);
+      const bool ok = real_step(tl);
+      db[NG + 2 * tl] = ok ? -S.lSa * fmaf(fmaf(-aA[tl], mA, q[NG + 2 * tl]), g[NG + 2 * tl], 1.0f) : 0.0f;
+      db[NG + 2 * tl + 1] = ok ? -S.lSm * fmaf(fmaf(-aM[tl], mp, q[NG + 2 * tl + 1]), g[NG + 2 * tl + 1], 1.0f) : 0.0f;
       ap = al[tl]; mp = mu[tl];
     }
   }
@@ -224,13 +248,13 @@ struct TimeSeriesLane {
     const Scales S = scales(x[0], x[1]);
     q[0] = x[0]; q[1] = x[1]; q[2] = x[2];
     // every location is a centred value: only the step before the lane's first comes from the neighbour
-    float ap = from_prev(x[NG + NL - 2]), mp = from_prev(x[NG + NL - 1]);
-    ap = slot == 0 ? 0.0f : ap; mp = slot == 0 ? 0.0f : mp;
+    float ap = from_earlier<1>(0.0f, x[NG + NL - 2]), mp = from_earlier<1>(0.0f, x[NG + NL - 1]);
 #pragma unroll
     for (int tl = 0; tl < B; ++tl) {
       const float mA = ap + mp;
-      q[NG + 2 * tl] = fmaf(x[NG + 2 * tl] - mA, fast_exp(-(1.0f - bA[tl]) * S.lSa), aA[tl] * mA);
-      q[NG + 2 * tl + 1] = fmaf(x[NG + 2 * tl + 1] - mp, fast_exp(-(1.0f - bM[tl]) * S.lSm), aM[tl] * mp);
+      const bool ok = real_step(tl);   // padding steps stay 0
+      q[NG + 2 * tl] = ok ? fmaf(x[NG + 2 * tl] - mA, fast_exp(-(1.0f - bA[tl]) * S.lSa), aA[tl] * mA) : 0.0f;
+      q[NG + 2 * tl + 1] = ok ? fmaf(x[NG + 2 * tl + 1] - mp, fast_exp(-(1.0f - bM[tl]) * S.lSm), aM[tl] * mp) : 0.0f;
       ap = x[NG + 2 * tl]; mp = x[NG + 2 * tl + 1];
     }
   }

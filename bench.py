@@ -533,16 +533,16 @@ def main():
         time_model("config2_radon_MN_CP_4096", mn, "CP", 4096, 4, 256, 0.05, radon_flop_per_leapfrog(Jm, mn.D),
                    "BASELINE configs[1]: 4 096 chains fill a quarter of the lanes a 256-CU device wants (16 lanes per chain: one wave per SIMD)")
         time_model("radon_MN_CP_65536", mn, "CP", 65536, 4, 64, 0.05, radon_flop_per_leapfrog(Jm, mn.D),
-                   "4 lanes per chain, 22 counties per lane: the packed kernel spills 4 - 21 values (DESIGN.md section 9)")
+                   "4 lanes per chain, 22 counties per lane (the packed kernel spills 3 - 21 values, about 1 % of its instructions)")
         sd = models._spec_radon_stddvs("MN")
         time_model("radon_stddvs_MN_NCP_65536", sd, "NCP", 65536, 8, 16, 0.01, 45.0 * Jm + 20.0 + 4.0 * sd.D,
-                   "per county 6 sufficient statistics and one exp: ~45 flop per county and gradient")
+                   "per county 6 sufficient statistics and one exp: ~45 flop per county and gradient; 8 lanes per chain, county tables in LDS, two waves per SIMD")
         el = models._spec_electric()
         time_model("electric_NCP_65536", el, "NCP", 65536, 8, 16, 0.01, 97 * 60.0 + 12 * 10.0 + 4.0 * el.D,
-                   "97 groups x ~60 flop (two cells, one-hot grade look-ups as 12 FMAs, one exp) + 12 grade scalars")
+                   "97 groups x ~60 flop (two cells, one-hot grade look-ups as 12 FMAs, one exp) + 12 grade scalars; 8 lanes per chain, tables in LDS")
         ts = models._spec_time_series()
         time_model("time_series_NCP_65536", ts, "NCP", 65536, 8, 16, 0.05, 60 * 80.0 + 4.0 * ts.D,
-                   "60 time steps x ~80 flop (centring recurrence and its adjoint as block scans); one wave per SIMD")
+                   "60 time steps x ~80 flop (centring recurrence and its adjoint as block scans); 8 lanes per chain (T padded to 64), two waves per SIMD")
         extras["other_models"] = others
 
     # arp_ess on its own: the [S, C, D] trace of a sampling run at the headline size (1 000 recorded samples = 18.6 GB),

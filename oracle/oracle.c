@@ -27,6 +27,8 @@ typedef struct orc_model {
   int n_groups;    /* sliced axis length (RNG stream layout) */
   int n_local_parts; /* latent parts sliced along that axis (german: beta_log_scales and beta) */
   int contig;      /* 1: slot s owns consecutive elements s*per_lane + i (german); 0: s + lanes*i */
+  int lane_unit;   /* elements per lane come in whole units of this many (0 or 1: none; time_series: 2, a lane owns whole
+                    * (alpha_t, mu_t) time steps, so per_lane = ceil(n_groups / lanes) rounded up to even) */
   int mom_spec;    /* momentum stream layout: 0 = top-level scalars first, drawn by every slot, slot 0's used;
                     * 1 = sliced elements first, then ceil(n_glob / lanes) extra normals per slot of which extra x of
                     * slot s is top-level scalar s + lanes*x (radon: no slot draws a normal it discards) */
@@ -262,7 +264,7 @@ orc_model* orc_time_series_create(int T, const float* x, const float* y) {
   M->model = 7; M->N = T; M->D = 3 + 2 * T;
   /* RNG stream layout: sigma_alpha, sigma_mu, beta are replicated; the 2T trend latents are one
    * part sliced in consecutive runs (slot s owns elements s*per_lane .. (s+1)*per_lane-1) */
-  M->n_glob = 3; M->n_groups = 2 * T; M->n_local_parts = 1; M->contig = 1;
+  M->n_glob = 3; M->n_groups = 2 * T; M->n_local_parts = 1; M->contig = 1; M->lane_unit = 2;
   M->glob_idx[0] = 0; M->glob_idx[1] = 1; M->glob_idx[2] = 2 + 2 * T;
   M->group_idx = (int*)malloc(sizeof(int) * 2 * T);
   for (int j = 0; j < 2 * T; ++j) M->group_idx[j] = 2 + j;
@@ -296,6 +298,13 @@ void orc_model_destroy(orc_model* M) {
 }
 int orc_model_dim(const orc_model* M) { return M->D; }
 double orc_model_logp_const(const orc_model* M) { return M->logp_const; }
+
+/* elements of the sliced axis a slot owns (the RNG stream partition of draw_momentum and the VI draws) */
+static int orc_per_lane(const orc_model* M, int lanes) {
+  int per_lane = (M->n_groups + lanes - 1) / lanes;
+  if (M->lane_unit > 1) per_lane = (per_lane + M->lane_unit - 1) / M->lane_unit * M->lane_unit;
+  return per_lane;
+}
 
 #define REAL float
 #define FN(x) x##_f32

@@ -532,7 +532,7 @@ int FN(orc_transform)(const orc_model* M, const float* a, const float* b, int di
  * ---------------------------------------------------------------------- */
 static void FN(draw_momentum)(const orc_model* M, orc_rng* streams, int lanes, REAL* p, REAL* u_out) {
   const int NG = M->n_glob, G = M->n_groups, P = M->n_local_parts;
-  const int per_lane = (G + lanes - 1) / lanes;
+  const int per_lane = orc_per_lane(M, lanes);
   const int spec1 = M->mom_spec == 1;
   const int extra = spec1 ? (NG + lanes - 1) / lanes : 0;
   /* normals every slot draws.  layout 0: scalars, then part by part; layout 1: the slices, then `extra` scalars */
@@ -882,7 +882,7 @@ int FN(orc_vi_run)(const orc_model* M, const float* a_in, const float* b_in, int
                    REAL* prior_out) {
   const int learn_a = learn_a_flags & 1, a_prior = (learn_a_flags >> 1) & 1;
   const int D = M->D, NG = M->n_glob, G = M->n_groups, P = M->n_local_parts;
-  const int per_lane = (G + lanes - 1) / lanes, nd = NG + P * per_lane;
+  const int per_lane = orc_per_lane(M, lanes), nd = NG + P * per_lane;
   const int cpp = block / lanes, passes = (n_mc + cpp - 1) / cpp;
   for (int li = 0; li < n_lr; ++li) {
     REAL* loc = loc_io + (size_t)li * D; REAL* rho = rho_io + (size_t)li * D;

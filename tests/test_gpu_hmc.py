@@ -9,7 +9,7 @@ import helpers
 import parity
 
 pytestmark = pytest.mark.gpu
-LANES = {"8schools": [1, 8], "radon_MN": [4, 8, 16], "radon_PA": [4, 8, 16], "election": [4, 8, 16], "german": [4, 8, 16], "radon_sd_MN": [8, 16], "funnel": [1], "electric": [8, 16], "time_series": [4]}
+LANES = {"8schools": [1, 8], "radon_MN": [4, 8, 16], "radon_PA": [4, 8, 16], "election": [4, 8, 16], "german": [4, 8, 16], "radon_sd_MN": [8, 16], "funnel": [1], "electric": [8, 16], "time_series": [4, 8, 16]}
 
 
 def _eng(mname, gpu):

@@ -7,7 +7,7 @@ import torch
 import helpers
 
 pytestmark = pytest.mark.gpu
-VI_LANES = {"8schools": 8, "radon_MN": 16, "election": 16, "german": 4, "radon_sd_MN": 16, "funnel": 1, "electric": 16, "time_series": 4}
+VI_LANES = {"8schools": 8, "radon_MN": 16, "election": 16, "german": 4, "radon_sd_MN": 16, "funnel": 1, "electric": 16, "time_series": 16}
 
 
 @pytest.mark.parametrize("mname", ["8schools", "radon_MN", "election", "german", "radon_sd_MN", "funnel", "electric", "time_series"])

@@ -43,7 +43,8 @@ def main():
             for lanes in (4, 8, 16):
                 run("german", models._spec_german(), 16384, 4, lanes, "NCP", T=4, eps=0.005)
         if "time_series" in only:
-            run("time_series", models._spec_time_series(), 65536, 8, 4, "NCP", eps=0.05)
+            for lanes in (4, 8, 16):
+                run("time_series", models._spec_time_series(), 65536, 8, lanes, "NCP", eps=0.05)
         if "radon_stddvs" in only:
             for lanes in (8, 16):
                 run("radon_sd", models._spec_radon_stddvs("MN"), 65536, 8, lanes, "NCP", eps=0.01)
