@@ -423,12 +423,11 @@ static const LaneOps* select_ops(arp_model* m, int K_req, int C) {
   // german credit: the 4-lane instantiation runs its likelihood on the matrix cores and beats the
   // wider ones at every chain count (per workgroup 4x the 8-lane and 17x the 16-lane rate)
   if (K_req == 0 && m->model == ARP_MODEL_GERMAN_CREDIT) K_req = 4;
-  // local linear trend: 8 lanes per chain (two waves per SIMD) beat 4 (one wave, 500+ registers) at every chain count
-  // that fills the device (tools/model_sweep.py time_series: 1.50 vs 1.57 ms at 65 536 chains); 16 below that
-  if (K_req == 0 && m->model == ARP_MODEL_TIME_SERIES) K_req = (long long)C * 8 >= 131072 ? 8 : 16;
   // radon: a wider split costs more replicated work than a second wave per SIMD returns (bench.py --chains 8192:
   // 1.21e10 leapfrog-steps/s at 8 lanes per chain, 1.07e10 at 16), so one wave per SIMD is enough
-  const long long fill = m->model == ARP_MODEL_RADON ? 65536 : 131072;
+  // time_series likewise: 4 lanes per chain (one wave per SIMD at 16 384 chains) beat 8 and 16 in every form wherever
+  // they fill the SIMDs once (round 3 sweep, profiles/r03_time_series_sweep.txt)
+  const long long fill = (m->model == ARP_MODEL_RADON || m->model == ARP_MODEL_TIME_SERIES) ? 65536 : 131072;
   const LaneOps* o = pick(*fam, m->n_groups, K_req, C, m->model != ARP_MODEL_GERMAN_CREDIT, fill,
                           m->model == ARP_MODEL_TIME_SERIES ? 2 : 1);
   if (!o) set_error("no kernel instantiation for this (lanes_per_chain, group count): add <Model>Lane<K, ceil(groups/K)> to the model's inst_*.hip");

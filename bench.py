@@ -542,7 +542,7 @@ def main():
                    "97 groups x ~60 flop (two cells, one-hot grade look-ups as 12 FMAs, one exp) + 12 grade scalars; 8 lanes per chain, tables in LDS")
         ts = models._spec_time_series()
         time_model("time_series_NCP_65536", ts, "NCP", 65536, 8, 16, 0.05, 60 * 80.0 + 4.0 * ts.D,
-                   "60 time steps x ~80 flop (centring recurrence and its adjoint as block scans); 8 lanes per chain (T padded to 64), two waves per SIMD")
+                   "60 time steps x ~80 flop of the general form (centring recurrence and its adjoint as block scans); the run takes the compile-time non-centred form (no per-step exp, unit block maps), 4 lanes per chain")
         extras["other_models"] = others
 
     # arp_ess on its own: the [S, C, D] trace of a sampling run at the headline size (1 000 recorded samples = 18.6 GB),

@@ -110,10 +110,10 @@ def test_german_trajectories_on_one_three_and_five_tiles(oracle_lib, gpu, n_obs)
     assert np.array_equal(r["ta"][:, ok], r["tao"][:, ok])
 
 
-@pytest.mark.parametrize("mname", ["election", "radon_PA", "german"])
+@pytest.mark.parametrize("mname", ["election", "radon_PA", "german", "time_series"])
 def test_trajectories_match_oracle_b_equal_one(oracle_lib, gpu, mname):
-    """a free, b = 1 (the parameterisation tied cVIP / dVIP runs execute): election has a compile-time form
-    for it, the other models take the general path; both against the oracle."""
+    """a free, b = 1 (the parameterisation tied cVIP / dVIP runs execute): election and time_series have a
+    compile-time form for it, the other models take the general path; both against the oracle."""
     for lanes in LANES[mname]:
         r = _compare(oracle_lib, gpu, mname, "B1", lanes, 0, 0.05, 4, 12)
         ok = r["clean"]
