@@ -7,7 +7,7 @@ import numpy as np, torch
 import helpers
 from autoreparam_amd import engine, _lib
 LANES = {"8schools": [1, 2, 4, 8], "radon_MN": [4, 8, 16], "radon_PA": [4, 8, 16], "election": [4, 8, 16],
-         "german": [4, 8, 16], "radon_sd_MN": [8, 16], "funnel": [1], "electric": [16], "time_series": [4]}
+         "german": [4, 8, 16], "radon_sd_MN": [8, 16], "funnel": [1], "electric": [8, 16], "time_series": [4, 8, 16]}
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
 t0 = time.time(); n = 0
@@ -18,7 +18,7 @@ while time.time() - t0 < budget:
     C = int(rs.choice([1, 3, 17, 63, 64, 65, 257, 1000, 4097, 20000]))
     if m == "german": C = min(C, 4097)
     lanes = int(rs.choice(LANES[m]))
-    kind = ["CP", "NCP", "VIP"][rs.randint(3)]
+    kind = ["CP", "NCP", "VIP", "B1"][rs.randint(4)]
     eng.set_param(0, helpers.params(sp, kind, seed=rs.randint(100)))
     eng.set_param(1, helpers.params(sp, "NCP"))
     q0 = helpers.states(sp, C, seed=rs.randint(1000), scale=0.05)
