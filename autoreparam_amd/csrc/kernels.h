@@ -843,6 +843,10 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
   constexpr int K = Lane::K, ND = Lane::ND, NG = Lane::NG;
   __shared__ float s_loc[kViDmax], s_sig[kViDmax], s_lsig[kViDmax], s_a[kViDmax], s_b[kViDmax];
   __shared__ float s_acc[4][kViDmax];   // sum g, sum g*eps, sum dlogp/da, sum dlogp/db
+  // every wave's partial sums, added up in wave order: the fit is bitwise reproducible from run to run (float atomics
+  // across the waves would add in arrival order)
+  __shared__ float s_part[kViBlock / 64][4][kViDmax];
+  __shared__ float s_elbo_w[kViBlock / 64], s_pri[kViDmax];
   __shared__ float s_elbo, s_prior;
   __shared__ float s_red[2][kViDmax];   // shared (a, b) groups: per-element gradient contributions, then the leaders' values
   const int D = P.D, tid = threadIdx.x, lr_i = blockIdx.x;
@@ -895,16 +899,17 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
         if (P.tied_b) s_b[tid] = a;
         if (P.wb) s_b[tid] = sigmoidf_(wb);
       }
-      s_acc[0][tid] = 0.f; s_acc[1][tid] = 0.f; s_acc[2][tid] = 0.f; s_acc[3][tid] = 0.f;
     }
-    if (tid == 0) { s_elbo = 0.f; s_prior = 0.f; }
     __syncthreads();
-    if (P.prior && tid < D && P.learn_a) {
+    if (P.prior && tid < D) {
       // log prior of the learnable parameters at the values this step's ELBO is evaluated with (inference.py:50-54);
       // a shared parameter is one variable and counts once
-      float lpr = lead[0] == tid ? discrete_prior_logp(s_a[tid]) : 0.f;
-      if (P.wb && lead[1] == tid) lpr += discrete_prior_logp(s_b[tid]);
-      atomicAdd(&s_prior, lpr);
+      float lpr = 0.f;
+      if (P.learn_a) {
+        lpr = lead[0] == tid ? discrete_prior_logp(s_a[tid]) : 0.f;
+        if (P.wb && lead[1] == tid) lpr += discrete_prior_logp(s_b[tid]);
+      }
+      s_pri[tid] = lpr;
     }
     if (P.learn_a) M.set_param(s_a, s_b);
 
@@ -961,15 +966,30 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
 #pragma unroll
       for (int i = 0; i < ND; ++i) {
         float v = chain_sum<K>(acc[k][i]);
-        if ((tid & 63) < K) {
-          if (i < NG) { if (slot == 0) atomicAdd(&s_acc[k][M.gg(i)], v); }
-          else if (M.lvalid(i - NG)) atomicAdd(&s_acc[k][M.lidx(i - NG)], v);
+        if ((tid & 63) < K) {    // every element d < D is written by exactly one lane of every wave
+          if (i < NG) { if (slot == 0) s_part[tid >> 6][k][M.gg(i)] = v; }
+          else if (M.lvalid(i - NG)) s_part[tid >> 6][k][M.lidx(i - NG)] = v;
         }
       }
     }
     elbo = chain_sum<K>(elbo);
-    if ((tid & 63) == 0) atomicAdd(&s_elbo, elbo);
+    if ((tid & 63) == 0) s_elbo_w[tid >> 6] = elbo;
     __syncthreads();
+    if (tid < D) {
+      for (int k = 0; k < nq; ++k) {
+        float t = s_part[0][k][tid];
+        for (int wv = 1; wv < kViBlock / 64; ++wv) t += s_part[wv][k][tid];
+        s_acc[k][tid] = t;            // read back by this thread only
+      }
+    }
+    if (tid == 0) {
+      float t = s_elbo_w[0];
+      for (int wv = 1; wv < kViBlock / 64; ++wv) t += s_elbo_w[wv];
+      s_elbo = t;
+      float pr = 0.f;
+      if (P.prior) for (int d = 0; d < D; ++d) pr += s_pri[d];
+      s_prior = pr;
+    }
 
     // Adam (tf.train.AdamOptimizer defaults) on -ELBO with NaN gradients zeroed
     // (inference.py:47, 62-66) and the learning-rate schedule of inference.py:69-75

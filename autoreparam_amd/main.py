@@ -325,6 +325,8 @@ def main(argv=None, flags=FLAGS):
         import torch
         import torch.distributed as dist
         local = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("ARP_SHARE_GPU") and torch.cuda.device_count():
+            local %= torch.cuda.device_count()     # tests only: several ranks on one GPU (with the gloo backend below)
         flags.device = "cuda:%d" % local
         if torch.cuda.is_available():          # (the engine itself fails loudly without a GPU)
             torch.cuda.set_device(local)
@@ -336,10 +338,14 @@ def main(argv=None, flags=FLAGS):
                 return None
         elif not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            try:
-                dist.init_process_group("nccl", device_id=torch.device(flags.device))
-            except TypeError:                                     # older torch: no device_id keyword
-                dist.init_process_group("nccl")
+            backend = os.environ.get("ARP_DIST_BACKEND", "nccl")   # "nccl" is RCCL; "gloo": tests that share one GPU
+            if backend != "nccl":
+                dist.init_process_group(backend)
+            else:
+                try:
+                    dist.init_process_group("nccl", device_id=torch.device(flags.device))
+                except TypeError:                                     # older torch: no device_id keyword
+                    dist.init_process_group("nccl")
     util.print_("Loading model {} with dataset {}.".format(flags.model, flags.dataset))
     model_config = models.get_model_by_name(flags.model, dataset=flags.dataset)
     results_dir = flags.results_dir if flags.results_dir != "" else flags.model + "_" + flags.dataset

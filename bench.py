@@ -308,16 +308,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if os.environ.get("ARP_SHARE_GPU") and torch.cuda.device_count():
+        local_rank %= torch.cuda.device_count()               # tests only: several ranks on one GPU (gloo backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev                                                # where the tensors of a collective live
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        try:
-            dist.init_process_group("nccl", device_id=dev)   # RCCL; binds the communicator to this rank's GPU
-        except TypeError:                                     # older torch: no device_id keyword
-            dist.init_process_group("nccl")
+        backend = os.environ.get("ARP_DIST_BACKEND", "nccl")  # "nccl" is RCCL; "gloo": tests that share one GPU
+        if backend != "nccl":
+            dist.init_process_group(backend)
+            cdev = torch.device("cpu")
+        else:
+            try:
+                dist.init_process_group("nccl", device_id=dev)   # RCCL; binds the communicator to this rank's GPU
+            except TypeError:                                     # older torch: no device_id keyword
+                dist.init_process_group("nccl")
 
     from autoreparam_amd import models, engine, _lib, parallel, util
     spec = models._spec_radon(args.dataset)
@@ -395,12 +403,12 @@ def main():
     t_coll = 0.0
     rank_ms = [kern_ms]
     if dist is not None:
-        tm = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tm = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         elapsed = float(tm.item())
         # every rank's own kernel time (HIP events): the spread is the load imbalance of the sharding
-        km = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(km, torch.tensor([kern_ms], dtype=torch.float64, device=dev))
+        km = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(km, torch.tensor([kern_ms], dtype=torch.float64, device=cdev))
         rank_ms = [float(t.item()) for t in km]
         torch.cuda.synchronize(); tc = time.perf_counter()
         acc = parallel.all_gather_chains(acc, C_total, dev)

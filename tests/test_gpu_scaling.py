@@ -52,12 +52,22 @@ def test_default_lanes_per_chain_is_the_fastest(gpu, chains):
     assert t0 <= 1.10 * t[best], (t0, t)
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def _two_rank_env():
+    """Two GPUs: one rank per GPU over RCCL, as in production.  One GPU (the test box): both ranks share it and the
+    end-of-run exchange runs over gloo (ARP_SHARE_GPU / ARP_DIST_BACKEND, test-only switches of main.py and bench.py) --
+    everything but the transport is the production path: the launcher, the sharding, the streams keyed by the global
+    chain id, the kernels, the gathers and the files rank 0 writes."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    if torch.cuda.device_count() < 2:
+        env.update(ARP_SHARE_GPU="1", ARP_DIST_BACKEND="gloo")
+    return env
+
+
 def test_two_rank_cli_equals_one_rank(tmp_path):
     """python -m torch.distributed.run --nproc-per-node 2 -m autoreparam_amd.main --inference=HMC: chains sharded over two
     ranks (streams keyed by the global chain id), per-chain minimum ESS all-gathered and acceptance counts
-    all-reduced over RCCL -- the rank-0 JSON and ESS files equal the single-process run bitwise."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    all-reduced -- the rank-0 JSON and ESS files equal the single-process run bitwise."""
+    env = _two_rank_env()
     out = {}
     for tag, launcher in (("one", [sys.executable, "-m", "autoreparam_amd.main"]),
                           ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
@@ -73,7 +83,29 @@ def test_two_rank_cli_equals_one_rank(tmp_path):
     assert j1["learned_variational_params"] == j2["learned_variational_params"]      # same VI fit (rank 0 runs it)
     for k in ("ess_min", "sem_min", "acceptance_rate"):
         assert j1[k] == j2[k], (k, j1[k], j2[k])
-    # rank 0 saves its own shard's per-chain ESS: the first half of the single-process arrays, bitwise
+    # rank 0 saves the per-element ESS of ALL chains (gathered from the ranks): the single-process arrays, bitwise
     for k in out["one"][1].files:
         a, b = out["one"][1][k], out["two"][1][k]
-        assert np.array_equal(a[: b.shape[0]], b), k
+        assert a.shape == b.shape and np.array_equal(a, b), k
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_rank_bench_line(scaling):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per GPU): one JSON line from rank 0
+    with the whole-job value, both ranks' kernel times and the end-of-run exchange."""
+    env = _two_rank_env()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr=127.0.0.1",
+           "--master-port=29519", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--chains", "4096", "--transitions", "32", "--scaling", scaling]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["scaling"] == scaling and j["steps"] == 3
+    per_gpu = 4096 if scaling == "weak" else 2048
+    assert j["config"]["chains_per_gpu"] == per_gpu and j["config"]["chains_total"] == 2 * per_gpu
+    assert len(j["kernel_ms_per_rank"]) == 2 and min(j["kernel_ms_per_rank"]) > 0
+    # the whole-job value: all ranks' leapfrog steps over the slowest rank's wall time
+    assert abs(j["value"] - 2 * per_gpu * 32 * 8 * 3 / (j["ms_per_step"] * 3e-3)) <= 1e-6 * j["value"]
+    assert 0.3 < j["accept_rate"] < 1.0

@@ -38,6 +38,27 @@ def test_vi_timeline_matches_oracle(oracle_lib, gpu, mname, kind):
     assert (elbo[:, -32:].mean(1) > elbo[:, :8].mean(1)).all()
 
 
+@pytest.mark.parametrize("mname", ["radon_MN", "election", "german"])
+def test_vi_fit_is_bitwise_reproducible(gpu, mname):
+    """The same fit twice (same seed, same starting point): every ELBO of the timeline and the fitted parameters equal
+    bit for bit -- the eight waves of a learning rate's workgroup add their partial gradients in wave order, not in
+    arrival order, so a whole `--inference=VI` + `--inference=HMC` flow repeats itself run after run."""
+    from autoreparam_amd import engine
+    sp = helpers.spec(mname)
+    eng = engine.Engine(sp, gpu)
+    eng.set_param(0, "NCP")
+    rs = np.random.RandomState(0)
+    loc0 = (1e-2 * rs.randn(2, sp.D)).astype(np.float32)
+    outs = []
+    for _ in range(3):
+        loc = torch.as_tensor(loc0.copy(), device=gpu); rho = torch.full((2, sp.D), -2.0, device=gpu)
+        elbo = eng.vi_run([0.02, 0.1], loc, rho, 200, 256, seed=11)
+        outs.append((elbo.cpu().numpy(), loc.cpu().numpy(), rho.cpu().numpy()))
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("mname", ["8schools", "radon_MN"])
 def test_cvip_learns_parameterisation(oracle_lib, gpu, mname):
     from autoreparam_amd import engine
