@@ -7,7 +7,7 @@ import numpy as np, torch
 import helpers, oracle
 from autoreparam_amd import engine
 LANES = {"8schools": [1, 2, 4, 8], "radon_MN": [4, 8, 16], "radon_PA": [4, 8, 16], "election": [4, 8, 16],
-         "german": [4, 8, 16], "radon_sd_MN": [8, 16], "funnel": [1], "electric": [16], "time_series": [4]}
+         "german": [4, 8, 16], "radon_sd_MN": [8, 16], "funnel": [1], "electric": [8, 16], "time_series": [4, 8, 16]}
 worst = {}
 for mname, lanes_list in LANES.items():
     sp = helpers.spec(mname); orc = oracle.OracleModel(sp); eng = engine.Engine(sp, "cuda:0")
