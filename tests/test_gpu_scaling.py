@@ -89,6 +89,23 @@ def test_two_rank_cli_equals_one_rank(tmp_path):
         assert a.shape == b.shape and np.array_equal(a, b), k
 
 
+def test_two_rank_vi_runs_on_rank_zero_only(tmp_path):
+    """--inference=VI under torch.distributed.run with two ranks: rank 0 fits and writes the JSON, rank 1 leaves at once,
+    no process group is created (nothing to exchange) and the launcher returns cleanly; the fit equals the
+    single-process fit bit for bit."""
+    env = _two_rank_env()
+    base = ["--model=radon", "--dataset=MN", "--method=CP", "--num_chains=64", "--seed=3", "--inference=VI",
+            "--num_optimization_steps=300"]
+    d1, d2 = str(tmp_path / "one"), str(tmp_path / "two")
+    subprocess.check_call([sys.executable, "-m", "autoreparam_amd.main"] + base + ["--results_dir=" + d1], env=env, cwd=ROOT)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr=127.0.0.1", "--master-port=29521", "-m", "autoreparam_amd.main"] + base +
+                          ["--results_dir=" + d2], env=env, cwd=ROOT, timeout=600)
+    j1, j2 = (json.load(open(os.path.join(d, "CP_tied.json"))) for d in (d1, d2))
+    for k in ("elbo", "learning_rate", "learned_variational_params", "initial_step_size"):
+        assert j1[k] == j2[k], k
+
+
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_two_rank_bench_line(scaling):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per GPU): one JSON line from rank 0
