@@ -11,7 +11,6 @@ NameError at main.py:515 and the CP.json / CP_tied.json file-name mismatch (both
 spellings are looked up).
 """
 import collections
-import io
 import json
 import os
 import sys
@@ -273,42 +272,35 @@ def run_interleaved_hmc(model_config, results_dir, file_path, flags=FLAGS):
     return results
 
 
-def save_hmc_results(file_path, **kwargs):
-    """reference main.py:531-550: every key is a list that is appended to."""
-    try:
-        with open(file_path, "r") as f:
-            results = json.load(f)
-    except IOError:
-        results = {}
-    for k in kwargs.keys():
-        if k not in results.keys():
-            results[k] = []
-    for k, v in kwargs.items():
-        results.get(k).append(v)
-    with open(file_path, "w") as outfile:
-        json.dump(results, outfile)
+def save_hmc_results(file_path, **record):
+    """Append one run to the result file: every key of the JSON object is a list with one entry per run (the file contract
+    of reference main.py:531-550 -- analyze.py and a later cVIP -> dVIP step read these lists)."""
+    history = {}
+    if os.path.exists(file_path):
+        with open(file_path) as f:
+            history = json.load(f)
+    for key, value in record.items():
+        history.setdefault(key, []).append(value)
+    with open(file_path, "w") as f:
+        json.dump(history, f)
 
 
 def save_ess(file_path_base, samples, normalized_ess_final, param_names, num_chains_to_save=0):
-    """reference main.py:552-585"""
-    dict_ess = dict([(param_names[i], np.array(normalized_ess_final[i])) for i in range(len(param_names))])
-    with open(file_path_base + "_ess.npz", "wb") as out_f:
-        buf = io.BytesIO()
-        np.savez(buf, **dict_ess)
-        out_f.write(buf.getvalue())
-    with open(file_path_base + "_ess.txt", "w") as out_f:
-        for k, v in dict_ess.items():
-            out_f.write("{}: {}\n\n".format(k, v))
-        out_f.write("\n\n")
-        for k, v in dict_ess.items():
-            out_f.write("{} mean: {}\n".format(k, np.mean(v, axis=0)))
-            out_f.write("{} stddev: {}\n\n".format(k, np.std(v, axis=0)))
+    """The side files of a sampling run (file contract of reference main.py:552-585): `<base>_ess.npz` with one [C, *event]
+    array of normalised ESS per latent part, `<base>_ess.txt` with the same arrays printed, then their mean and standard
+    deviation over chains, and -- with --num_chains_to_save -- `<base>_traces.npz` with the first chains' samples."""
+    ess_by_part = {name: np.asarray(e) for name, e in zip(param_names, normalized_ess_final)}
+    np.savez(file_path_base + "_ess.npz", **ess_by_part)
+    lines = ["{}: {}\n\n".format(name, e) for name, e in ess_by_part.items()]
+    lines.append("\n\n")
+    for name, e in ess_by_part.items():
+        lines.append("{} mean: {}\n".format(name, e.mean(axis=0)))
+        lines.append("{} stddev: {}\n\n".format(name, e.std(axis=0)))
+    with open(file_path_base + "_ess.txt", "w") as f:
+        f.writelines(lines)
     if num_chains_to_save > 0:
-        dict_res = dict([(param_names[i], samples[i][:, :num_chains_to_save]) for i in range(len(param_names))])
-        with open(file_path_base + "_traces.npz", "wb") as out_f:
-            buf = io.BytesIO()
-            np.savez(buf, **dict_res)
-            out_f.write(buf.getvalue())
+        np.savez(file_path_base + "_traces.npz",
+                 **{name: x[:, :num_chains_to_save] for name, x in zip(param_names, samples)})
 
 
 def main(argv=None, flags=FLAGS):
