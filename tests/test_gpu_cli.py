@@ -143,3 +143,15 @@ def test_config3_full_size_german_dvip(gpu, tmp_path):
     assert len(r["ess_min"]) == 1 and len(r["mcmc_time_sec"]) == 1
     tr = np.load(os.path.join(d, "dVIP_eig_tied_traces.npz"))
     assert tr["beta"].shape == (S, 4, 62)
+
+
+def test_every_model_and_method_runs_through_the_cli():
+    """The reference's README model list x its five methods (CP, NCP, cVIP, dVIP, i), each VI -> HMCtuning -> HMC through
+    main.py at 256 chains (tools/cli_matrix.py): 45 runs, finite ESS and acceptance rates, the file sequencing the
+    reference demands (cVIP's fit before dVIP, CP and NCP before the interleaved sampler)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "cli_matrix.py")], cwd=root, timeout=1500,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    lines = [l for l in r.stdout.splitlines() if "ess_min/1000 grad" in l]
+    assert r.returncode == 0 and len(lines) == 45 and "cells failed: 0" in r.stdout, r.stdout[-3000:]
