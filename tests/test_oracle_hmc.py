@@ -277,3 +277,23 @@ def test_metropolis_margins_explain_the_decisions(oracle_lib):
                         margin=mg, escale=es)
     assert np.array_equal(mg[:, 0] < 0, t0.astype(bool)) and np.array_equal(mg[:, 1] < 0, t1.astype(bool))
     assert np.isfinite(es).all()
+
+
+def test_time_series_stream_partition_in_whole_time_steps(oracle_lib):
+    """The random-stream partition of time_series: a slot owns whole (alpha_t, mu_t) time steps, ceil(120 / lanes)
+    rounded up to even elements (30 / 16 / 8 at 4 / 8 / 16 lanes per chain, oracle.c: orc_per_lane).  Every latent gets
+    a momentum draw whatever the split (one tiny leapfrog step moves EVERY latent), and the splits are different
+    streams."""
+    sp = helpers.spec("time_series")
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "NCP")
+    q0 = helpers.states(sp, 6, seed=3, scale=0.05)
+    ends = {}
+    for lanes in (4, 8, 16):
+        st = oracle_lib.new_state(q0, np.float64)
+        orc.hmc_run(st, a, b, np.full(sp.D, 1e-6, np.float64), 1, 1, seed=9, lanes=lanes)
+        moved = st["q"] - q0
+        assert (st["accept_count"] == 1).all()                 # an (almost) exact integrator step is accepted
+        assert (np.abs(moved) > 0).all(), lanes                 # every latent received a momentum
+        ends[lanes] = moved
+    assert not np.allclose(ends[4], ends[8]) and not np.allclose(ends[8], ends[16])
