@@ -155,3 +155,31 @@ def test_every_model_and_method_runs_through_the_cli():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     lines = [l for l in r.stdout.splitlines() if "ess_min/1000 grad" in l]
     assert r.returncode == 0 and len(lines) == 45 and "cells failed: 0" in r.stdout, r.stdout[-3000:]
+
+
+def test_analyze_reports_a_real_results_directory(gpu, tmp_path, capsys):
+    """The analyze.py-compatible report over files the engine really wrote: radon MN under all five methods
+    through the CLI, then every table of autoreparam_amd.analyze."""
+    from autoreparam_amd import analyze
+    d = os.path.join(str(tmp_path), "radon_MN")
+    base = ["--model=radon", "--dataset=MN", "--results_dir=" + d, "--num_chains=128", "--seed=4", "--num_optimization_steps=400"]
+    hm = ["--num_samples=200", "--num_burnin_steps=300", "--num_adaptation_steps=250"]
+    for method in ("CP", "NCP", "cVIP", "dVIP"):
+        _run(base + ["--method=" + method, "--inference=VI"])
+        for L in (2, 4):
+            _run(base + ["--method=" + method, "--inference=HMCtuning", "--num_leapfrog_steps=%d" % L] + hm)
+        _run(base + ["--method=" + method, "--inference=HMC"] + hm)
+    _run(base + ["--method=i", "--inference=HMC"] + hm)
+    res = analyze.load(str(tmp_path), "radon_MN")
+    assert sorted(res) == ["CP_tied", "NCP_tied", "cVIP_eig_tied", "dVIP_eig_tied", "i_tied"]
+    elbos = analyze.report_elbos(res)
+    assert len(elbos) == 4 and all("+/-" in l for l in elbos)
+    assert any("m_a" in l for l in analyze.report_reparams(res))
+    for norm in (False, True):
+        lines = analyze.report_ess(res, normalize_times=norm)
+        assert len(lines) == 5, lines
+    # a plain HMC run's leapfrog count comes from its best tuning run, the interleaved run's from its own key
+    assert analyze.leapfrog_steps(res["CP_tied"]) in (2, 4) and analyze.leapfrog_steps(res["i_tied"]) in (4, 8)
+    analyze.main(["--results_dir", str(tmp_path), "--model", "radon_MN", "--elbos", "--ess", "--reparams"])
+    out = capsys.readouterr().out
+    assert "CP_tied" in out and "i_tied" in out
