@@ -107,7 +107,7 @@ ARP_DEV float* lane_stage(float* own) {
   __shared__ __attribute__((aligned(16))) float s_stage_own[lane_stage_alias<Lane>::value ? 4 : (kBlock / 64) * stage_floats<Lane>()]; \
   float* const s_stage = lane_stage<Lane>(s_stage_own)
 
-template <class Lane>
+template <bool STREAM = false, class Lane>
 ARP_DEV void store_row_wave(const Lane& M, float* stage, float* gdst, int cl, int D, int nvalid,
                             const float (&v)[Lane::ND]) {
   float* row = stage + cl * D;
@@ -124,7 +124,7 @@ ARP_DEV void store_row_wave(const Lane& M, float* stage, float* gdst, int cl, in
     for (int k = lane * 4; k < nvalid; k += 256) {
       const float4 t = *reinterpret_cast<const float4*>(stage + k);
       if (k + 3 < nvalid) {
-        *reinterpret_cast<float4*>(gdst + k) = t;
+        store_f4<STREAM>(reinterpret_cast<float4*>(gdst + k), t);
       } else {
         gdst[k] = t.x;
         if (k + 1 < nvalid) gdst[k + 1] = t.y;
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
       auto record = [&](const float (&v)[ND]) {
         if (to_trace) {
           const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
-          store_row_wave(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, v);
+          store_row_wave<true>(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, v);
         }
         if (P.stats) {
           stats_update_wave(M, stage, P, cw0, cl, D, nvalid, v, rec_row == 0, bpos + 1 == P.stats_batch);
@@ -753,8 +753,8 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
       if (P.trace && cw0 < P.trace_chains) {
         const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
         float* wrow = P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D;
-        if (use_x) store_row_wave(M, stage, wrow, cl, D, nv, x);
-        else store_row_wave(M, stage, wrow, cl, D, nv, q);
+        if (use_x) store_row_wave<true>(M, stage, wrow, cl, D, nv, x);
+        else store_row_wave<true>(M, stage, wrow, cl, D, nv, q);
       }
       if (P.stats) {
         const bool bend = bpos + 1 == P.stats_batch;

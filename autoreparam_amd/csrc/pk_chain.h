@@ -253,7 +253,7 @@ __device__ __noinline__ void copy_stage_rows(const float* stage, float* gdst, in
 // when the wave is full and D is the instantiation's own dimension (the reference's PA: 68 = 4 x 17 counties), every
 // offset a compile-time constant -- the staging writes are ds_write2_b32 off one base, the copy is an unrolled run of
 // ds_read_b128 / global_store_dwordx4 off a wave-uniform base: no address arithmetic on the vector pipe.
-template <class T>
+template <bool STREAM = false, class T>
 ARP_DEV void pk_store_rows(const T& M, float* stage, float* gdst, int cl, int D, int nvalid,
                               const float (&xg)[T::NG], const v2f (&xc)[T::NP]) {
   constexpr int K = T::K, NL = T::NL, DC = T::DCAP, NV = (64 / K) * DC;
@@ -277,7 +277,7 @@ ARP_DEV void pk_store_rows(const T& M, float* stage, float* gdst, int cl, int D,
 #pragma unroll
     for (int it = 0; it < (NV / 4 + 63) / 64; ++it) {
       const int k = lane + 64 * it;
-      if ((it + 1) * 64 <= NV / 4 || k < NV / 4) g4[k] = s4[k];
+      if ((it + 1) * 64 <= NV / 4 || k < NV / 4) store_f4<STREAM>(g4 + k, s4[k]);
     }
     __builtin_amdgcn_wave_barrier();
   } else if (nvalid == (64 / K) * D && (nvalid & 3) == 0 && (reinterpret_cast<uintptr_t>(gdst) & 15) == 0) {
@@ -304,7 +304,7 @@ ARP_DEV void pk_store_rows(const T& M, float* stage, float* gdst, int cl, int D,
 #pragma unroll
     for (int it = 0; it < (NV / 4 + 63) / 64; ++it) {
       const int k = lane + 64 * it;
-      if (k < n4) g4[k] = s4[k];
+      if (k < n4) store_f4<STREAM>(g4 + k, s4[k]);
     }
     __builtin_amdgcn_wave_barrier();
   } else {   // ragged tail of the launch, or an unaligned destination: general offsets, out-of-line copy
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(kBlock, STATS && T::MINW > 2 ? 2 : T::MINW) void pk
         }
         if (to_trace) {
           const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
-          pk_store_rows(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, xg, xc);
+          pk_store_rows<true>(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, xg, xc);
         }
         if (STATS) {
           pk_stats_accumulate<T>(s_stats, ++n_acc, xg, xc);
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(kBlock, STATS && T::MINW > 2 ? 2 : T::MINW) void pk
       if (to_trace) {
         const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
         float* dst = P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D;
-        if (use_x) pk_store_rows(M, stage, dst, cl, D, nv, xg, xc); else pk_store_rows(M, stage, dst, cl, D, nv, qg, qc);
+        if (use_x) pk_store_rows<true>(M, stage, dst, cl, D, nv, xg, xc); else pk_store_rows<true>(M, stage, dst, cl, D, nv, qg, qc);
       }
       if (STATS) {
         ++n_acc;

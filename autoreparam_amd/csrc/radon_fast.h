@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kBlock, T::MINW) void radon_interleaved_kernel(Rado
       const bool to_trace = P.trace && cw0 < P.trace_chains;
       if (to_trace) {
         const int nv = min(nvalid, (int)(P.trace_chains - cw0) * D);
-        pk_store_rows(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, qg, qc);
+        pk_store_rows<true>(M, stage, P.trace + ((size_t)rec_row * P.trace_chains + cw0) * D, cl, D, nv, qg, qc);
       }
       if (STATS) {
         pk_stats_accumulate<T>(s_stats, ++n_acc, qg, qc);
