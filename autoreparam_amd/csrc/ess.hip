@@ -38,6 +38,11 @@ constexpr int kEssDenseAbove = 3;         // ... taken by a wave with more than 
 #ifndef ARP_ESS_LOAD
 #define ARP_ESS_LOAD (ARP_ESS_WIN % 16 == 0 ? 16 : 8)
 #endif
+// cache policy of the trace loads: 2 = non-temporal (`buffer_load_dword ... nt`): every sample is read once per pass, and
+// the pass is longer than every cache -- 1 - 1.5 % faster than the default policy on the 18.6 GB trace
+#ifndef ARP_ESS_AUX
+#define ARP_ESS_AUX 2
+#endif
 #ifndef ARP_ESS_DEPTH
 #define ARP_ESS_DEPTH 2
 #endif
@@ -65,7 +70,7 @@ struct EssSeries {
   __device__ __forceinline__ float at(long long t) const {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + t * stride), 0,
                                                                         (int)row_bytes, 0x00020000);   // raw dword buffer
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)boff, 0, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)boff, 0, ARP_ESS_AUX));
   }
 };
 
