@@ -108,14 +108,20 @@ def _cli_sequence(results_dir):
     base = ["--model=8schools", "--results_dir=%s" % results_dir, "--seed=3", "--num_chains=7", "--num_samples=12",
             "--num_burnin_steps=4", "--num_adaptation_steps=3", "--num_chains_to_save=2"]
     out = {}
-    for m in ("CP", "NCP"):
-        out["vi_" + m] = cli.main(base + ["--inference=VI", "--method=" + m], flags=FLAGS.copy())
+
+    def phase(args):
+        # on the command line every phase is its own launch: it has ended -- rank 0 has written its files -- before the next
+        # one starts and reads them (the tuning runs decide the leapfrog count of the HMC run on EVERY rank)
+        r = cli.main(base + args, flags=FLAGS.copy())
         if dist.is_initialized():
-            dist.barrier()      # on the command line the VI run has ended (rank 0 has written its JSON) before HMC is launched
+            dist.barrier()
+        return r
+    for m in ("CP", "NCP"):
+        out["vi_" + m] = phase(["--inference=VI", "--method=" + m])
         for L in (2, 4):
-            cli.main(base + ["--inference=HMCtuning", "--method=" + m, "--num_leapfrog_steps=%d" % L], flags=FLAGS.copy())
-    out["hmc"] = cli.main(base + ["--inference=HMC", "--method=CP"], flags=FLAGS.copy())
-    out["inter"] = cli.main(base + ["--inference=HMC", "--method=i"], flags=FLAGS.copy())
+            phase(["--inference=HMCtuning", "--method=" + m, "--num_leapfrog_steps=%d" % L])
+    out["hmc"] = phase(["--inference=HMC", "--method=CP"])
+    out["inter"] = phase(["--inference=HMC", "--method=i"])
     return out
 
 
