@@ -7,7 +7,10 @@ CP/NCP, 4 + 4 = "8 leapfrog steps" per step, main.py:493), on the fused HIP kern
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one launch of the hot path over the rank's whole chain batch: `--transitions`
-(default 256) sampler steps for every chain.  A sampler step (--method i) is one interleaved step:
+(default 1 024) sampler steps for every chain -- 13 ms per step, so that a handful of warm-up steps cover
+the ~30 ms an idle MI355X takes to reach the clock it then holds (profiles/r03_clock_ramp.txt: the first
+launches after idle take 5.7, 4.1, 3.8, 3.6, 3.55, 3.5, 3.4 ms per 256 steps, the following hundreds
+3.36; with 256-step launches the driver's `--warmup 5` ended inside the ramp).  A sampler step (--method i) is one interleaved step:
 num_ls leapfrogs in CP coordinates, to_ncp, num_ls leapfrogs in NCP coordinates, to_cp, two
 Metropolis tests, two simple step-size adaptations (counted as 2*num_ls leapfrog steps; the
 reference's two bootstrap gradient evaluations per step are not needed -- the kernel carries the
@@ -289,7 +292,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--method", default="i", choices=["i", "CP"])
     ap.add_argument("--leapfrog", type=int, default=8, help="leapfrog steps per sampler step (i: split CP/NCP)")
-    ap.add_argument("--transitions", type=int, default=256, help="sampler steps per launch (= per bench step)")
+    ap.add_argument("--transitions", type=int, default=1024, help="sampler steps per launch (= per bench step)")
     ap.add_argument("--thin", type=int, default=2, help="a trace row every THIN-th sampler step (reference: 2)")
     ap.add_argument("--dataset", default="PA")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per chain (0 = library default)")
