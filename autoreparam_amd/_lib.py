@@ -8,8 +8,16 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ARP_LIB_PATH: timing experiments only (a variant built with ARP_HIPCC_FLAGS / ARP_BUILD_TAG)
-LIB_PATH = os.environ.get("ARP_LIB_PATH") or os.path.join(_HERE, "libautoreparam_hip.so")
+# ARP_LIB_PATH: timing experiments only (a variant built with ARP_HIPCC_FLAGS / ARP_BUILD_TAG); honoured under
+# ARP_DEBUG=1 only and announced on stderr
+LIB_PATH = os.path.join(_HERE, "libautoreparam_hip.so")
+if os.environ.get("ARP_LIB_PATH"):
+    import sys as _sys
+    if os.environ.get("ARP_DEBUG") == "1":
+        LIB_PATH = os.environ["ARP_LIB_PATH"]
+        print("autoreparam_amd: DEBUG SWITCH ARP_LIB_PATH=%s is in effect (ARP_DEBUG=1)" % LIB_PATH, file=_sys.stderr, flush=True)
+    else:
+        print("autoreparam_amd: ARP_LIB_PATH IGNORED (experiment switch; set ARP_DEBUG=1 to enable it)", file=_sys.stderr, flush=True)
 
 MODEL_EIGHT_SCHOOLS, MODEL_RADON, MODEL_GERMAN_CREDIT, MODEL_ELECTION, MODEL_RADON_STDDVS = 0, 1, 2, 3, 4
 MODEL_NEALS_FUNNEL = 5

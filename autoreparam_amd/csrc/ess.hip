@@ -8,17 +8,21 @@
 //
 // Bound: HBM.  A series is S floats a whole trace row apart, so the kernel is a strided stream of the trace; the work
 // per sample (W + 1 multiply-adds for W lags) is ~ 1 ms of vector issue for the 18.6 GB headline trace against >= 2.3 ms
-// of HBM time.  What decides the time is (i) how many bytes are in flight -- every window's loads are issued one window
+// of HBM time.  What decides the time is (i) how many bytes are in flight -- every batch's loads are issued one batch
 // AHEAD of their use (two register buffers, ping-pong), four waves per SIMD -- and (ii) how often the trace is read:
-//   sweep 1  lags 0 .. W = 32 and the mean in ONE pass (no mean pass in front of it): with y_t = x_t - r (r = the mean of
-//            the first W samples, so that y is small) and m' = mean(y),
+//   sweep 1  lags 0 .. W = 16 (kEssWin) and the mean in ONE pass (no mean pass in front of it): with y_t = x_t - r (r = the
+//            mean of the first W samples, so that y is small) and m' = mean(y),
 //              sum_{t>=k} (y_t - m')(y_{t-k} - m') = sum_{t>=k} y_t y_{t-k} - m' (2 T - head_k - tail_k) + (S - k) m'^2,
-//            T = sum_t y_t, head_k / tail_k = the sums of the first / last k values (two W-sample loops).
-//            A WAVE goes on to further sweeps when any of its 64 series is still positive at the last lag, and a wave
-//            is about one chain's elements, slow ones included: with 16 lags two waves in three of the headline trace
-//            needed a second pass over it (8.3 ms); 32 lags leave few.  The 33 running totals of a thread live in its
-//            own LDS column (float: the register file holds the 33 window sums, the 32-deep window and two load buffers);
-//   sweep 2+ lags beyond W, 16 at a time: the leading and the lagged stream are both read (slowly mixing series only).
+//            T = sum_t y_t, head_k / tail_k = the sums of the first / last k values (two W-sample loops).  Window sums of
+//            128 products in registers, flushed into the thread's LDS column of W + 2 float running totals.
+//   dense    a WAVE with more than kEssDenseAbove (3) series still positive at lag W takes lags W+1 .. W+32 of all its
+//            series in one more coalesced pass, about the mean, from a 48-deep register ring (ess_sweep_dense).  Its
+//            sums are S-long FLOAT accumulations with no flush: relative error ~ sqrt(S) 2^-24 typical (2e-5 at
+//            S = 50 000), S 2^-24 worst case (3e-3) on sum |y y'| -- these lags only decide where the sum is cut and add
+//            a few per cent to it, against a sampling noise of 1 / sqrt(S).
+//   tail     what is still positive after that: S + 72 <= 2 304 floats -- one series at a time in the wave's LDS block,
+//            64 lags per round by all lanes (ess_tail_cooperative); longer series per lane, 16 lags per pass with the
+//            leading and the lagged stream both read (ess_sweep_far; sums flushed into doubles every 128 samples).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "host_common.h"
@@ -55,7 +59,8 @@ constexpr int kEssDepth = ARP_ESS_DEPTH;  // load buffers: kEssDepth - 1 batches
 // the raw sums are (1 + m^2) times the centred ones, so rho carries ~ (1 + m^2) x that.  The sweep is retaken around the
 // mean itself when m^2 > 16 (a whole WAVE retakes it when one of its 64 series does, so the threshold sits where a
 // stationary chain's first samples practically never land): rho is good to ~ 2e-5 typical, 7e-4 worst case -- against a
-// sampling noise of 1 / sqrt(S) >= 4e-3.  The sweeps past the first flush into doubles (registers are free there).
+// sampling noise of 1 / sqrt(S) >= 4e-3.  ess_sweep_far flushes into doubles (registers are free there); the dense sweep
+// keeps float sums (header).
 
 // A series is addressed as (wave-uniform row base)[32-bit lane byte offset] through BUFFER loads: the row base is a
 // buffer resource in scalar registers (rebuilt per row with two scalar adds), the lane's offset one VGPR shared by all of
@@ -336,7 +341,9 @@ __global__ __launch_bounds__(256, ARP_ESS_MINB) void ess_kernel(const float* __r
       total += done ? 0.0 : (double)(S - j) / (double)S * rho;
     }
   }
-  done = done || S <= W;
+  // lanes past the end shadow series n - 1: they must not vote a wave into further sweeps (nor have the cooperative
+  // tail run once more per shadow lane)
+  done = done || S <= W || !valid;
   int tail_from = W;                          // first lag not yet taken
   if (__builtin_popcountll(__ballot(!done)) > kEssDenseAbove && S > W + kEssDenseLags) {
     // many of the wave's series go on: the next kEssDenseLags lags of all of them in one more coalesced pass

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string>
 #include <type_traits>
@@ -113,9 +114,20 @@ struct Launch {
   }
 };
 
-// experiments only: ARP_STATS_LDS=0 sends statistics runs down the plane-per-sample route of kernels.h again
+// experiments only: ARP_STATS_LDS=0 sends statistics runs down the plane-per-sample route of kernels.h again.  Honoured
+// under ARP_DEBUG=1 only and announced on stderr: a stray variable must not change which kernel a production run takes.
 inline bool stats_lds_enabled() {
-  static const bool on = [] { const char* e = getenv("ARP_STATS_LDS"); return !(e && e[0] == '0'); }();
+  static const bool on = [] {
+    const char* e = getenv("ARP_STATS_LDS");
+    if (!(e && e[0] == '0')) return true;
+    const char* d = getenv("ARP_DEBUG");
+    if (!(d && d[0] == '1' && d[1] == 0)) {
+      fprintf(stderr, "libautoreparam_hip: ARP_STATS_LDS=0 IGNORED (experiment switch; set ARP_DEBUG=1 to enable it)\n");
+      return true;
+    }
+    fprintf(stderr, "libautoreparam_hip: DEBUG SWITCH ARP_STATS_LDS=0 is in effect (statistics take the plane-per-sample route)\n");
+    return false;
+  }();
   return on;
 }
 

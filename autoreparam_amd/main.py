@@ -111,8 +111,7 @@ def run_vi(model_config, results_dir, file_path, flags=FLAGS):
         "learned_reparam": _clean_dict(learned_reparam),
         "learned_variational_params": _clean_dict(learned_variational_params),
     }
-    with open(file_path, "w") as outfile:
-        json.dump(results, outfile)
+    _write_json_atomic(file_path, results)
     return results
 
 
@@ -281,8 +280,18 @@ def save_hmc_results(file_path, **record):
             history = json.load(f)
     for key, value in record.items():
         history.setdefault(key, []).append(value)
-    with open(file_path, "w") as f:
-        json.dump(history, f)
+    _write_json_atomic(file_path, history)
+
+
+def _write_json_atomic(file_path, obj):
+    """A reader (another rank at the top of its next phase, a later run) sees the old file or the new one, never a
+    half-written one: write next to it, then rename over it."""
+    tmp = "%s.tmp.%d" % (file_path, os.getpid())
+    with open(tmp, "w") as f:
+        json.dump(obj, f)
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp, file_path)
 
 
 def save_ess(file_path_base, samples, normalized_ess_final, param_names, num_chains_to_save=0):
@@ -317,7 +326,7 @@ def main(argv=None, flags=FLAGS):
         import torch
         import torch.distributed as dist
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        if os.environ.get("ARP_SHARE_GPU") and torch.cuda.device_count():
+        if util.debug_switch("ARP_SHARE_GPU") and torch.cuda.device_count():
             local %= torch.cuda.device_count()     # tests only: several ranks on one GPU (with the gloo backend below)
         flags.device = "cuda:%d" % local
         if torch.cuda.is_available():          # (the engine itself fails loudly without a GPU)
@@ -330,7 +339,7 @@ def main(argv=None, flags=FLAGS):
                 return None
         elif not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            backend = os.environ.get("ARP_DIST_BACKEND", "nccl")   # "nccl" is RCCL; "gloo": tests that share one GPU
+            backend = util.debug_switch("ARP_DIST_BACKEND") or "nccl"   # "nccl" is RCCL; "gloo": tests that share one GPU
             if backend != "nccl":
                 dist.init_process_group(backend)
             else:
@@ -352,13 +361,21 @@ def main(argv=None, flags=FLAGS):
     file_path = os.path.join(results_dir, filename)
     if flags.inference == "VI":
         return run_vi(model_config, results_dir, file_path, flags)
-    elif flags.inference == "HMC":
-        if flags.method == "i":
-            return run_interleaved_hmc(model_config, results_dir, file_path, flags)
-        return run_hmc(model_config, results_dir, file_path, tuning=False, flags=flags)
-    elif flags.inference == "HMCtuning":
+    if flags.inference not in ("HMC", "HMCtuning"):
+        raise Exception("unknown inference {}".format(flags.inference))
+    try:
+        if flags.inference == "HMC":
+            if flags.method == "i":
+                return run_interleaved_hmc(model_config, results_dir, file_path, flags)
+            return run_hmc(model_config, results_dir, file_path, tuning=False, flags=flags)
         return run_hmc(model_config, results_dir, file_path, tuning=True, flags=flags)
-    raise Exception("unknown inference {}".format(flags.inference))
+    finally:
+        # Every rank reads the result file at the top of a sampling phase (step sizes, tuning_runs -> the leapfrog count)
+        # and rank 0 rewrites it at the end of one: no rank may enter the next phase before rank 0's write has landed,
+        # or the ranks could sample with different leapfrog counts.  (A rank that raised never reaches its peers'
+        # barrier; the launcher then tears the job down.)
+        if sys.exc_info()[0] is None:
+            parallel.barrier()
 
 
 if __name__ == "__main__":

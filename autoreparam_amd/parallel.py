@@ -24,6 +24,12 @@ def world():
     return 0, 1
 
 
+def barrier():
+    """All ranks of the job (no-op for a single process)."""
+    if world()[1] > 1:
+        dist.barrier()
+
+
 def shard_bounds(n, rank, world_size):
     """Contiguous block [lo, hi) of `n` chains owned by `rank` (sizes differ by at most one)."""
     base, rem = divmod(n, world_size)

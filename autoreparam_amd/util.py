@@ -11,6 +11,24 @@ def print_(*args):
     print(*args, flush=True)
 
 
+def debug_switch(name):
+    """Value of a test / experiment environment switch (ARP_SHARE_GPU, ARP_DIST_BACKEND, ARP_LIB_PATH, ...), honoured
+    only under ARP_DEBUG=1 and announced on stderr every time it takes effect: a stray variable in a production
+    launch must not silently put two ranks on one GPU or move the collectives to the host."""
+    import os
+    import sys
+    v = os.environ.get(name)
+    if not v:
+        return None
+    if os.environ.get("ARP_DEBUG") != "1":
+        print("autoreparam_amd: %s=%s IGNORED (test/experiment switch; set ARP_DEBUG=1 to enable it)" % (name, v),
+              file=sys.stderr, flush=True)
+        return None
+    print("autoreparam_amd: DEBUG SWITCH %s=%s is in effect (ARP_DEBUG=1) -- not a production configuration" % (name, v),
+          file=sys.stderr, flush=True)
+    return v
+
+
 def get_approximate_step_size(variational_parameters, num_leapfrog_steps):
     """reference util.py:271-276: the variational scales divided by L^2."""
     return [np.asarray(variational_parameters[key]) / num_leapfrog_steps ** 2

@@ -311,8 +311,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    if os.environ.get("ARP_SHARE_GPU") and torch.cuda.device_count():
-        local_rank %= torch.cuda.device_count()               # tests only: several ranks on one GPU (gloo backend)
+    from autoreparam_amd.util import debug_switch
+    if debug_switch("ARP_SHARE_GPU") and torch.cuda.device_count():
+        local_rank %= torch.cuda.device_count()               # tests only (ARP_DEBUG=1): several ranks on one GPU (gloo backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = dev                                                # where the tensors of a collective live
@@ -320,7 +321,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("ARP_DIST_BACKEND", "nccl")  # "nccl" is RCCL; "gloo": tests that share one GPU
+        backend = debug_switch("ARP_DIST_BACKEND") or "nccl"  # "nccl" is RCCL; "gloo": tests that share one GPU
         if backend != "nccl":
             dist.init_process_group(backend)
             cdev = torch.device("cpu")
@@ -500,6 +501,10 @@ def main():
             ems = _time_launches(lambda: eeng.hmc_run(ste, epse, Le, Te, **kwe), 3, 1)
             rate = Ce * Te * Le / (ems * 1e-3)
             ib, ib_cyc = election_issue_bound(name, Le)
+            # the clock the chip holds under a vector-bound load (GRBM_GUI_ACTIVE / 8 / kernel time of the newest headline
+            # profile): the nominal 2.4 GHz overstates what back-to-back issue could deliver on this box
+            prof_clk = ((load_profile({}) or {}).get("derived") or {}).get("clock_ghz_estimate")
+            ib_held = election_issue_bound(name, Le, prof_clk)[0] if prof_clk else None
             el[name] = {"kernel_ms": ems, "leapfrog_steps_per_s": rate,
                         "roofline": {"bound": "valu", "achieved": Ce * Te * Le * eflop / (ems * 1e-3) / 1e12,
                                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -507,6 +512,9 @@ def main():
                                      "algorithmic_flop_per_leapfrog": eflop},
                         # the ceiling the transcendentals set: the same kernel's instruction mix issued back to back
                         "issue_bound": {"leapfrog_steps_per_s": ib, "frac": rate / ib, "clock_ghz": 2.4,
+                                        "at_held_clock": {"clock_ghz": prof_clk, "leapfrog_steps_per_s": ib_held,
+                                                          "frac": rate / ib_held if ib_held else None,
+                                                          "clock_source": "newest profiles/rNN_headline.json: derived.clock_ghz_estimate"},
                                         "issue_cycles_per_wave_transition": ib_cyc, "mix_per_wave": ELECTION_MIX[name],
                                         "cycles_per_instruction": ISSUE_CYCLES,
                                         "note": "per state and gradient: 1 v_exp + 4 v_rcp (+ 8 v_log per state pair in the "
@@ -626,6 +634,10 @@ def main():
                         "measured_frac_of_8TBps": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                         "note": "the byte model charges every transition a state load/store the fused kernel performs "
                                 "once per launch; the measured figure is what crosses HBM"}}
+        if dist is not None and dist.get_backend() == "nccl":
+            out_rccl = world
+        else:
+            out_rccl = None
         if prof:
             roof["profile"] = prof
             # shader clock held under this kernel's load (GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the profiled pass);
@@ -653,9 +665,15 @@ def main():
                        "trace_thin": thin if rec else 0, "D": D, "lanes_per_chain": args.lanes,
                        "parallelism": "chains sharded, %d rank(s), %s scaling" % (world, args.scaling)},
             "roofline": roof,
-            "accept_rate": accept_rate, "rccl_ranks": world, "stats_allgather_s": t_coll,
+            "accept_rate": accept_rate, "ranks": world,
+            # the transport the end-of-run exchange actually ran on: "nccl" is RCCL; "gloo" only in the tests that put
+            # two ranks on one GPU; None for a single rank (no process group)
+            "dist_backend": dist.get_backend() if dist is not None else None,
+            "stats_allgather_s": t_coll,
             "kernel_ms_per_rank": rank_ms, "rank_imbalance_max_over_min": max(rank_ms) / min(rank_ms), "ess": ess_info,
         }
+        if out_rccl is not None:
+            out["rccl_ranks"] = out_rccl      # only when the collectives really ran over RCCL
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -1,0 +1,36 @@
+"""CPU: the frozen parts of bench.py's contract -- checked on the source, no GPU."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _src():
+    return open(os.path.join(ROOT, "bench.py")).read()
+
+
+def test_bench_step_is_frozen_at_1024_interleaved_steps():
+    s = _src()
+    m = re.search(r'add_argument\("--transitions", type=int, default=(\d+)', s)
+    assert m and int(m.group(1)) == 1024
+    m = re.search(r'add_argument\("--thin", type=int, default=(\d+)', s)
+    assert m and int(m.group(1)) == 2                      # the reference's sample_chain thinning
+    m = re.search(r'add_argument\("--chains", type=int, default=(\d+)', s)
+    assert m and int(m.group(1)) == 65536                  # BASELINE.json's headline chain count
+    m = re.search(r'add_argument\("--gpus", type=int, default=(\d+)', s)
+    assert m and int(m.group(1)) == 1
+
+
+def test_bench_reports_the_transport_it_used():
+    s = _src()
+    assert '"dist_backend"' in s and '"ranks"' in s
+    # rccl_ranks is only emitted under the nccl backend
+    assert re.search(r'get_backend\(\) == "nccl"', s)
+
+
+def test_oracle_only_in_the_cpu_baseline_leg():
+    s = _src()
+    for m in re.finditer(r"^\s*import oracle|^\s*from oracle", s, flags=re.M):
+        # inside cpu_baseline() or the child-process code string it builds
+        head = s[:m.start()]
+        assert head.rfind("def cpu_baseline(") > head.rfind("\ndef main("), "oracle imported outside the cpu_baseline leg"

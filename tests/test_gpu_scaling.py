@@ -52,6 +52,12 @@ def test_default_lanes_per_chain_is_the_fastest(gpu, chains):
     assert t0 <= 1.10 * t[best], (t0, t)
 
 
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
 def _two_rank_env():
     """Two GPUs: one rank per GPU over RCCL, as in production.  One GPU (the test box): both ranks share it and the
     end-of-run exchange runs over gloo (ARP_SHARE_GPU / ARP_DIST_BACKEND, test-only switches of main.py and bench.py) --
@@ -59,7 +65,7 @@ def _two_rank_env():
     chain id, the kernels, the gathers and the files rank 0 writes."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
     if torch.cuda.device_count() < 2:
-        env.update(ARP_SHARE_GPU="1", ARP_DIST_BACKEND="gloo")
+        env.update(ARP_DEBUG="1", ARP_SHARE_GPU="1", ARP_DIST_BACKEND="gloo")
     return env
 
 
@@ -71,7 +77,7 @@ def test_two_rank_cli_equals_one_rank(tmp_path):
     out = {}
     for tag, launcher in (("one", [sys.executable, "-m", "autoreparam_amd.main"]),
                           ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                                   "--master-addr=127.0.0.1", "--master-port=29517", "-m", "autoreparam_amd.main"])):
+                                   "--master-addr=127.0.0.1", "--master-port=%d" % _free_port(), "-m", "autoreparam_amd.main"])):
         d = str(tmp_path / tag)
         base = ["--model=radon", "--dataset=MN", "--method=CP", "--results_dir=" + d, "--num_chains=128", "--seed=3"]
         hm = ["--num_samples=200", "--num_burnin_steps=200", "--num_adaptation_steps=150", "--num_leapfrog_steps=4"]
@@ -99,7 +105,7 @@ def test_two_rank_vi_runs_on_rank_zero_only(tmp_path):
     d1, d2 = str(tmp_path / "one"), str(tmp_path / "two")
     subprocess.check_call([sys.executable, "-m", "autoreparam_amd.main"] + base + ["--results_dir=" + d1], env=env, cwd=ROOT)
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                           "--master-addr=127.0.0.1", "--master-port=29521", "-m", "autoreparam_amd.main"] + base +
+                           "--master-addr=127.0.0.1", "--master-port=%d" % _free_port(), "-m", "autoreparam_amd.main"] + base +
                           ["--results_dir=" + d2], env=env, cwd=ROOT, timeout=600)
     j1, j2 = (json.load(open(os.path.join(d, "CP_tied.json"))) for d in (d1, d2))
     for k in ("elbo", "learning_rate", "learned_variational_params", "initial_step_size"):
@@ -112,14 +118,19 @@ def test_two_rank_bench_line(scaling):
     with the whole-job value, both ranks' kernel times and the end-of-run exchange."""
     env = _two_rank_env()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr=127.0.0.1",
-           "--master-port=29519", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--master-port=%d" % _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--chains", "4096", "--transitions", "32", "--scaling", scaling]
     r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["scaling"] == scaling and j["steps"] == 3
+    assert j["n_gpus"] == 2 and j["ranks"] == 2 and j["scaling"] == scaling and j["steps"] == 3
+    # the transport is reported as what it was: RCCL on a two-GPU box, gloo when both ranks share the test box's GPU
+    if torch.cuda.device_count() >= 2:
+        assert j["dist_backend"] == "nccl" and j["rccl_ranks"] == 2
+    else:
+        assert j["dist_backend"] == "gloo" and "rccl_ranks" not in j
     per_gpu = 4096 if scaling == "weak" else 2048
     assert j["config"]["chains_per_gpu"] == per_gpu and j["config"]["chains_total"] == 2 * per_gpu
     assert len(j["kernel_ms_per_rank"]) == 2 and min(j["kernel_ms_per_rank"]) > 0
