@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "host_common.h"
+#include "ess_tail.h"
 
 namespace arp {
 
@@ -290,7 +291,7 @@ __device__ __forceinline__ double ess_tail_cooperative(const float* __restrict__
 constexpr int kEssRows = 36;   // LDS floats per lane: the first sweep's totals, then (per wave) a whole series + padding
 
 __global__ __launch_bounds__(256, ARP_ESS_MINB) void ess_kernel(const float* __restrict__ trace, long long S, long long n,
-                                                                long long stride, float* __restrict__ ess) {
+                                                                long long stride, float* __restrict__ ess, EssDefer defer) {
   constexpr int W = kEssWin, WF = kEssFar;
   static_assert(W + 2 <= kEssRows, "the totals of the first sweep fit the lane's LDS column");
   __shared__ __attribute__((aligned(16))) float s_buf[kEssRows * 256];   // one block of kEssRows x 64 floats per wave
@@ -374,6 +375,22 @@ __global__ __launch_bounds__(256, ARP_ESS_MINB) void ess_kernel(const float* __r
       const double add = ess_tail_cooperative(trace, stride, S, idx_u, mean_u, __builtin_bit_cast(double, c0u), tail_from, wbuf, lane);
       if (lane == u) total += add;
     }
+  } else if (defer.count) {
+    // a series too long for the wave's LDS block, and the caller gave a workspace: what is still positive goes to the
+    // work list of the matrix-core tail (ess_tail.h), which writes its ESS
+    const unsigned long long m = __ballot(!done);
+    if (m) {
+      const int leader = __builtin_ctzll(m);
+      unsigned base = 0;
+      if (lane == leader) base = atomicAdd(defer.count, (unsigned)__builtin_popcountll(m));
+      base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+      if (!done) {
+        const unsigned pos = base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        defer.idx[pos] = (unsigned)i; defer.mean[pos] = mean; defer.c0[pos] = c0; defer.total[pos] = total;
+        defer.from[pos] = tail_from;
+      }
+    }
+    if (!done) return;
   } else {
     // a series too long for the wave's LDS block: per lane, lags kb+1 .. kb+16 per sweep, leading and lagged stream read
     for (long long kb = tail_from; kb < S && !done; kb += WF) {
@@ -394,17 +411,79 @@ __global__ __launch_bounds__(256, ARP_ESS_MINB) void ess_kernel(const float* __r
 
 }  // namespace arp
 
-extern "C" int arp_ess(const float* trace, int64_t n_samples, int64_t n_series, int64_t row_stride, float* ess,
-                       void* stream) {
+namespace arp {
+// workspace layout of arp_ess_ws: [count | idx | mean | c0 | total | from | rows], every array 256-byte aligned
+struct EssWsLayout {
+  size_t off_idx, off_mean, off_c0, off_total, off_from, off_rows;
+  static size_t up(size_t x) { return (x + 255) & ~(size_t)255; }
+  explicit EssWsLayout(int64_t n) {
+    off_idx = 256;
+    off_mean = off_idx + up((size_t)n * 4);
+    off_c0 = off_mean + up((size_t)n * 4);
+    off_total = off_c0 + up((size_t)n * 8);
+    off_from = off_total + up((size_t)n * 8);
+    off_rows = off_from + up((size_t)n * 4);
+  }
+};
+}  // namespace arp
+
+extern "C" int64_t arp_ess_workspace_bytes(int64_t n_samples, int64_t n_series) {
+  using namespace arp;
+  if (n_samples <= 0 || n_series <= 0) return 0;
+  if (n_samples + 72 <= kEssRows * 64) return 0;          // short series finish inside the first-stage kernel
+  return (int64_t)(EssWsLayout(n_series).off_rows + (size_t)n_series * (size_t)ess_row_floats(n_samples) * 4);
+}
+
+extern "C" int arp_ess_ws(const float* trace, int64_t n_samples, int64_t n_series, int64_t row_stride, float* ess,
+                          void* workspace, int64_t workspace_bytes, void* stream) {
   using namespace arp;
   if (!trace || !ess || n_samples <= 0 || n_series <= 0 || row_stride < n_series) {
     set_error("arp_ess: trace/ess, n_samples > 0, n_series > 0 and row_stride >= n_series are required");
     return 1;
   }
   if (n_series >= (1ll << 30)) { set_error("arp_ess: at most 2^30 - 1 series per call (32-bit lane offsets)"); return 1; }
+  hipStream_t st = (hipStream_t)stream;
   const long long blocks = (n_series + 255) / 256;
-  hipLaunchKernelGGL(ess_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, trace, (long long)n_samples,
-                     (long long)n_series, (long long)row_stride, ess);
+  EssDefer D{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  long long rows_cap = 0;
+  const bool long_series = n_samples + 72 > kEssRows * 64;
+  const long long SR = ess_row_floats(n_samples);
+  if (long_series && workspace) {
+    if (((uintptr_t)workspace & 255) != 0) { set_error("arp_ess_ws: the workspace must be 256-byte aligned"); return 1; }
+    const EssWsLayout Lw(n_series);
+    rows_cap = workspace_bytes > (int64_t)Lw.off_rows ? ((workspace_bytes - (int64_t)Lw.off_rows) / (SR * 4)) & ~63ll : 0;
+    if (rows_cap < 64) {
+      set_error("arp_ess_ws: workspace too small (the work lists and at least 64 series rows: see arp_ess_workspace_bytes)");
+      return 1;
+    }
+    if (rows_cap > n_series) rows_cap = (n_series + 63) & ~63ll;
+    char* w = (char*)workspace;
+    D = EssDefer{(unsigned*)w, (unsigned*)(w + Lw.off_idx), (float*)(w + Lw.off_mean), (double*)(w + Lw.off_c0),
+                 (double*)(w + Lw.off_total), (int*)(w + Lw.off_from)};
+    ARP_HIP_OK(hipMemsetAsync(w, 0, 256, st));
+  }
+  hipLaunchKernelGGL(ess_kernel, dim3((unsigned)blocks), dim3(256), 0, st, trace, (long long)n_samples,
+                     (long long)n_series, (long long)row_stride, ess, D);
   ARP_HIP_OK(hipGetLastError());
+  if (D.count) {
+    // The listed series, `rows_cap` at a time; how many there are stays on the device (no host synchronisation): every
+    // chunk that could hold listed series is launched, and workgroups past the count leave at once.
+    float* rows = (float*)((char*)workspace + EssWsLayout(n_series).off_rows);
+    for (long long p0 = 0; p0 < n_series; p0 += rows_cap) {
+      const unsigned pmax = (unsigned)std::min<long long>(p0 + rows_cap, n_series);
+      const unsigned nrow = pmax - (unsigned)p0;
+      hipLaunchKernelGGL(ess_gather_kernel, dim3((nrow + 63) / 64, (unsigned)(SR / 64)), dim3(256), 0, st, trace,
+                         (long long)n_samples, (long long)row_stride, D, (unsigned)p0, pmax, rows);
+      hipLaunchKernelGGL(ess_tail_kernel, dim3(nrow), dim3(64), 0, st, (const float*)rows, (long long)n_samples, D,
+                         (unsigned)p0, pmax, ess);
+    }
+    ARP_HIP_OK(hipGetLastError());
+  }
   return 0;
+}
+
+extern "C" int arp_ess(const float* trace, int64_t n_samples, int64_t n_series, int64_t row_stride, float* ess,
+                       void* stream) {
+  // no workspace: long, slowly mixing series take the per-lane far sweeps (slow, but no memory is needed)
+  return arp_ess_ws(trace, n_samples, n_series, row_stride, ess, nullptr, 0, stream);
 }

@@ -31,9 +31,13 @@ _DEFS = [
     # build-specific additions (the reference is unseeded and single-device)
     ("seed", int, 0, "Seed of the sampler's counter-based RNG and of the variational initial states."),
     ("device", str, "cuda:0", "GPU to run on."),
-    ("trace_chunk_rows", int, None, "Force the streaming mode (statistics accumulated inside the kernels, no [S, C, D] "
-                                    "trace; batch length of the batch-means ESS = this / 8).  Default: automatic, only "
+    ("trace_chunk_rows", int, None, "Force the streaming mode (moments and batch means accumulated inside the kernels, "
+                                    "a whole trace only for --ess_chains chains; batch length of the batch-means ESS = "
+                                    "this / 8).  Default: automatic, only "
                                     "when the trace does not fit in HBM."),
+    ("ess_chains", int, 1024, "Streaming mode: the chains with global id below this keep their whole [S, k, D] trace on "
+                              "the device, and the reported ESS is the reference's autocorrelation ESS of those chains "
+                              "(the batch-means figure of all chains is written next to it)."),
     ("lanes_per_chain", int, 0, "Lanes of a wave64 a chain is spread over (0 = automatic)."),
 ]
 

@@ -260,12 +260,42 @@ def _trace_plan(S, C, D, dev, force_chunk=None):
     return min(rows, S), True
 
 
-def _sample(run_segment, st, S, B, thin, C, D, dev, keep_chains, n_acc, chunk_rows=None):
+class EssInfo(object):
+    """What a sampling run's ESS is: `estimator` ("autocorrelation" = tfp.mcmc.effective_sample_size's definition, the
+    reference's; "batch_means(b)" only when not even a small chain subset's trace fits), `chains` = the number of this
+    rank's chains it was computed on (all of them with a whole trace; the chains with global id < --ess_chains in
+    streaming mode), and -- streaming mode -- `batch_means`, the batch-means ESS [C, D] of EVERY local chain from the
+    in-kernel accumulators with its batch length, reported next to the autocorrelation figure, never instead of it."""
+
+    def __init__(self, estimator, chains, batch_means=None, batch=None, kernel_ms=None):
+        self.estimator, self.chains, self.batch_means, self.batch, self.kernel_ms = estimator, chains, batch_means, batch, kernel_ms
+
+
+def _ess_subset(S, C, D, dev, chain_offset, ess_chains):
+    """(k_total, k_local): the chains whose whole trace a streaming run keeps for the autocorrelation ESS are those with
+    GLOBAL id < k_total, so the subset -- hence the reported figure -- does not depend on how many ranks share the job;
+    k_local of them are this rank's.  k_total = --ess_chains, halved until [S, k_total, D] fits in 40 % of the device's
+    memory (a function of the device model only: every rank of a job takes the same decision); 0 when not even 64 chains
+    fit, or --ess_chains=0 asks for batch means only."""
+    k = max(int(ess_chains), 0)
+    cap = 0.4 * torch.cuda.get_device_properties(dev).total_memory
+    while k > 64 and 4.0 * S * k * D > cap:
+        k //= 2
+    if 4.0 * S * k * D > cap:
+        k = 0
+    return k, int(min(C, max(k - int(chain_offset), 0)))
+
+
+def _sample(run_segment, st, S, B, thin, C, D, dev, keep_chains, n_acc, chunk_rows=None, chain_offset=0, ess_chains=1024):
     """Drive `run_segment(n_steps, n_burnin, trace, accept_buffers, **extra)` over the whole
     sample_chain schedule (result r after transition 1 + B + r*thin).  Whole-trace mode keeps the
-    reference's [S, C, D] trace; when that does not fit in HBM (or --trace_chunk_rows forces it) the
-    kernels accumulate the statistics themselves (arp_hmc_io.stats) and only the first `keep_chains`
-    chains keep a trace.  Returns (trace or None, kept host trace, accept arrays, ess [C, D], estimator, moments):
+    reference's [S, C, D] trace and takes tfp's autocorrelation ESS of every series (arp_ess).  When that does not
+    fit in HBM (or --trace_chunk_rows forces it) the run STREAMS: the kernels accumulate the per-chain moments and batch
+    means themselves (arp_hmc_io.stats) for all chains, and the chains with global id < --ess_chains keep their whole
+    [S, k, D] trace on the device, on which the same autocorrelation ESS is taken -- the reference's estimator on a
+    chain subset (its mean over chains has a standard error of ~ 1/sqrt(k) of the spread between chains), with the
+    batch-means figure of all chains next to it.
+    Returns (trace or None, kept trace (device, [S, k, D]) or None, accept arrays, ess [k, D], EssInfo, moments):
     moments = (mean, var) [C, D] float64 from the in-kernel accumulators in streaming mode, None with a whole trace."""
     rows, streaming = _trace_plan(S, C, D, dev, chunk_rows)
     total = 1 + B + thin * (S - 1)
@@ -279,24 +309,34 @@ def _sample(run_segment, st, S, B, thin, C, D, dev, keep_chains, n_acc, chunk_ro
             done += n
         ess = util.effective_sample_size(trace)
         # the whole trace is returned: moments are the caller's to take
-        return trace, None, [_DeviceAccept(a) for a in accs], ess, "autocorrelation", None
+        return trace, None, [_DeviceAccept(a) for a in accs], ess, EssInfo("autocorrelation", C), None
     batch = max(8, min(rows, S) // 8)
+    k_total, k_ess = _ess_subset(S, C, D, dev, chain_offset, ess_chains)
+    k = max(k_ess, keep_chains)            # --num_chains_to_save chains keep their trace on every rank, as before
     stats = torch.zeros(6, C, D, dtype=torch.float32, device=dev)
-    kept = torch.zeros(S, keep_chains, D, dtype=torch.float32, device=dev)
+    kept = torch.zeros(S, k, D, dtype=torch.float32, device=dev)
     racc = [torch.zeros(C, dtype=torch.int32, device=dev) for _ in range(n_acc)]
-    extra = dict(stats=stats, stats_batch=batch, n_samples=S, trace_chains=keep_chains)
-    for k in range(n_acc):
-        extra["rec_accept%d" % k] = racc[k]
+    extra = dict(stats=stats, stats_batch=batch, n_samples=S, trace_chains=k)
+    for j in range(n_acc):
+        extra["rec_accept%d" % j] = racc[j]
     done = 0
     while done < total:
         n = min(_MAX_STEPS_PER_LAUNCH, total - done)
         run_segment(n, B, kept, [None] * n_acc, **extra)
         done += n
-    mean, var, ess = _engine.stats_summary(stats, S, batch)
+    mean, var, ess_bm = _engine.stats_summary(stats, S, batch)
+    ess_bm = ess_bm.to(torch.float32)
+    if k_total > 0:
+        # [k_ess, D]; empty on a rank that owns none of the subset (the summaries gather variable-length blocks)
+        ess = util.effective_sample_size(kept[:, :k_ess]) if k_ess > 0 else torch.empty(0, D, dtype=torch.float32, device=dev)
+        info = EssInfo("autocorrelation", k_ess, batch_means=ess_bm, batch=batch)
+    else:
+        # --ess_chains=0, or not even 64 chains' traces fit next to the run: batch means are all there is (the key says so)
+        ess = ess_bm
+        info = EssInfo("batch_means(%d)" % batch, C, batch_means=ess_bm, batch=batch)
     # per-chain posterior mean / variance of every (centred) element from the in-kernel accumulators, [C, D] float64
     # (build-specific: the reference would take them from the [S, C, D] trace this mode does not materialise)
-    return None, kept.cpu().numpy(), [a.cpu().numpy()[np.newaxis, :] for a in racc], ess.to(torch.float32), \
-        "batch_means(%d)" % batch, (mean, var)
+    return None, kept, [a.cpu().numpy()[np.newaxis, :] for a in racc], ess, info, (mean, var)
 
 
 def _check_trace_fits(S, C, D, dev):
@@ -334,9 +374,10 @@ def hmc(target, model_config, step_size_init, initial_states, reparam, flags=FLA
                     lanes=flags.lanes_per_chain, rec_accept=rec_accept0, **extra)
 
     keep = max(1, int(flags.num_chains_to_save))
-    hmc.last_ess_estimator = hmc.last_moments = None      # nothing stale survives a run that raises
-    trace, kept, accs, ess_flat, estimator, moments = _sample(run_segment, st, S, B, thin, C, spec.D, dev, min(keep, C), 1,
-                                                             getattr(flags, "trace_chunk_rows", None))
+    hmc.last_ess_estimator = hmc.last_moments = hmc.last_ess_info = None      # nothing stale survives a run that raises
+    trace, kept, accs, ess_flat, info, moments = _sample(run_segment, st, S, B, thin, C, spec.D, dev, min(keep, C), 1,
+                                                        getattr(flags, "trace_chunk_rows", None), chain_offset,
+                                                        getattr(flags, "ess_chains", 1024))
     torch.cuda.synchronize(dev)
     ess = spec.unpack(ess_flat.cpu().numpy())
     step_mult = st.adapt[:, 0].cpu().numpy()
@@ -345,11 +386,13 @@ def hmc(target, model_config, step_size_init, initial_states, reparam, flags=FLA
         states_transformed = _device_parts(spec, trace)
         states_orig = _LazyOriginalStates(eng, spec, trace, 0)
     else:
-        # streaming run: only the first `num_chains_to_save` chains keep their trace, is_accepted
-        # holds per-chain counts ([1, C]; np.sum is unchanged) and ESS comes from batch means
-        states_transformed = spec.unpack(kept)
+        # streaming run: only the chains with global id < --ess_chains keep their trace ([S, k, D], left on the device),
+        # is_accepted holds per-chain counts ([1, C]; np.sum is unchanged) and `ess` is [k, *event]: the reference's
+        # autocorrelation ESS of those chains (EssInfo; the batch-means figure of all chains rides along in it)
+        states_transformed = _device_parts(spec, kept)
         states_orig = None
-    hmc.last_ess_estimator = estimator
+    hmc.last_ess_estimator = info.estimator
+    hmc.last_ess_info = info
     hmc.last_moments = moments
     return states_orig, kernel_results, states_transformed, ess
 
@@ -381,15 +424,17 @@ def hmc_interleaved(model_config, target_cp, target_ncp, num_leapfrog_steps_cp, 
                             trace_centered=False, lanes=flags.lanes_per_chain, **extra)
 
     keep = max(1, int(flags.num_chains_to_save))
-    hmc_interleaved.last_ess_estimator = hmc_interleaved.last_moments = None
-    trace, kept, accs, ess_flat, estimator, moments = _sample(run_segment, st, S, B, thin, C, spec.D, dev, min(keep, C), 2,
-                                                             getattr(flags, "trace_chunk_rows", None))
+    hmc_interleaved.last_ess_estimator = hmc_interleaved.last_moments = hmc_interleaved.last_ess_info = None
+    trace, kept, accs, ess_flat, info, moments = _sample(run_segment, st, S, B, thin, C, spec.D, dev, min(keep, C), 2,
+                                                        getattr(flags, "trace_chunk_rows", None), chain_offset,
+                                                        getattr(flags, "ess_chains", 1024))
     torch.cuda.synchronize(dev)
-    states = _device_parts(spec, trace) if trace is not None else spec.unpack(kept)
+    states = _device_parts(spec, trace if trace is not None else kept)
     ess = spec.unpack(ess_flat.cpu().numpy())
     kr = InterleavedKernelResults(
         cp_results=KernelResults(HmcInnerResults(accs[0]), st.adapt[:, 0].cpu().numpy(), st.step),
         ncp_results=KernelResults(HmcInnerResults(accs[1]), st.adapt1[:, 0].cpu().numpy(), st.step))
-    hmc_interleaved.last_ess_estimator = estimator
+    hmc_interleaved.last_ess_estimator = info.estimator
+    hmc_interleaved.last_ess_info = info
     hmc_interleaved.last_moments = moments
     return states, kr, ess

@@ -124,6 +124,33 @@ def _param_names(model_config):
     return list(model_config.model.part_names)
 
 
+def _ess_chain_count(info, model_config, flags):
+    """Chains of the whole job the ESS parts cover: all of them, or None for the chain subset of a streaming run
+    (inference.EssInfo; the per-rank block lengths are then gathered with the values)."""
+    if info is not None and info.batch_means is not None and info.estimator == "autocorrelation":
+        return None
+    return flags.num_chains
+
+
+def _ess_report(info, model_config, flags, dev):
+    """Build-specific keys next to the reference's `ess_min`: which estimator it is and on how many chains, and -- for a
+    streaming run -- the batch-means figure of ALL chains from the in-kernel accumulators.  (A collective when ws > 1:
+    every rank calls it.)"""
+    if info is None:
+        return {}
+    out = {"ess_estimator": info.estimator}
+    n_local = int(info.chains)
+    out["ess_chains"] = int(parallel.all_reduce_sum(float(n_local), dev).item())
+    if info.batch_means is not None:
+        norm = 1000.0 / (flags.num_samples * flags.num_leapfrog_steps)
+        bm = np.nan_to_num(info.batch_means.cpu().numpy()) * norm          # [C_local, D]
+        mins = parallel.all_gather_chains(bm.min(axis=1).astype(np.float32), flags.num_chains, dev).cpu().numpy()
+        m, sem = parallel.mean_sem(mins)
+        out.update(ess_min_batch_means=m, sem_min_batch_means=sem, batch_means_batch=int(info.batch))
+        util.print_("    batch-means ESS of all {} chains (batches of {}): {} +/- {}".format(len(mins), info.batch, m, sem))
+    return out
+
+
 def run_hmc(model_config, results_dir, file_path, tuning=False, flags=FLAGS):
     """reference main.py:296-398"""
     if os.path.exists(file_path):
@@ -162,12 +189,16 @@ def run_hmc(model_config, results_dir, file_path, tuning=False, flags=FLAGS):
     is_accepted = kernel_results.inner_results.is_accepted
     mcmc_time = time.time() - start_time
     normalized_ess_final = [1000 * e / (flags.num_samples * flags.num_leapfrog_steps) for e in ess_final]
+    info = getattr(inference.hmc, "last_ess_info", None)
+    dev = flags.device if ws > 1 else None
+    n_ess = _ess_chain_count(info, model_config, flags)          # None: a chain subset (streaming run)
     ess_min, sem_min, acceptance_rate, _ = parallel.summarize(
-        normalized_ess_final, is_accepted, flags.num_samples, flags.num_chains, device=flags.device if ws > 1 else None)
+        normalized_ess_final, is_accepted, flags.num_samples, flags.num_chains, device=dev, ess_chains_total=n_ess)
     util.print_("ESS per 1000 gradients: {} +/- {}".format(ess_min, sem_min))
+    extra = _ess_report(info, model_config, flags, dev)
     if ws > 1 and not tuning:
         # _ess.npz / _ess.txt hold every chain's per-element ESS: collect the other ranks' blocks (a collective: all ranks)
-        normalized_ess_final = parallel.gather_parts(normalized_ess_final, flags.num_chains, flags.device)
+        normalized_ess_final = parallel.gather_parts(normalized_ess_final, n_ess, flags.device)
     if rank != 0:
         return ess_min, sem_min, acceptance_rate, mcmc_time
     if tuning:
@@ -175,10 +206,10 @@ def run_hmc(model_config, results_dir, file_path, tuning=False, flags=FLAGS):
                          tuning_runs={"num_leapfrog_steps": flags.num_leapfrog_steps, "ess_min": float(ess_min),
                                       "sem_min": float(sem_min), "acceptance_rate": float(acceptance_rate),
                                       "mcmc_time": mcmc_time, "num_samples": flags.num_samples,
-                                      "num_burnin_steps": flags.num_burnin_steps})
+                                      "num_burnin_steps": flags.num_burnin_steps, **extra})
     else:
         save_hmc_results(file_path=file_path, ess_min=float(ess_min), sem_min=float(sem_min),
-                         acceptance_rate=float(acceptance_rate), mcmc_time_sec=mcmc_time)
+                         acceptance_rate=float(acceptance_rate), mcmc_time_sec=mcmc_time, **extra)
         save_ess(file_path_base=file_path[:-5], samples=samples, param_names=param_names,
                  normalized_ess_final=normalized_ess_final, num_chains_to_save=flags.num_chains_to_save)
     return ess_min, sem_min, acceptance_rate, mcmc_time
@@ -203,20 +234,23 @@ def run_interleaved_hmc_with_leapfrog_steps(model_config, results_dir, num_leapf
     is_accepted_ncp = kernel_results.ncp_results.inner_results.is_accepted
     normalized_ess_final = [1000 * e / (flags.num_samples * flags.num_leapfrog_steps) for e in ess_final]
     dev = flags.device if ws > 1 else None
+    info = getattr(inference.hmc_interleaved, "last_ess_info", None)
+    n_ess = _ess_chain_count(info, model_config, flags)
     ess_min, sem_min, acc_cp, _ = parallel.summarize(normalized_ess_final, is_accepted_cp, flags.num_samples,
-                                                     flags.num_chains, device=dev)
+                                                     flags.num_chains, device=dev, ess_chains_total=n_ess)
+    extra = _ess_report(info, model_config, flags, dev)
     acc_ncp = float(parallel.all_reduce_sum(float(np.sum(is_accepted_ncp)), dev).item()) * 100.0 / float(
         flags.num_samples * flags.num_chains)
     util.print_("ESS: {} +/- {}".format(ess_min, sem_min))
     if ws > 1:
-        normalized_ess_final = parallel.gather_parts(normalized_ess_final, flags.num_chains, flags.device)
+        normalized_ess_final = parallel.gather_parts(normalized_ess_final, n_ess, flags.device)
     # Only `[:, :num_chains_to_save]` of the samples is ever read again (save_ess).  Taking that slice to the host now
     # releases the [S, C, D] device trace before the next candidate leapfrog count allocates its own (two 18.6 GB traces
     # alive at once at the headline size, and a fresh device allocation of that size can cost half a second).
     k = max(0, int(flags.num_chains_to_save))
     states = [np.asarray(s[:, :k]) for s in states] if k > 0 else [np.zeros((flags.num_samples, 0), np.float32) for _ in states]
     del kernel_results, is_accepted_cp, is_accepted_ncp
-    return (ess_min, sem_min, acc_cp, acc_ncp, mcmc_time, states, normalized_ess_final)
+    return (ess_min, sem_min, acc_cp, acc_ncp, mcmc_time, states, normalized_ess_final, extra)
 
 
 def _first_existing(results_dir, names):
@@ -258,14 +292,14 @@ def run_interleaved_hmc(model_config, results_dir, file_path, flags=FLAGS):
             initial_step_size_ncp=initial_step_size_ncp, initial_states_cp=initial_states_cp, flags=flags)
         if float(res[0]) > best_ess_min or best_num_ls is None:
             best_ess_min, best_num_ls, results = float(res[0]), num_ls, res
-    ess_min, sem_min, acceptance_rate_cp, acceptance_rate_ncp, mcmc_time, samples, normalized_ess_final = results
+    ess_min, sem_min, acceptance_rate_cp, acceptance_rate_ncp, mcmc_time, samples, normalized_ess_final, extra = results
     flags.num_leapfrog_steps = best_num_ls + best_num_ls
     if parallel.world()[0] != 0:
         return results
     save_hmc_results(file_path=file_path, initial_step_size_ncp=initial_step_size_ncp,
                      initial_step_size_cp=initial_step_size_cp, num_leapfrog_steps=best_num_ls,
                      ess_min=float(ess_min), sem_min=float(sem_min), acceptance_rate_cp=float(acceptance_rate_cp),
-                     acceptance_rate_ncp=float(acceptance_rate_ncp), mcmc_time_sec=mcmc_time)
+                     acceptance_rate_ncp=float(acceptance_rate_ncp), mcmc_time_sec=mcmc_time, **extra)
     save_ess(file_path_base=file_path[:-5], samples=samples, param_names=param_names,
              normalized_ess_final=normalized_ess_final, num_chains_to_save=flags.num_chains_to_save)
     return results

@@ -45,7 +45,9 @@ def shard_states(parts, rank, world_size):
 
 
 def all_gather_chains(local, n_total, device=None):
-    """Concatenate per-chain values (first axis = local chains) from all ranks, in rank order."""
+    """Concatenate per-chain values (first axis = local chains) from all ranks, in rank order.  `n_total` = chains of
+    the whole job when every rank contributes its shard; None when the blocks have lengths only their owners know (the
+    ESS chain subset of a streaming run: the chains with global id < --ess_chains) -- the lengths are gathered first."""
     rank, ws = world()
     t = torch.as_tensor(local)
     if ws == 1:
@@ -53,7 +55,13 @@ def all_gather_chains(local, n_total, device=None):
     device = _collective_device(device)
     if device is not None:
         t = t.to(device)
-    sizes = [shard_bounds(n_total, r, ws)[1] - shard_bounds(n_total, r, ws)[0] for r in range(ws)]
+    if n_total is None:
+        mine = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+        got = [torch.zeros_like(mine) for _ in range(ws)]
+        dist.all_gather(got, mine)
+        sizes = [int(g.item()) for g in got]
+    else:
+        sizes = [shard_bounds(n_total, r, ws)[1] - shard_bounds(n_total, r, ws)[0] for r in range(ws)]
     mx = max(sizes)
     pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
@@ -74,12 +82,20 @@ def all_reduce_sum(value, device=None):
     return t
 
 
-def summarize(normalized_ess_parts, is_accepted, num_samples, num_chains_total, device=None):
+def min_ess_per_chain(ess_parts, num_chains_total, device=None):
+    """Per chain the minimum over all elements of all parts (reference util.get_min_ess), gathered over the ranks.
+    `num_chains_total` None: variable-length blocks (see all_gather_chains)."""
+    parts = [np.nan_to_num(np.asarray(e)) for e in ess_parts]
+    n = parts[0].shape[0]
+    local_min = np.min(np.stack([p.reshape(n, -1).min(axis=1) if n else np.zeros(0, p.dtype) for p in parts]), axis=0)
+    return all_gather_chains(torch.as_tensor(local_min, dtype=torch.float32), num_chains_total, device).cpu().numpy()
+
+
+def summarize(normalized_ess_parts, is_accepted, num_samples, num_chains_total, device=None, ess_chains_total=-1):
     """ess_min, sem_min (reference util.get_min_ess) and acceptance rate in percent
-    (main.py:372-373) over ALL chains, from each rank's local chains."""
-    local_min = np.min(np.stack([np.nan_to_num(np.asarray(e)).reshape(np.asarray(e).shape[0], -1).min(axis=1)
-                                 for e in normalized_ess_parts]), axis=0)
-    mins = all_gather_chains(torch.as_tensor(local_min, dtype=torch.float32), num_chains_total, device).cpu().numpy()
+    (main.py:372-373) over ALL chains, from each rank's local chains.  `ess_chains_total` = None when the ESS parts
+    cover a chain subset whose per-rank sizes differ (streaming runs); default: the same chains as everything else."""
+    mins = min_ess_per_chain(normalized_ess_parts, num_chains_total if ess_chains_total == -1 else ess_chains_total, device)
     acc = float(all_reduce_sum(float(np.sum(is_accepted)), device).item())
     ess_min = float(np.mean(mins))
     sem_min = float(np.std(mins) / np.sqrt(len(mins)))
@@ -92,3 +108,8 @@ def gather_parts(parts, num_chains_total, device=None):
     if world()[1] == 1:
         return [np.asarray(p) for p in parts]
     return [all_gather_chains(torch.as_tensor(np.asarray(p)), num_chains_total, device).cpu().numpy() for p in parts]
+
+
+def mean_sem(x):
+    x = np.asarray(x, np.float64)
+    return float(np.mean(x)), float(np.std(x) / np.sqrt(len(x)))

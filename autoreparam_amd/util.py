@@ -59,15 +59,32 @@ def effective_sample_size(states, max_chains_per_batch=None):
     if states.is_cuda and states.dtype == torch.float32:
         import ctypes as C
         from . import _lib
-        x = states if states.is_contiguous() else states.contiguous()
-        S, Cn, D = x.shape
+        S, Cn, D = states.shape
+        # a leading block of chains of a wider trace ([S, :k, D] of [S, K, D]) is taken in place: rows stay rows, the
+        # row stride says how far apart they are
+        in_place = states.is_contiguous() or (Cn > 0 and states.stride(2) == 1 and states.stride(1) == D and S > 1)
+        x = states if in_place else states.contiguous()
+        row_stride = x.stride(0) if S > 1 else Cn * D
         out = torch.empty(Cn, D, dtype=torch.float32, device=x.device)
+        L = _lib.lib()
         with torch.cuda.device(x.device):
+            # long traces (a streaming run's kept chains at the reference's 50 000 samples): slowly mixing series are
+            # finished on the matrix cores out of a workspace -- every series at once when that fits in a third of the
+            # free memory, in chunks otherwise
+            need = int(L.arp_ess_workspace_bytes(S, Cn * D))
+            ws = None
+            if need > 0:
+                free, _ = torch.cuda.mem_get_info(x.device)
+                lists = 28 * Cn * D + 4096
+                ws = torch.empty(max(min(need, int(free // 3)), lists + (64 * 4 + 256) * (S + 64)), dtype=torch.uint8,
+                                 device=x.device)
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-            _lib.check(_lib.lib().arp_ess(C.c_void_p(x.data_ptr()), S, Cn * D, Cn * D, C.c_void_p(out.data_ptr()),
-                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            _lib.check(L.arp_ess_ws(C.c_void_p(x.data_ptr()), S, Cn * D, row_stride, C.c_void_p(out.data_ptr()),
+                                    C.c_void_p(ws.data_ptr() if ws is not None else 0), ws.numel() if ws is not None else 0,
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
             ev[1].record()
+            del ws
         # bench.py reads the kernel time of the LAST call off these events (after the caller has synchronised anyway)
         effective_sample_size.last_events = ev + (4.0 * S * Cn * D,)
         return out

@@ -204,6 +204,17 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
  * auto-correlations cut at the first negative one.  A constant series gives NaN (0/0), as the reference's does. */
 int arp_ess(const float* trace, int64_t n_samples, int64_t n_series, int64_t row_stride, float* ess, void* stream);
 
+/* The same statistic with a caller-owned device workspace for LONG traces (the [S = 50 000][k D] trace of a streaming
+ * run's kept chains, inference.py:238-240 at main.py:101-110's default schedule): series that are still positively
+ * correlated after the coalesced sweeps (48 lags) are copied series-major into the workspace and finished on the matrix
+ * cores (csrc/ess_tail.h), instead of per-lane sweeps that re-read the trace 16 lags at a time (arp_ess: 5.5 s on the
+ * german-credit trace, this: see profiles/).  arp_ess_workspace_bytes is the size at which every series fits at once
+ * (0 when n_samples is short enough for the one-kernel path); a smaller workspace works (the listed series are taken in
+ * chunks) as long as the work lists (28 bytes per series) and 64 series rows fit.  256-byte aligned. */
+int64_t arp_ess_workspace_bytes(int64_t n_samples, int64_t n_series);
+int arp_ess_ws(const float* trace, int64_t n_samples, int64_t n_series, int64_t row_stride, float* ess,
+               void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Test hook: the step-size adaptation recurrence of the chain kernels on SCRIPTED log acceptance ratios
  * (tfp.mcmc.DualAveragingStepSizeAdaptation / SimpleStepSizeAdaptation as wired at inference.py:224-226, 288-306;
  * SURVEY.md 8c known answer (7)).  For each of `n` independent rows, applies the update after transitions

@@ -88,12 +88,24 @@ def _fake_engine(monkeypatch_target):
         samples = [np.broadcast_to(g.reshape((1, Cl) + (1,) * len(sh)).astype(np.float32), (S, Cl) + tuple(sh)).copy()
                    for sh in spec.part_shapes]
         kr = inference.KernelResults(inference.HmcInnerResults(acc), np.ones(Cl, np.float32), S)
-        return None, kr, samples, _ess_parts(spec, g)
+        fake_hmc.last_ess_info = inference.EssInfo("autocorrelation", Cl)
+        ess = _ess_parts(spec, g)
+        if getattr(flags, "trace_chunk_rows", None):
+            # a streaming run: the autocorrelation ESS covers the chains with GLOBAL id < --ess_chains (this rank's block
+            # of them may be empty), the batch-means ESS every local chain
+            import torch
+            k = int(min(Cl, max(int(flags.ess_chains) - chain_offset, 0)))
+            ess = [e[:k] for e in ess]
+            samples = [x[:, :max(k, int(flags.num_chains_to_save))] for x in samples]
+            bm = torch.as_tensor(np.concatenate([e.reshape(Cl, -1) for e in _ess_parts(spec, g)], axis=1) * 0.5)
+            fake_hmc.last_ess_info = inference.EssInfo("autocorrelation", k, batch_means=bm, batch=4)
+        return None, kr, samples, ess
 
     def fake_inter(model_config, target_cp, target_ncp, num_leapfrog_steps_cp, num_leapfrog_steps_ncp, step_size_cp,
                    step_size_ncp, initial_states_cp, flags=None, chain_offset=0):
         _, kr, samples, ess = fake_hmc(target_cp, model_config, step_size_cp, initial_states_cp, None, flags, chain_offset)
         acc1 = ~np.asarray(kr.inner_results.is_accepted)
+        fake_inter.last_ess_info = fake_hmc.last_ess_info
         return samples, inference.InterleavedKernelResults(kr, inference.KernelResults(
             inference.HmcInnerResults(acc1), kr.new_step_size, kr.step)), ess
 
@@ -122,6 +134,10 @@ def _cli_sequence(results_dir):
             phase(["--inference=HMCtuning", "--method=" + m, "--num_leapfrog_steps=%d" % L])
     out["hmc"] = phase(["--inference=HMC", "--method=CP"])
     out["inter"] = phase(["--inference=HMC", "--method=i"])
+    # streaming runs: the ESS chain subset lies on rank 0 alone (3 of 7 chains) / on both ranks (5 = 4 + 1)
+    out["hmc_s3"] = phase(["--inference=HMC", "--method=CP", "--trace_chunk_rows=8", "--ess_chains=3"])
+    out["hmc_s5"] = phase(["--inference=HMC", "--method=NCP", "--trace_chunk_rows=8", "--ess_chains=5"])
+    out["inter_s5"] = phase(["--inference=HMC", "--method=i", "--trace_chunk_rows=8", "--ess_chains=5"])
     return out
 
 
@@ -138,7 +154,9 @@ def _cli_worker(rank, ws, port, results_dir):
     out = _cli_sequence(results_dir)
     assert (out["vi_NCP"] is None) == (rank != 0)
     np.save(os.path.join(results_dir, "ret%d.npy" % rank), np.array([out["hmc"][0], out["hmc"][1], out["hmc"][2],
-                                                                      out["inter"][0], out["inter"][2], out["inter"][3]], np.float64))
+                                                                      out["inter"][0], out["inter"][2], out["inter"][3],
+                                                                      out["hmc_s3"][0], out["hmc_s5"][0], out["hmc_s5"][1],
+                                                                      out["inter_s5"][0]], np.float64))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -183,6 +201,14 @@ def test_cli_rank_logic_two_ranks_equal_one(tmp_path):
                 assert np.array_equal(va, vb), (k, kk)
             else:
                 assert va == vb or np.allclose(va, vb, rtol=1e-6), (k, kk, va, vb)
-    want = np.array([ref["hmc"][0], ref["hmc"][1], ref["hmc"][2], ref["inter"][0], ref["inter"][2], ref["inter"][3]])
+    want = np.array([ref["hmc"][0], ref["hmc"][1], ref["hmc"][2], ref["inter"][0], ref["inter"][2], ref["inter"][3],
+                     ref["hmc_s3"][0], ref["hmc_s5"][0], ref["hmc_s5"][1], ref["inter_s5"][0]])
+    # the streaming runs' extra keys: estimator, subset size, the batch-means figure of all 7 chains
+    import json
+    r = json.load(open(os.path.join(two, "CP_tied.json")))
+    assert r["ess_estimator"] == ["autocorrelation", "autocorrelation"] and r["ess_chains"] == [7, 3]
+    assert len(r["ess_min_batch_means"]) == 1 and r["batch_means_batch"] == [4]
+    assert a["CP_tied_ess.npz"]["theta"].shape == (3, 8)             # the last run's: the 3-chain subset
+    assert a["NCP_tied_ess.npz"]["theta"].shape == (5, 8) and np.array_equal(a["NCP_tied_ess.npz"]["theta"], b["NCP_tied_ess.npz"]["theta"])
     for r in range(2):   # every rank returns the statistics over ALL chains
         np.testing.assert_allclose(np.load(os.path.join(two, "ret%d.npy" % r)), want, rtol=1e-6)

@@ -84,28 +84,63 @@ def test_cvip_then_dvip_and_interleaved(gpu, tmp_path):
 
 
 def test_streaming_trace_mode_equals_whole_trace(gpu):
-    """inference.hmc with a chunked trace (--trace_chunk_rows) draws the same samples as the
-    whole-trace run: kept chains, acceptance totals and moments agree; ESS estimators are close."""
+    """inference.hmc in streaming mode (--trace_chunk_rows) draws the same samples as the whole-trace run, and its ESS
+    is the SAME estimator -- tfp's autocorrelation ESS, here on the chains with global id < --ess_chains: bitwise the
+    whole-trace figures of those chains; the batch-means ESS of all chains rides along, it does not replace it."""
     from autoreparam_amd import flags as flags_mod, graphs, inference, models, util
     cfg = models.get_model_by_name("radon", "MN")
     sp = cfg.model
     f = flags_mod.FlagValues()
-    f.num_chains, f.num_samples, f.num_burnin_steps, f.num_adaptation_steps, f.num_leapfrog_steps = 64, 400, 100, 80, 4
+    f.num_chains, f.num_samples, f.num_burnin_steps, f.num_adaptation_steps, f.num_leapfrog_steps = 96, 400, 100, 80, 4
     f.num_chains_to_save = 5
     target, *_ = graphs.make_cp_graph(cfg, flags=f)
     rs = np.random.RandomState(0)
-    init = [0.1 * rs.randn(64, *s).astype(np.float32) for s in sp.part_shapes]
+    init = [0.1 * rs.randn(96, *s).astype(np.float32) for s in sp.part_shapes]
     step = [0.15] * 3 + [np.full(85, 0.3)]
     _, kr_a, st_a, ess_a = inference.hmc(target, cfg, step, init, "CP", flags=f)
-    assert inference.hmc.last_ess_estimator == "autocorrelation"
-    f2 = f.copy(); f2.trace_chunk_rows = 96
-    so, kr_b, st_b, ess_b = inference.hmc(target, cfg, step, init, "CP", flags=f2)
-    assert inference.hmc.last_ess_estimator.startswith("batch_means") and so is None
-    for a, b in zip(st_a, st_b):
-        assert b.shape[1] == 5 and np.array_equal(a[:, :5], b)          # bitwise: same chains, same streams
-    assert np.sum(kr_a.inner_results.is_accepted) == np.sum(kr_b.inner_results.is_accepted)
-    ma, mb = util.get_min_ess(ess_a)[0], util.get_min_ess(ess_b)[0]
-    assert 0.4 < mb / ma < 2.5
+    assert inference.hmc.last_ess_estimator == "autocorrelation" and inference.hmc.last_ess_info.chains == 96
+    for k_ess in (1024, 70, 0):
+        f2 = f.copy(); f2.trace_chunk_rows = 96; f2.ess_chains = k_ess
+        so, kr_b, st_b, ess_b = inference.hmc(target, cfg, step, init, "CP", flags=f2)
+        info = inference.hmc.last_ess_info
+        assert so is None and info.batch_means.shape == (96, sp.D) and info.batch == 12
+        k = min(k_ess, 96)
+        for a, b in zip(st_a, st_b):
+            assert b.shape[1] == max(k, 5) and np.array_equal(np.asarray(a[:, :5]), np.asarray(b[:, :5]))   # bitwise: same chains, same streams
+        assert np.sum(kr_a.inner_results.is_accepted) == np.sum(kr_b.inner_results.is_accepted)
+        if k_ess:
+            assert info.estimator == "autocorrelation" and info.chains == k
+            for a, b in zip(ess_a, ess_b):
+                assert b.shape[0] == k and np.array_equal(np.asarray(a)[:k], np.asarray(b))
+        else:   # --ess_chains=0: batch means only, and the estimator's name says so
+            assert info.estimator == "batch_means(12)" and ess_b[0].shape[0] == 96
+
+
+def test_batch_means_agree_with_autocorrelation_where_both_fit(gpu):
+    """One streaming run yields both estimators on the same samples (--ess_chains >= C): with batches much longer than
+    the autocorrelation time, the integrated autocorrelation time tau = S / ESS per element, averaged over chains, agrees
+    between tfp's autocorrelation estimator (arp_ess on the kept trace) and the kernels' batch means to 10 %."""
+    import torch
+    from autoreparam_amd import flags as flags_mod, graphs, inference, models
+    cfg = models.get_model_by_name("radon", "MN")
+    sp = cfg.model
+    f = flags_mod.FlagValues()
+    C, S = 512, 8192
+    f.num_chains, f.num_samples, f.num_burnin_steps, f.num_adaptation_steps, f.num_leapfrog_steps = C, S, 600, 500, 4
+    f.trace_chunk_rows, f.ess_chains = 2048, C                       # batches of 256 samples: 32 of them
+    target, *_ = graphs.make_cp_graph(cfg, flags=f)
+    rs = np.random.RandomState(1)
+    init = [0.1 * rs.randn(C, *s).astype(np.float32) for s in sp.part_shapes]
+    step = [0.15] * 3 + [np.full(85, 0.3)]
+    _, kr, st, ess = inference.hmc(target, cfg, step, init, "CP", flags=f)
+    info = inference.hmc.last_ess_info
+    assert info.estimator == "autocorrelation" and info.chains == C and info.batch == 256
+    ac = torch.as_tensor(sp.pack([np.asarray(e) for e in ess])).double()      # [C, D]
+    bm = info.batch_means.cpu().double()
+    tau_ac, tau_bm = (S / ac).mean(dim=0), (S / bm).mean(dim=0)
+    assert tau_ac.max() < 40.0                                       # batches of 256 are long against every series
+    ratio = (tau_bm / tau_ac).numpy()
+    assert np.abs(ratio - 1.0).max() < 0.10, (ratio.min(), ratio.max())
 
 
 def test_config3_full_size_german_dvip(gpu, tmp_path):
@@ -125,7 +160,8 @@ def test_config3_full_size_german_dvip(gpu, tmp_path):
     hm = ["--num_samples=%d" % S, "--num_burnin_steps=%d" % burn, "--num_adaptation_steps=1200", "--num_leapfrog_steps=8",
           "--trace_chunk_rows=64", "--num_chains_to_save=4"]
     res = _run(base + ["--inference=HMC", "--method=dVIP"] + hm)
-    assert inference.hmc.last_ess_estimator.startswith("batch_means")
+    info = inference.hmc.last_ess_info
+    assert info.estimator == "autocorrelation" and info.chains == 1024 and info.batch_means.shape == (16384, 125)
     ess_min, sem_min, acc, mcmc_time = res
     assert 55 < acc < 95 and ess_min > 0
     mean_c, var_c = inference.hmc.last_moments                 # [C, D] per-chain moments from the kernels' accumulators
@@ -141,6 +177,9 @@ def test_config3_full_size_german_dvip(gpu, tmp_path):
     assert np.abs(sd / sd_g - 1).max() < 0.12
     r = json.load(open(os.path.join(d, "dVIP_eig_tied.json")))
     assert len(r["ess_min"]) == 1 and len(r["mcmc_time_sec"]) == 1
+    # the reference's key holds the reference's estimator; the batch-means figure of all chains sits next to it
+    assert r["ess_estimator"] == ["autocorrelation"] and r["ess_chains"] == [1024] and r["ess_min_batch_means"][0] > 0
+    assert np.load(os.path.join(d, "dVIP_eig_tied_ess.npz"))["beta"].shape == (1024, 62)
     tr = np.load(os.path.join(d, "dVIP_eig_tied_traces.npz"))
     assert tr["beta"].shape == (S, 4, 62)
 

@@ -164,3 +164,45 @@ def test_native_ess_matches_oracle_and_ar1(gpu):
     # series slow enough to need lag sweeps past the first window (rho = 0.98: ~ 100 positive lags)
     slow = torch.as_tensor(ess_ref.ar1(3000, (16, 3), [0.98, 0.95, 0.5], seed=7), dtype=torch.float32)
     np.testing.assert_allclose(util.effective_sample_size(slow.to(gpu)).cpu().numpy(), ess_ref.ess_fft(slow.numpy()), rtol=2e-3)
+
+
+def test_long_series_ess_on_the_matrix_cores(gpu):
+    """arp_ess_ws: series longer than the one-kernel path holds in LDS (S + 72 > 2 304) that are still positively
+    correlated after the coalesced sweeps are finished by ess_tail_kernel (Toeplitz blocks on v_mfma_f32_16x16x4_f32)
+    out of a caller-owned workspace -- against the float64 FFT oracle, against the workspace-free per-lane route of
+    arp_ess, with the listed series taken in one chunk and in many, and for a leading block of a wider trace."""
+    import ctypes as C
+    from oracle import ess_ref
+    from autoreparam_amd import util, _lib
+    S, Cn, D = 6000, 24, 5
+    rho = np.array([0.995, 0.97, 0.5, 0.9, -0.2])              # cut lags from ~ 1 000 down to 0
+    x64 = ess_ref.ar1(S, (Cn, D), rho, seed=11) * [1.0, 4.0, 0.1, 30.0, 1.0] + [0.0, -20.0, 5.0, 1e3, 0.0]
+    x = torch.as_tensor(x64, dtype=torch.float32)
+    xd = x.to(gpu)
+    ref = ess_ref.ess_fft(x.numpy())
+    got = util.effective_sample_size(xd).cpu().numpy()          # with a workspace (util allocates it)
+    np.testing.assert_allclose(got, ref, rtol=2e-3)
+    L = _lib.lib()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n = Cn * D
+    out = torch.empty(Cn, D, device=gpu)
+    _lib.check(L.arp_ess(C.c_void_p(xd.data_ptr()), S, n, n, C.c_void_p(out.data_ptr()), stream))   # no workspace
+    np.testing.assert_allclose(out.cpu().numpy(), got, rtol=1e-4)
+    # a workspace that holds the lists and 64 rows: the 72 listed series go in two chunks -- bitwise the one-chunk result
+    need = int(L.arp_ess_workspace_bytes(S, n))
+    assert need > 4 * n * S
+    small = torch.empty(28 * n + 4096 + 64 * 4 * ((S + 63) // 64 * 64) + 4096, dtype=torch.uint8, device=gpu)
+    out2 = torch.empty(Cn, D, device=gpu)
+    _lib.check(L.arp_ess_ws(C.c_void_p(xd.data_ptr()), S, n, n, C.c_void_p(out2.data_ptr()), C.c_void_p(small.data_ptr()),
+                            small.numel(), stream))
+    assert np.array_equal(out2.cpu().numpy(), got)
+    tiny = torch.empty(1024, dtype=torch.uint8, device=gpu)
+    assert L.arp_ess_ws(C.c_void_p(xd.data_ptr()), S, n, n, C.c_void_p(out2.data_ptr()), C.c_void_p(tiny.data_ptr()),
+                        tiny.numel(), stream) != 0 and b"workspace too small" in L.arp_last_error()
+    assert L.arp_ess_workspace_bytes(1000, 10 ** 6) == 0        # short series never need one
+    # leading block of chains of a wider trace, taken in place (a streaming run's kept trace)
+    sub = util.effective_sample_size(xd[:, :7, :]).cpu().numpy()
+    assert np.array_equal(sub, got[:7])
+    # a series that never decorrelates within the trace (a trend): every lag positive until the weights run out
+    t = torch.linspace(0, 1, 2500, device=gpu).reshape(-1, 1, 1) + 0.01 * torch.randn(2500, 2, 3, device=gpu)
+    np.testing.assert_allclose(util.effective_sample_size(t).cpu().numpy(), ess_ref.ess_fft(t.cpu().numpy()), rtol=5e-3)
