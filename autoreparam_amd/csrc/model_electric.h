@@ -64,8 +64,14 @@ struct ElectricLane {
   float si[kElG], cs[kElG];   // 1/100^b and 100^(1-b) of b_k
   int slot, P;
 
-  // table entry of (slice i, slot): [wm0..3][og0..3][n0 y0 n1 y1][ss - - -], 64 bytes
-  static constexpr int kEntry = 16;
+  // table entry of (slice i, slot): [wm0..3][og0..3][n0 y0 n1 y1][ss - - -], 20 floats apart.
+  // Bank conflicts (MI355X_MICROARCH.md, LDS): a ds_read_b128 is served in groups of 16 lanes over 64 banks; the K
+  // distinct entries a group touches must fall on distinct 4-bank windows.  At round 3's stride of 16 dwords slots s
+  // and s + 4 shared a window (2-way on each of the three b128 reads) and the lone `ss` went out as a ds_read_b32
+  // (groups of 32 lanes over 32 banks: 4-way): 18 extra LDS cycles per pair and gradient on top of 14
+  // (SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS = 4.0).  20 s mod 64 is a permutation of the multiples of 4 for 8 and for 16
+  // lanes per chain, and `ss` is read as the fourth b128.
+  static constexpr int kEntry = 20;
   static ARP_DEV float* onehot_table() {
     __shared__ __attribute__((aligned(16))) float tab[NL * K * kEntry];
     return tab;
@@ -85,10 +91,14 @@ struct ElectricLane {
   }
   // the pair's two cells: counts and means of the control / treated scores, pooled within-cell sum of squares
   ARP_DEV void cells(int i, float& n0, float& y0, float& n1, float& y1, float& ss) const {
-    const float* e = onehot_table() + entry(i);
-    const float4 c = reinterpret_cast<const float4*>(e)[2];
+    const float4* e = reinterpret_cast<const float4*>(onehot_table() + entry(i));
+    const float4 c = e[2];
+    float4 d = e[3];
+    // the whole quad passes through an (empty) asm statement, so the compiler cannot narrow the read to a ds_read_b32
+    // (served over 32 banks: 4-way conflicts at this stride) again
+    asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
     n0 = c.x; y0 = c.y; n1 = c.z; y1 = c.w;
-    ss = e[12];
+    ss = d.x;
   }
 
   // flattened index of replicated scalar i: mua, sigma_y in front of a[P], b behind it
@@ -114,6 +124,7 @@ struct ElectricLane {
         float* e = tab + (i * K + slot) * kEntry + 8;
         e[0] = has ? A.n0[j] : 0.0f; e[1] = has ? A.y0[j] : 0.0f; e[2] = has ? A.n1[j] : 0.0f; e[3] = has ? A.y1[j] : 0.0f;
         e[4] = has ? A.ss[j] : 0.0f; e[5] = 0.0f; e[6] = 0.0f; e[7] = 0.0f;
+        e[8] = e[9] = e[10] = e[11] = 0.0f;
       }
     }
     lat_last = slot + K * (NL - 1) < P ? 1.0f : 0.0f;

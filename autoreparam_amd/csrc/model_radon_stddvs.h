@@ -43,13 +43,19 @@ struct RadonSdLane {
   // The seven per-county statistics depend on (slot, slice) only, not on the chain: they live in an LDS table shared by
   // the workgroup (two ds_read_b128 per county and gradient; a wave's 64 lanes read K distinct entries, a broadcast)
   // instead of 7 NLS registers per lane -- what lets two waves share a SIMD at 8 lanes per chain.
-  //   entry (slice i, slot) = [n sx sy sxx][sxy syy u -]
-  static constexpr int kEntry = 8;
+  //   entry (slice i, slot) = [n sx sy sxx][-2 sxy, syy, u, sxy], 12 floats apart.
+  // Bank conflicts (MI355X_MICROARCH.md, LDS): a ds_read_b128 is served in groups of 16 lanes over 64 banks, and the
+  // K distinct entries a group touches must fall on distinct 4-bank windows: a stride of 12 dwords does that for 8 and
+  // for 16 lanes per chain (12 s mod 64 is a permutation of the multiples of 4), a stride of 8 only for 8.  Both
+  // reads must BE ds_read_b128: with the second quad's last float unused the compiler shrank it to ds_read_b96, which
+  // is served in groups of 8 lanes over 32 banks -- slots s and s + 4 collided, 8 extra LDS cycles per county and
+  // gradient (round 3: SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS = 3.0).  The fourth float now carries -2 sxy's partner.
+  static constexpr int kEntry = 12;
   static ARP_DEV float* county_table() {
     __shared__ __attribute__((aligned(16))) float tab[NLS * K * kEntry];
     return tab;
   }
-  struct County { float n, sx, sy, sxx, sxy, syy, u; };
+  struct County { float n, sx, sy, sxx, m2sxy, syy, u, sxy; };
   // the entry's index is laundered: the table is loop invariant, and left to itself the compiler hoists every read out of
   // the leapfrog loop into registers -- the very registers the table is there to save
   ARP_DEV County county(int i) const {
@@ -57,7 +63,7 @@ struct RadonSdLane {
     asm volatile("" : "+v"(e));
     const float4* t = reinterpret_cast<const float4*>(county_table() + e);
     const float4 p = t[0], r = t[1];
-    return County{p.x, p.y, p.z, p.w, r.x, r.y, r.z};
+    return County{p.x, p.y, p.z, p.w, r.x, r.y, r.z, r.w};
   }
 
   static ARP_DEV int gg(int i) { return i; }
@@ -80,7 +86,8 @@ struct RadonSdLane {
         const bool ok = j < J;
         float* e = tab + (i * K + slot) * kEntry;
         e[0] = ok ? A.n[j] : 0.0f;  e[1] = ok ? A.sx[j] : 0.0f;  e[2] = ok ? A.sy[j] : 0.0f;  e[3] = ok ? A.sxx[j] : 0.0f;
-        e[4] = ok ? A.sxy[j] : 0.0f;  e[5] = ok ? A.syy[j] : 0.0f;  e[6] = ok ? A.u[j] : 0.0f;  e[7] = 0.0f;
+        e[4] = ok ? -2.0f * A.sxy[j] : 0.0f;  e[5] = ok ? A.syy[j] : 0.0f;  e[6] = ok ? A.u[j] : 0.0f;  e[7] = ok ? A.sxy[j] : 0.0f;
+        e[8] = e[9] = e[10] = e[11] = 0.0f;
       }
     }
     __syncthreads();
@@ -100,13 +107,14 @@ struct RadonSdLane {
       const float mt = q[NG + i], s = q[NG + NLS + i];
       const County c_ = county(i);
       const float n_i = c_.n, sx_i = c_.sx, sy_i = c_.sy, sxx_i = c_.sxx, sxy_i = c_.sxy, syy_i = c_.syy, u_i = c_.u;
+      const float m2sxy_i = c_.m2sxy;
       const float mu = fmaf(u_i, b1, mua);
       const float r = fmaf(-a[i], mu, mt);
       const float m = r + mu;
       const float w = fast_exp(-2.0f * s);
       const float t = fmaf(-b2, sx_i, sy_i);
       const float resid = fmaf(-n_i, m, t);
-      const float c = fmaf(b2, fmaf(b2, sxx_i, -2.0f * sxy_i), syy_i);
+      const float c = fmaf(b2, fmaf(b2, sxx_i, m2sxy_i), syy_i);    // -2 sxy is exact: same value as before
       const float Q = fmaf(-m, resid + t, c);
       const float l = w * resid;                       // d loglik / d m
       const float gm = l - r;

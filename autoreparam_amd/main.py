@@ -206,7 +206,7 @@ def run_hmc(model_config, results_dir, file_path, tuning=False, flags=FLAGS):
                          tuning_runs={"num_leapfrog_steps": flags.num_leapfrog_steps, "ess_min": float(ess_min),
                                       "sem_min": float(sem_min), "acceptance_rate": float(acceptance_rate),
                                       "mcmc_time": mcmc_time, "num_samples": flags.num_samples,
-                                      "num_burnin_steps": flags.num_burnin_steps, **extra})
+                                      "num_burnin_steps": flags.num_burnin_steps})   # the reference's keys, no more
     else:
         save_hmc_results(file_path=file_path, ess_min=float(ess_min), sem_min=float(sem_min),
                          acceptance_rate=float(acceptance_rate), mcmc_time_sec=mcmc_time, **extra)

@@ -71,6 +71,21 @@ ELECTION_MIX = {
 }
 
 
+# The headline kernel's own instruction mix: VALU instructions per WAVE (16 chains) and interleaved step (2 x 4 leapfrogs)
+# by issue class, from the ISA (tools/asm_ledger.py, profiles/r04_headline_ledger.txt; the hardware's SQ_INSTS_VALU says
+# 1 543 against the ledger's 1 567, which counts both arms of the rejection branch), priced with the same measured costs.
+HEADLINE_COST = {"pk": 4.4, "trans": 8.2, "dpp": 4.2, "mad_u64": 5.4, "half_rate": 4.2, "mov": 2.6, "other": 2.6}
+HEADLINE_MIX = {"pk": 840.0, "trans": 76.0, "dpp": 76.0, "mad_u64": 37.0, "half_rate": 59.5, "mov": 77.5, "other": 401.5}
+
+
+def headline_issue_bound(clock_ghz, leapfrogs_per_step=8, chains_per_wave=16):
+    """leapfrog-steps/s if all 1 024 SIMDs issued the headline step's instruction mix back to back: a bound the
+    measured rate cannot exceed (unlike SQ_ACTIVE_INST_VALU-based "pipe busy" figures, which count the overlapping
+    execution of a SIMD's two waves twice)"""
+    cyc = sum(HEADLINE_COST[k] * v for k, v in HEADLINE_MIX.items())
+    return 256 * 4 * clock_ghz * 1e9 / cyc * chains_per_wave * leapfrogs_per_step, cyc
+
+
 def election_issue_bound(form, L, clock_ghz=2.4):
     """leapfrog-steps/s if the vector pipes of all 1 024 SIMDs issued this instruction mix back to back"""
     m = ELECTION_MIX[form]
@@ -562,6 +577,19 @@ def main():
         ts = models._spec_time_series()
         time_model("time_series_NCP_65536", ts, "NCP", 65536, 8, 16, 0.05, 60 * 80.0 + 4.0 * ts.D,
                    "60 time steps x ~80 flop of the general form (centring recurrence and its adjoint as block scans); the run takes the compile-time non-centred form (no per-step exp, unit block maps), 4 lanes per chain")
+        # The general per-element (a, b) form -- what `--tied_pparams=False` cVIP / dVIP runs execute
+        # (program_transformations.py:513-533, 555-600) -- on the two BASELINE models whose CP / NCP / b = 1 forms have
+        # packed kernels: these runs take the generic float-array kernels (kernels.h: hmc_kernel<Lane, kModeVIP>)
+        es2 = models._spec_election()
+        rs_ab = np.random.RandomState(7)
+        ab_el = (rs_ab.uniform(0.2, 0.8, es2.D).astype(np.float32), rs_ab.uniform(0.2, 0.8, es2.D).astype(np.float32))
+        time_model("election_untied_general_ab_131072", es2, ab_el, 131072, 4, 128, 0.02, 4500.0 + 4.0 * es2.D,
+                   "untied cVIP: a and b free per element (exp(b log sigma) per state and pass); generic kernel, LDS cell tables")
+        pa = models._spec_radon("PA")
+        ab_pa = (rs_ab.uniform(0.2, 0.8, pa.D).astype(np.float32), rs_ab.uniform(0.2, 0.8, pa.D).astype(np.float32))
+        time_model("radon_PA_general_ab_65536", pa, ab_pa, 65536, 8, 256, 0.02, radon_flop_per_leapfrog(pa.D - 3, pa.D),
+                   "cVIP / dVIP with a free per element (m has unit scale: b is inert); generic float-array kernel against the "
+                   "packed CP kernel's plain_hmc entry above")
         extras["other_models"] = others
 
     # arp_ess on its own: the [S, C, D] trace of a sampling run at the headline size (1 000 recorded samples = 18.6 GB),
@@ -586,11 +614,27 @@ def main():
                 ess_t.append(a_.elapsed_time(b_))
             ems_ = float(np.median(ess_t))
             nbytes = 4.0 * S_e * C * D
+            # measured HBM bytes of a profiled pass of the same call (tools/profile_bench.sh: FETCH_SIZE x 2 + WRITE_SIZE,
+            # separate passes), only when that pass ran this very configuration
+            import glob as _glob
+            ess_prof = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_ess_kernel.json")))
+            ess_traffic, ess_src = None, None
+            if ess_prof:
+                try:
+                    ep = json.load(open(ess_prof[-1]))
+                    if abs(ep["grid"] - C * D) < 256 and ep["hbm_bytes_per_dispatch_x2_reads"]:
+                        # the first dispatches of that run are this trace (bench's own); the last two the flow's candidates
+                        own = ep["hbm_bytes_per_dispatch_x2_reads"][:-2] or ep["hbm_bytes_per_dispatch_x2_reads"]
+                        ess_traffic, ess_src = float(np.median(own)), "profiles/" + os.path.basename(ess_prof[-1])
+                except Exception:
+                    pass
             extras["ess_kernel"] = {
                 "kernel": "ess_kernel", "samples": S_e, "series": C * D, "kernel_ms": ems_, "kernel_ms_min": float(min(ess_t)),
                 "kernel_ms_max": float(max(ess_t)), "mean_min_ess_per_chain": float(ess_v.min(dim=1).values.mean().item()),
                 "roofline": {"bound": "hbm", "achieved": nbytes / (ems_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": nbytes / (ems_ * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                             "frac": nbytes / (ems_ * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": ess_traffic,
+                             "traffic_source": ess_src,
+                             "traffic_over_algorithmic": (ess_traffic / nbytes) if ess_traffic else None,
                              "algorithmic_bytes": nbytes,
                              "note": "algorithmic bytes = one read of the trace; series still positive at lag 16 are read "
                                      "once more by their wave (64-byte sectors), so the HBM traffic is higher"}}
@@ -645,6 +689,16 @@ def main():
             clk = prof.get("derived", {}).get("clock_ghz_estimate")
             roof["clock_ghz_estimate"] = clk
             roof["clock_source"] = prof["source"] if clk else None
+        if inter and D == 71 and num_ls == 4 and args.lanes in (0, 4):
+            # how close the launch comes to issuing its own instruction mix back to back (<= 1 by construction)
+            rate1 = C * T * LL / (kern_ms * 1e-3)
+            ib24, cyc = headline_issue_bound(2.4)
+            clk = roof.get("clock_ghz_estimate")
+            roof["issue_bound"] = {"cycles_per_wave_step": cyc, "mix_per_wave_step": HEADLINE_MIX,
+                                   "cycles_per_instruction": HEADLINE_COST, "source": "profiles/r04_headline_ledger.txt",
+                                   "at_2.4GHz": {"leapfrog_steps_per_s": ib24, "frac": rate1 / ib24},
+                                   "at_held_clock": ({"clock_ghz": clk, "leapfrog_steps_per_s": headline_issue_bound(clk)[0],
+                                                      "frac": rate1 / headline_issue_bound(clk)[0]} if clk else None)}
         out = {
             "metric": "leapfrog-steps/sec (all chains) + ESS/sec, radon(%s) %d chains%s" % (
                 args.dataset, args.chains, " per GPU" if args.scaling == "weak" else " in total"),
