@@ -30,49 +30,70 @@ def _vip_suffix(flags):
                              "_discrete_prior" if flags.discrete_prior else "")
 
 
+TargetBundle = collections.namedtuple("TargetBundle", ["target", "model", "elbo", "variational_parameters",
+                                                         "learnable_parameters", "reparam"])
+
+
+def _stored_cvip_reparam(results_dir, flags, required_for):
+    """`learned_reparam` of the cVIP fit this results directory holds (the dVIP / cVIP-HMC steps start from it)."""
+    path = os.path.join(results_dir, "cVIP_{}.json".format(_vip_suffix(flags)))
+    if not os.path.exists(path):
+        raise Exception("Run cVIP first to find reparameterisation" if required_for == "dVIP" else
+                        "no cVIP fit at {}: run --inference=VI --method=cVIP first".format(path))
+    with open(path, "r") as f:
+        return json.load(f)["learned_reparam"]
+
+
+def _bundle_fixed(kind):
+    """CP / NCP: a fixed parameterisation."""
+    def build(model_config, results_dir, flags):
+        make = graphs.make_cp_graph if kind == "CP" else graphs.make_ncp_graph
+        return TargetBundle(*make(model_config, flags=flags), reparam=kind)
+    return build
+
+
+def _bundle_interleaved(model_config, results_dir, flags):
+    """`i`: the pair (centred, non-centred) for the interleaved sampler; there is nothing to fit."""
+    if flags.inference == "VI":
+        raise Exception("Cannot run interleaved VI. Use `i` method with HMC only.")
+    cp = graphs.make_cp_graph(model_config, flags=flags)
+    ncp = graphs.make_ncp_graph(model_config, flags=flags)
+    return TargetBundle((cp[0], ncp[0]), (cp[1], ncp[1]), None, None, None, None)
+
+
+def _bundle_cvip(model_config, results_dir, flags):
+    """cVIP: the learnable parameterisation while fitting; the fitted (continuous) one when sampling."""
+    ptype = flags.learnable_parameterisation_type
+    if flags.inference == "VI":
+        return TargetBundle(*graphs.make_cvip_graph(model_config, parameterisation_type=ptype,
+                                                    tied_pparams=flags.tied_pparams, flags=flags), reparam=None)
+    fitted = _stored_cvip_reparam(results_dir, flags, "cVIP")
+    return TargetBundle(*graphs.make_dvip_graph(model_config, fitted, parameterisation_type=ptype, flags=flags),
+                        reparam=fitted)
+
+
+def _bundle_dvip(model_config, results_dir, flags):
+    """dVIP: the cVIP fit rounded to {0, 1} element by element (reference main.py:170-172)."""
+    fitted = _stored_cvip_reparam(results_dir, flags, "dVIP")
+    rounded = collections.OrderedDict((name, (np.array(value) >= 0.5).astype(np.float32)) for name, value in fitted.items())
+    util.print_("dVIP parameterisation (cVIP fit thresholded at 0.5): {}".format(rounded))
+    return TargetBundle(*graphs.make_dvip_graph(model_config, rounded,
+                                                parameterisation_type=flags.learnable_parameterisation_type, flags=flags),
+                        reparam=rounded)
+
+
+_BUNDLES = {"CP": _bundle_fixed("CP"), "NCP": _bundle_fixed("NCP"), "i": _bundle_interleaved, "cVIP": _bundle_cvip,
+            "dVIP": _bundle_dvip}
+
+
 def create_target_graph(model_config, results_dir, flags=FLAGS):
-    """reference main.py:117-187"""
-    cVIP_path = os.path.join(results_dir, "cVIP_{}.json".format(_vip_suffix(flags)))
-    actual_reparam = None
-    if flags.method == "CP":
-        target, model, elbo, vp, lp = graphs.make_cp_graph(model_config, flags=flags)
-        actual_reparam = "CP"
-    elif flags.method == "NCP":
-        target, model, elbo, vp, lp = graphs.make_ncp_graph(model_config, flags=flags)
-        actual_reparam = "NCP"
-    elif flags.method == "i":
-        if flags.inference == "VI":
-            raise Exception("Cannot run interleaved VI. Use `i` method with HMC only.")
-        target_cp, model_cp, _, _, _ = graphs.make_cp_graph(model_config, flags=flags)
-        target_ncp, model_ncp, _, _, _ = graphs.make_ncp_graph(model_config, flags=flags)
-        target, model = (target_cp, target_ncp), (model_cp, model_ncp)
-        elbo, vp, lp = None, None, None
-    elif flags.method == "cVIP":
-        if flags.inference == "VI":
-            target, model, elbo, vp, lp = graphs.make_cvip_graph(
-                model_config, parameterisation_type=flags.learnable_parameterisation_type,
-                tied_pparams=flags.tied_pparams, flags=flags)
-        else:
-            with open(cVIP_path, "r") as f:
-                actual_reparam = json.load(f)["learned_reparam"]
-            target, model, elbo, vp, lp = graphs.make_dvip_graph(
-                model_config, actual_reparam, parameterisation_type=flags.learnable_parameterisation_type,
-                flags=flags)
-    elif flags.method == "dVIP":
-        if os.path.exists(cVIP_path):
-            with open(cVIP_path, "r") as f:
-                reparam = json.load(f)["learned_reparam"]
-        else:
-            raise Exception("Run cVIP first to find reparameterisation")
-        discrete = collections.OrderedDict(
-            [(key, (np.array(reparam[key]) >= 0.5).astype(np.float32)) for key in reparam.keys()])
-        print("discrete parameterisation is", discrete)
-        target, model, elbo, vp, lp = graphs.make_dvip_graph(
-            model_config, discrete, parameterisation_type=flags.learnable_parameterisation_type, flags=flags)
-        actual_reparam = discrete
-    else:
+    """The target (log joint under the method's parameterisation), ELBO and variational parameters of a run -- the
+    reference's create_target_graph (main.py:117-187), same 6-tuple; one builder per --method."""
+    try:
+        build = _BUNDLES[flags.method]
+    except KeyError:
         raise Exception("unknown method {}".format(flags.method))
-    return target, model, elbo, vp, lp, actual_reparam
+    return tuple(build(model_config, results_dir, flags))
 
 
 def _clean_dict(d):
@@ -151,68 +172,86 @@ def _ess_report(info, model_config, flags, dev):
     return out
 
 
-def run_hmc(model_config, results_dir, file_path, tuning=False, flags=FLAGS):
-    """reference main.py:296-398"""
-    if os.path.exists(file_path):
-        with open(file_path, "r") as f:
-            prev_results = json.load(f)
-    else:
+def _read_vi_fit(file_path):
+    """The JSON a VI run of the same method left behind (step sizes, variational parameters, tuning runs so far)."""
+    if not os.path.exists(file_path):
         raise Exception("Run VI first to find initial step sizes")
-    param_names = _param_names(model_config)
-    initial_step_size = prev_results["initial_step_size"]
-    initial_states = list(util.variational_inits_from_params(
-        prev_results["learned_variational_params"], param_names=param_names, num_inits=flags.num_chains,
-        seed=flags.seed).values())
+    with open(file_path, "r") as f:
+        return json.load(f)
+
+
+def _initial_population(fit, model_config, flags):
+    """num_chains draws from the fitted mean-field Normal (reference util.py:394-410), one array per latent part."""
+    names = _param_names(model_config)
+    return list(util.variational_inits_from_params(fit["learned_variational_params"], param_names=names,
+                                                   num_inits=flags.num_chains, seed=flags.seed).values())
+
+
+def _settle_leapfrog_count(fit, tuning, flags):
+    """--num_leapfrog_steps as given; a tuning run insists on it (and is skipped when the file already has that count),
+    a sampling run without it takes the best tuning run's.  Returns False when there is nothing to do."""
     if tuning:
         if not flags.num_leapfrog_steps:
             raise ValueError("You must specify the number of leapfrog steps for a tuning run.")
-        for existing_run in prev_results.get("tuning_runs", []):
-            if existing_run["num_leapfrog_steps"] == flags.num_leapfrog_steps:
-                print("A tuning run already exists for HMC with {} leapfrog steps, skipping. ({})".format(
-                    flags.num_leapfrog_steps, existing_run))
-                return
-    if not flags.num_leapfrog_steps:
-        flags.num_leapfrog_steps = get_best_num_leapfrog_steps_from_tuning_runs(prev_results["tuning_runs"])
-    util.print_("\nNumber of leaprog steps is set to {}.\n".format(flags.num_leapfrog_steps))
+        done = [t for t in fit.get("tuning_runs", []) if t["num_leapfrog_steps"] == flags.num_leapfrog_steps]
+        if done:
+            util.print_("tuning run with {} leapfrog steps is already recorded ({}): skipped".format(
+                flags.num_leapfrog_steps, done[0]))
+            return False
+    elif not flags.num_leapfrog_steps:
+        flags.num_leapfrog_steps = get_best_num_leapfrog_steps_from_tuning_runs(fit["tuning_runs"])
+    util.print_("\nsampling with {} leapfrog steps per transition\n".format(flags.num_leapfrog_steps))
     if flags.count_in_leapfrog_steps:
-        flags.num_samples = int(flags.num_samples / float(flags.num_leapfrog_steps))
-        flags.num_burnin_steps = int(flags.num_burnin_steps / float(flags.num_leapfrog_steps))
-        flags.num_adaptation_steps = int(flags.num_adaptation_steps / float(flags.num_leapfrog_steps))
-    target, _, elbo, vp, lp, actual_reparam = create_target_graph(model_config, results_dir, flags)
+        # schedule lengths given in gradient evaluations (reference main.py:331-336)
+        for name in ("num_samples", "num_burnin_steps", "num_adaptation_steps"):
+            setattr(flags, name, int(getattr(flags, name) / float(flags.num_leapfrog_steps)))
+    return True
+
+
+def run_hmc(model_config, results_dir, file_path, tuning=False, flags=FLAGS):
+    """One HMC run (or one HMCtuning run) of a fitted method: the reference's run_hmc (main.py:296-398) -- same inputs,
+    files and keys; chains sharded over the ranks of the job, statistics combined at the end."""
+    fit = _read_vi_fit(file_path)
+    if not _settle_leapfrog_count(fit, tuning, flags):
+        return
+    initial_states = _initial_population(fit, model_config, flags)
+    target, _, _, _, _, reparam = create_target_graph(model_config, results_dir, flags)
     # one process per GPU: every rank draws the same initial population and keeps its block of chains
     rank, ws = parallel.world()
     initial_states, chain_offset = parallel.shard_states(initial_states, rank, ws)
-    start_time = time.time()
-    states_orig, kernel_results, samples, ess_final = inference.hmc(
-        target, model_config, initial_step_size, initial_states=initial_states, reparam=actual_reparam, flags=flags,
+    clock = time.time()
+    _, kernel_results, samples, ess_final = inference.hmc(
+        target, model_config, fit["initial_step_size"], initial_states=initial_states, reparam=reparam, flags=flags,
         chain_offset=chain_offset)
-    is_accepted = kernel_results.inner_results.is_accepted
-    mcmc_time = time.time() - start_time
-    normalized_ess_final = [1000 * e / (flags.num_samples * flags.num_leapfrog_steps) for e in ess_final]
+    mcmc_time = time.time() - clock
+    per_1000_gradients = 1000.0 / (flags.num_samples * flags.num_leapfrog_steps)
+    normalized_ess_final = [e * per_1000_gradients for e in ess_final]
     info = getattr(inference.hmc, "last_ess_info", None)
     dev = flags.device if ws > 1 else None
     n_ess = _ess_chain_count(info, model_config, flags)          # None: a chain subset (streaming run)
     ess_min, sem_min, acceptance_rate, _ = parallel.summarize(
-        normalized_ess_final, is_accepted, flags.num_samples, flags.num_chains, device=dev, ess_chains_total=n_ess)
+        normalized_ess_final, kernel_results.inner_results.is_accepted, flags.num_samples, flags.num_chains, device=dev,
+        ess_chains_total=n_ess)
     util.print_("ESS per 1000 gradients: {} +/- {}".format(ess_min, sem_min))
     extra = _ess_report(info, model_config, flags, dev)
     if ws > 1 and not tuning:
         # _ess.npz / _ess.txt hold every chain's per-element ESS: collect the other ranks' blocks (a collective: all ranks)
         normalized_ess_final = parallel.gather_parts(normalized_ess_final, n_ess, flags.device)
+    summary = (ess_min, sem_min, acceptance_rate, mcmc_time)
     if rank != 0:
-        return ess_min, sem_min, acceptance_rate, mcmc_time
+        return summary
     if tuning:
-        save_hmc_results(file_path=file_path,
-                         tuning_runs={"num_leapfrog_steps": flags.num_leapfrog_steps, "ess_min": float(ess_min),
-                                      "sem_min": float(sem_min), "acceptance_rate": float(acceptance_rate),
-                                      "mcmc_time": mcmc_time, "num_samples": flags.num_samples,
-                                      "num_burnin_steps": flags.num_burnin_steps})   # the reference's keys, no more
-    else:
-        save_hmc_results(file_path=file_path, ess_min=float(ess_min), sem_min=float(sem_min),
-                         acceptance_rate=float(acceptance_rate), mcmc_time_sec=mcmc_time, **extra)
-        save_ess(file_path_base=file_path[:-5], samples=samples, param_names=param_names,
-                 normalized_ess_final=normalized_ess_final, num_chains_to_save=flags.num_chains_to_save)
-    return ess_min, sem_min, acceptance_rate, mcmc_time
+        # the reference's keys of a tuning_runs entry, no more
+        save_hmc_results(file_path=file_path, tuning_runs=dict(
+            num_leapfrog_steps=flags.num_leapfrog_steps, ess_min=float(ess_min), sem_min=float(sem_min),
+            acceptance_rate=float(acceptance_rate), mcmc_time=mcmc_time, num_samples=flags.num_samples,
+            num_burnin_steps=flags.num_burnin_steps))
+        return summary
+    save_hmc_results(file_path=file_path, ess_min=float(ess_min), sem_min=float(sem_min),
+                     acceptance_rate=float(acceptance_rate), mcmc_time_sec=mcmc_time, **extra)
+    save_ess(file_path_base=file_path[:-5], samples=samples, param_names=_param_names(model_config),
+             normalized_ess_final=normalized_ess_final, num_chains_to_save=flags.num_chains_to_save)
+    return summary
 
 
 def run_interleaved_hmc_with_leapfrog_steps(model_config, results_dir, num_leapfrog_steps_cp,
@@ -261,48 +300,48 @@ def _first_existing(results_dir, names):
     return None
 
 
-def run_interleaved_hmc(model_config, results_dir, file_path, flags=FLAGS):
-    """reference main.py:452-528 (intended behaviour, see module docstring)"""
-    tied = "_tied" if flags.tied_pparams else ""
-    file_path_cp = _first_existing(results_dir, ["CP.json", "CP%s.json" % tied])
-    file_path_ncp = _first_existing(results_dir, ["NCP.json", "NCP%s.json" % tied])
-    param_names = _param_names(model_config)
-    if file_path_cp and file_path_ncp:
-        with open(file_path_cp, "r") as f:
-            prev = json.load(f)
-            initial_step_size_cp = prev["initial_step_size"]
-            num_leapfrog_steps_cp = get_best_num_leapfrog_steps_from_tuning_runs(prev["tuning_runs"])
-            learned_variational_params_cp = prev["learned_variational_params"]
-        with open(file_path_ncp, "r") as f:
-            prev = json.load(f)
-            initial_step_size_ncp = prev["initial_step_size"]
-            num_leapfrog_steps_ncp = get_best_num_leapfrog_steps_from_tuning_runs(prev["tuning_runs"])
-    else:
+def _tuned_fit(results_dir, names, what):
+    """(step sizes, best tuned leapfrog count, variational parameters) of a CP / NCP fit this directory holds; the
+    reference writes `CP_tied.json` and looks for `CP.json`: both spellings are accepted."""
+    path = _first_existing(results_dir, names)
+    if path is None:
         raise Exception("Run VI first to find initial step sizes, and HMC first to find num_leapfrog_steps.")
-    initial_states_cp = list(util.variational_inits_from_params(
-        learned_variational_params_cp, param_names=param_names, num_inits=flags.num_chains,
-        seed=flags.seed).values())
-    best_ess_min, best_num_ls, results = 0, None, ()
-    for num_ls in sorted(set([num_leapfrog_steps_ncp, num_leapfrog_steps_cp])):
-        flags.num_leapfrog_steps = num_ls + num_ls
-        util.print_("\nNumber of leaprog steps is set to {}.\n".format(flags.num_leapfrog_steps))
-        res = run_interleaved_hmc_with_leapfrog_steps(
+    with open(path, "r") as f:
+        fit = json.load(f)
+    if not fit.get("tuning_runs"):
+        raise Exception("no HMCtuning run recorded for {}: run --inference=HMCtuning --method={} first".format(path, what))
+    return fit["initial_step_size"], get_best_num_leapfrog_steps_from_tuning_runs(fit["tuning_runs"]), \
+        fit["learned_variational_params"]
+
+
+def run_interleaved_hmc(model_config, results_dir, file_path, flags=FLAGS):
+    """--method=i: the interleaved CP / NCP sampler started from the centred fit, once per tuned leapfrog count of the two
+    fits, keeping the run with the larger ESS (reference main.py:452-528, intended behaviour: module docstring)."""
+    tied = "_tied" if flags.tied_pparams else ""
+    step_cp, ls_cp, vparams_cp = _tuned_fit(results_dir, ["CP.json", "CP%s.json" % tied], "CP")
+    step_ncp, ls_ncp, _ = _tuned_fit(results_dir, ["NCP.json", "NCP%s.json" % tied], "NCP")
+    initial_states_cp = _initial_population({"learned_variational_params": vparams_cp}, model_config, flags)
+    kept, kept_ls = None, None
+    for num_ls in sorted({ls_ncp, ls_cp}):
+        flags.num_leapfrog_steps = 2 * num_ls          # what the ESS normalisation counts (reference main.py:493)
+        util.print_("\ninterleaved sampling with {0} + {0} leapfrog steps per step\n".format(num_ls))
+        run = run_interleaved_hmc_with_leapfrog_steps(
             model_config=model_config, results_dir=results_dir, num_leapfrog_steps_cp=num_ls,
-            num_leapfrog_steps_ncp=num_ls, initial_step_size_cp=initial_step_size_cp,
-            initial_step_size_ncp=initial_step_size_ncp, initial_states_cp=initial_states_cp, flags=flags)
-        if float(res[0]) > best_ess_min or best_num_ls is None:
-            best_ess_min, best_num_ls, results = float(res[0]), num_ls, res
-    ess_min, sem_min, acceptance_rate_cp, acceptance_rate_ncp, mcmc_time, samples, normalized_ess_final, extra = results
-    flags.num_leapfrog_steps = best_num_ls + best_num_ls
+            num_leapfrog_steps_ncp=num_ls, initial_step_size_cp=step_cp, initial_step_size_ncp=step_ncp,
+            initial_states_cp=initial_states_cp, flags=flags)
+        if kept is None or float(run[0]) > float(kept[0]):
+            kept, kept_ls = run, num_ls
+    ess_min, sem_min, acceptance_rate_cp, acceptance_rate_ncp, mcmc_time, samples, normalized_ess_final, extra = kept
+    flags.num_leapfrog_steps = 2 * kept_ls
     if parallel.world()[0] != 0:
-        return results
-    save_hmc_results(file_path=file_path, initial_step_size_ncp=initial_step_size_ncp,
-                     initial_step_size_cp=initial_step_size_cp, num_leapfrog_steps=best_num_ls,
-                     ess_min=float(ess_min), sem_min=float(sem_min), acceptance_rate_cp=float(acceptance_rate_cp),
-                     acceptance_rate_ncp=float(acceptance_rate_ncp), mcmc_time_sec=mcmc_time, **extra)
-    save_ess(file_path_base=file_path[:-5], samples=samples, param_names=param_names,
+        return kept
+    save_hmc_results(file_path=file_path, initial_step_size_ncp=step_ncp, initial_step_size_cp=step_cp,
+                     num_leapfrog_steps=kept_ls, ess_min=float(ess_min), sem_min=float(sem_min),
+                     acceptance_rate_cp=float(acceptance_rate_cp), acceptance_rate_ncp=float(acceptance_rate_ncp),
+                     mcmc_time_sec=mcmc_time, **extra)
+    save_ess(file_path_base=file_path[:-5], samples=samples, param_names=_param_names(model_config),
              normalized_ess_final=normalized_ess_final, num_chains_to_save=flags.num_chains_to_save)
-    return results
+    return kept
 
 
 def save_hmc_results(file_path, **record):

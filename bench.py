@@ -592,6 +592,40 @@ def main():
                    "packed CP kernel's plain_hmc entry above")
         extras["other_models"] = others
 
+    # The mean-field VI kernel (find_best_learning_rate, inference.py:26-154): all learning rates x all optimisation steps in
+    # ONE launch, one workgroup per learning rate -- 5 of the 256 CUs, by design (256 Monte-Carlo draws per step, every
+    # step depends on the last: a latency-bound recurrence, not a throughput kernel).  Priced on its gradient evaluations.
+    if secondary:
+        try:
+            vflags_lrs = [0.02, 0.05, 0.1, 0.2, 0.4]
+            n_opt, n_mc = 3000, 256
+            vi = {}
+            for tag, vspec, flop in (("radon_PA_CP", spec, radon_flop_per_leapfrog(J, D) - 4.0 * D),
+                                     ("german_NCP", models._spec_german(), 4.0 * 1000 * 62)):
+                veng = engine.Engine(vspec, dev)
+                veng.set_param(0, "CP" if tag.startswith("radon") else "NCP")
+                times = []
+                for rep in range(2):
+                    loc = torch.zeros(len(vflags_lrs), vspec.D, device=dev)
+                    rho = torch.full((len(vflags_lrs), vspec.D), -2.0, device=dev)
+                    torch.cuda.synchronize()
+                    a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a_.record(); veng.vi_run(vflags_lrs, loc, rho, n_opt, n_mc, seed=1); b_.record(); torch.cuda.synchronize()
+                    times.append(a_.elapsed_time(b_))
+                ms = min(times)
+                grads = len(vflags_lrs) * n_opt * n_mc
+                vi[tag] = {"kernel_ms": ms, "learning_rates": len(vflags_lrs), "steps": n_opt, "mc_samples": n_mc,
+                           "gradients_per_s": grads / (ms * 1e-3), "us_per_optimisation_step": 1e3 * ms / n_opt,
+                           "roofline": {"bound": "latency", "achieved": grads * flop / (ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": grads * flop / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                        "workgroups": len(vflags_lrs), "cus_used_of_256": len(vflags_lrs),
+                                        "note": "one workgroup per learning rate: each optimisation step is 256 gradients + an "
+                                                "Adam update that the next step depends on; frac is against the whole chip"}}
+                del veng
+            extras["vi_kernel"] = vi
+        except Exception as e:
+            extras["vi_kernel"] = {"error": repr(e)}
+
     # arp_ess on its own: the [S, C, D] trace of a sampling run at the headline size (1 000 recorded samples = 18.6 GB),
     # priced against HBM: the kernel is a strided stream of the trace (algorithmic bytes = one read of it)
     if secondary and inter and not args.no_ess:
