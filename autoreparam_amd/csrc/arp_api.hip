@@ -524,6 +524,7 @@ int arp_hmc_run(arp_model* m, int which, const arp_hmc_config* cfg, const arp_hm
   if (m->param_kind[which] == kModeCP && o->hmc_cp) fn = o->hmc_cp;
   if (m->param_kind[which] == kModeNCP && o->hmc_ncp) fn = o->hmc_ncp;
   if (m->param_kind[which] == kModeB1 && o->hmc_b1) fn = o->hmc_b1;
+  if (m->param_kind[which] == kModeVIP && o->hmc_vip_pk) fn = o->hmc_vip_pk;
   fn(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, (hipStream_t)stream);
   ARP_HIP_OK(hipGetLastError());
   return 0;

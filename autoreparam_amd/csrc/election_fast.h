@@ -1,6 +1,9 @@
 // Packed-f32 lane model of election88 (reference models.py:967-1008) for its three compile-time parameterisations --
-// centred, non-centred, and "a free, b = 1" (what the reference's tied cVIP / dVIP runs execute) -- on the
-// packed chain kernels of pk_chain.h.  model_election.h has the model, its one-hot quirk and the general VIP form.
+// centred, non-centred, and "a free, b = 1" (what the reference's tied cVIP / dVIP runs execute) -- and,
+// round 4, for the GENERAL per-element (a, b) of `--tied_pparams=False` runs (program_transformations.py:513-533, 555-600;
+// MODE kModeVIP: one more exponential per state and pass, sigma^{-b_t}), on the packed chain kernels of pk_chain.h.
+// model_election.h has the model, its one-hot quirk and the generic float-array form (the checker of this one in the
+// density tests, and the interleaved / VI kernels' lane model).
 //
 // A lane's states t = slot + K*i are held two at a time (pair k = states 2k, 2k+1), so everything per state but the
 // transcendentals is one v_pk_*_f32 per pair: per pass and pair 24 packed operations, two exponentials (exp(-a_t), shared
@@ -59,7 +62,10 @@ struct ElectionPk {
     return tab + e;
   }
 
-  v2f al2[NP];      // a of the state effects (MODE b = 1 only; dead otherwise)
+  v2f al2[NP];      // a of the state effects (MODE b = 1 and the general form; dead otherwise)
+  v2f bl2[NP];      // b of the state effects (general form only)
+  float nbl;        // sum of b over the lane's state effects (general form: -b ls per state in the log density)
+  float csr[NG], sir[NG];   // general form: s_i^(1 - b_i) and s_i^(-b_i) of the top-level scalars (s = 100, 10, 100, 100)
   v2f mlast;        // 1/0: which elements of the LAST pair are state effects (the cell-only group S and padding are not)
   float nlat;       // state effects owned by the lane
   float d1, d2;     // sum over the lane's cells of (y - n) that carry b1 / b2
@@ -72,7 +78,7 @@ struct ElectionPk {
   static constexpr ARP_DEV int loff(int i) { return K * i; }
   ARP_DEV bool lvalid(int i) const { return i < NL - 1 ? true : last_ok; }
 
-  ARP_DEV void init(const Args& A, const float* av, const float*, int slot_) {
+  ARP_DEV void init(const Args& A, const float* av, const float* bv, int slot_) {
     slot = slot_;
     S = A.S;
     gmap2 = 2 + S; gmap3 = 3 + S;
@@ -81,6 +87,15 @@ struct ElectionPk {
     if (NL & 1) mlast = v2f{ll, 0.0f}; else mlast = v2f{1.0f, ll};
     nlat = (float)(NL - 1) + ll;
     d1 = 0.0f; d2 = 0.0f;
+    nbl = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      // wave uniform: log2 of the prior scale (100, 10, 100, 100) times (1 - b), -b
+      const float l2s = i == 1 ? 3.3219280948873623f : 6.643856189774724f;
+      const float bi = bv ? bv[gg(i)] : 1.0f;
+      csr[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, __builtin_amdgcn_exp2f((1.0f - bi) * l2s))));
+      sir[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, __builtin_amdgcn_exp2f(-bi * l2s))));
+    }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       const float4* e = entry(k);
@@ -93,6 +108,8 @@ struct ElectionPk {
         const int i = 2 * k + h;
         const bool lat = i < NL && slot + K * i < S;
         al2[k][h] = (lat && av) ? av[LBASE + slot + K * i] : 0.0f;
+        bl2[k][h] = (lat && bv) ? bv[LBASE + slot + K * i] : 0.0f;
+        nbl += bl2[k][h];
       }
     }
   }
@@ -119,18 +136,23 @@ struct ElectionPk {
     return MODE == kModeNCP ? 1.0f : (i == 1 ? 0.1f : 0.01f);
   }
 
+  template <int MODE> ARP_DEV float csv(int i) const { if constexpr (MODE == kModeVIP) return csr[i]; else return cs<MODE>(i); }
+  template <int MODE> ARP_DEV float siv(int i) const { if constexpr (MODE == kModeVIP) return sir[i]; else return si<MODE>(i); }
+
   // PASS 0 interior (gradient, kick, drift), 1 closing (gradient, logp, kinetic energy), 2 bootstrap (gradient, logp)
   template <int MODE, int PASS>
   ARP_DEV void pass(float (&qg)[NG], v2f (&qc)[NP], float (&pg)[NG], v2f (&pc)[NP], const float (&eg)[NG],
                     const v2f (&ec)[NP], float (&gg_)[NG], v2f (&gc)[NP], float& lp, float& ke) const {
-    constexpr bool B1ISH = MODE != kModeNCP;       // b = 1 on the state effects (centred, or a free with b = 1)
-    const float mua = cs<MODE>(0) * qg[0], ls = cs<MODE>(1) * qg[1], b1 = cs<MODE>(2) * qg[2], b2 = cs<MODE>(3) * qg[3];
+    constexpr bool GEN = MODE == kModeVIP;          // per-element (a, b): z = (q - a mua) sigma^{-b}
+    constexpr bool B1ISH = MODE == kModeCP || MODE == kModeB1;   // b = 1 on the state effects (centred, or a free with b = 1)
+    const float mua = csv<MODE>(0) * qg[0], ls = csv<MODE>(1) * qg[1], b1 = csv<MODE>(2) * qg[2], b2 = csv<MODE>(3) * qg[3];
     const float sig = fast_exp(ls);
     const float eu = B1ISH ? fast_exp(-ls) : 1.0f;
     const float E1 = fast_exp(-b1), E2 = fast_exp(-b2), E12 = E1 * E2;
     const v2f vmua = splat(mua), vmua_last = vmua * mlast, vsig = splat(sig), veu = splat(eu);
     const v2f vE1 = splat(E1), vE2 = splat(E2), vE12 = splat(E12), one = splat(1.0f), half = splat(0.5f);
     const v2f nl2e = splat(-1.4426950408889634f);
+    const v2f vnls2 = splat(-1.4426950408889634f * ls);      // general form: sigma^{-b} = exp2(b (-ls log2 e))
     v2f a_mua = splat(0.0f), a_ls = splat(0.0f), a_b1 = splat(0.0f), a_b2 = splat(0.0f);
     // log density: |logp| ~ 7 600 while Metropolis needs its differences to ~1e-3, so the per-pair terms (a few hundred
     // each) go into a compensated (Kahan) sum; the pairs' own four-cell sums start from zero
@@ -143,7 +165,13 @@ struct ElectionPk {
       v2f z;
       if (MODE == kModeCP) z = (qt - (last ? vmua_last : vmua)) * veu;
       else if (MODE == kModeNCP) z = qt;
-      else z = vfma(-al2[k], vmua, qt) * veu;
+      else if (MODE == kModeB1) z = vfma(-al2[k], vmua, qt) * veu;
+      v2f euk = one;
+      if (GEN) {
+        const v2f e = bl2[k] * vnls2;
+        euk = v2f{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+        z = vfma(-al2[k], vmua, qt) * euk;
+      }
       v2f as = vfma(vsig, z, vmua);
       if (last) as = as * mlast;            // the cell-only group and padding see no state effect
       const v2f e2 = as * nl2e;
@@ -163,17 +191,24 @@ struct ElectionPk {
       const v2f W = (w[0] + w[2]) + s13;
       a_b2 += s13;
       a_b1 += s23;
-      v2f gt = vfma(vsig, W, -z);
+      v2f gt, sW;
+      if (GEN) { sW = vsig * W; gt = (sW - z) * euk; }
+      else gt = vfma(vsig, W, -z);                  // (the three compile-time forms keep round 3's arithmetic bit for bit)
       if (B1ISH) gt = gt * veu;
       if (last) gt = gt * mlast;
       // d/dmua: the likelihood through a_t, minus what the (a mua) location of the prior takes back
       v2f hm;
       if (MODE == kModeCP) hm = W - gt;
       else if (MODE == kModeNCP) hm = W;
-      else hm = vfma(-al2[k], gt, W);
+      else hm = vfma(-al2[k], gt, W);                 // b = 1 and the general form alike
       a_mua += last ? hm * mlast : hm;
       // d/dls: b (z^2 - 1) + (1 - b) W sigma z; the constants (-1 per state effect, the factor sigma) follow the reduction
-      a_ls = B1ISH ? vfma(z, z, a_ls) : vfma(W, z, a_ls);
+      if (GEN) {
+        const v2f swz = sW * z;
+        a_ls += vfma(bl2[k], vfma(z, z, -swz), swz);          // b z^2 + (1 - b) sigma W z
+      } else {
+        a_ls = B1ISH ? vfma(z, z, a_ls) : vfma(W, z, a_ls);
+      }
       if (PASS == 0) {
         const v2f pn = vfma(ec[k], gt, pc[k]);
         pc[k] = pn;
@@ -199,15 +234,15 @@ struct ElectionPk {
     }
     const float s_mua = group_sum<K>(a_mua[0] + a_mua[1]);
     const float zz = a_ls[0] + a_ls[1];                       // b = 1: sum z^2; b = 0: sum W z
-    const float s_ls = group_sum<K>(B1ISH ? zz - nlat : zz * sig);
+    const float s_ls = group_sum<K>(GEN ? zz - nbl : (B1ISH ? zz - nlat : zz * sig));
     const float s_b1 = group_sum<K>(a_b1[0] + a_b1[1]);
     const float s_b2 = group_sum<K>(a_b2[0] + a_b2[1]);
     const float gs[4] = {s_mua, s_ls, s_b1, s_b2};
     float gi[4], u[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      u[i] = qg[i] * si<MODE>(i);
-      gi[i] = fmaf(cs<MODE>(i), gs[i], -u[i] * si<MODE>(i));
+      u[i] = qg[i] * siv<MODE>(i);
+      gi[i] = fmaf(csv<MODE>(i), gs[i], -u[i] * siv<MODE>(i));
     }
     if (PASS == 0) {
 #pragma unroll
@@ -219,7 +254,7 @@ struct ElectionPk {
 #pragma unroll
       for (int i = 0; i < 4; ++i) gg_[i] = gi[i];
       float part = (lps[0] + lps[1]) - (lpc[0] + lpc[1]);
-      part += fmaf(d1, b1, d2 * b2) - (B1ISH ? nlat * ls : 0.0f);                  // (y - n) b-terms; - b ls per state effect
+      part += fmaf(d1, b1, d2 * b2) - (GEN ? nbl * ls : (B1ISH ? nlat * ls : 0.0f));   // (y - n) b-terms; - b ls per state effect
       lp = group_sum<K>(part) - 0.5f * ((u[0] * u[0] + u[1] * u[1]) + (u[2] * u[2] + u[3] * u[3]));
       if (PASS == 1) {
         float kg = 0.0f;
@@ -237,17 +272,23 @@ struct ElectionPk {
   template <int MODE>
   ARP_DEV void to_centered(const float (&qg)[NG], const v2f (&qc)[NP], float (&xg)[NG], v2f (&xc)[NP]) const {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xg[i] = cs<MODE>(i) * qg[i];
+    for (int i = 0; i < 4; ++i) xg[i] = csv<MODE>(i) * qg[i];
     const v2f vmua = splat(xg[0]);
     const v2f vsig = splat(MODE == kModeNCP ? fast_exp(xg[1]) : 1.0f);
+    const v2f vls2 = splat(1.4426950408889634f * xg[1]);
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       const bool last = k == NP - 1;
       v2f x;
       if (MODE == kModeCP) x = qc[k];                                           // a = b = 1: identity
       else if (MODE == kModeNCP) x = vfma(vsig, qc[k], vmua);                   // a = b = 0: mua + sigma q
-      else x = vfma((last ? mlast : splat(1.0f)) - al2[k], vmua, qc[k]);        // b = 1: q + (1 - a) mua
-      xc[k] = (last && MODE == kModeNCP) ? x * mlast : x;
+      else if (MODE == kModeB1) x = vfma((last ? mlast : splat(1.0f)) - al2[k], vmua, qc[k]);   // b = 1: q + (1 - a) mua
+      else {                                                                    // mua + sigma^(1 - b) (q - a mua)
+        const v2f e = (splat(1.0f) - bl2[k]) * vls2;
+        const v2f sc = v2f{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+        x = vfma(sc, vfma(-al2[k], vmua, qc[k]), vmua);
+      }
+      xc[k] = (last && (MODE == kModeNCP || MODE == kModeVIP)) ? x * mlast : x;
     }
   }
 
@@ -255,17 +296,23 @@ struct ElectionPk {
   template <int MODE>
   ARP_DEV void from_centered(const float (&xg)[NG], const v2f (&xc)[NP], float (&qg)[NG], v2f (&qc)[NP]) const {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) qg[i] = xg[i] * (1.0f / cs<MODE>(i));
+    for (int i = 0; i < 4; ++i) qg[i] = xg[i] * (1.0f / csv<MODE>(i));
     const v2f vmua = splat(xg[0]);
     const v2f vis = splat(MODE == kModeNCP ? fast_exp(-xg[1]) : 1.0f);
+    const v2f vls2 = splat(1.4426950408889634f * xg[1]);
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       const bool last = k == NP - 1;
       v2f q;
       if (MODE == kModeCP) q = xc[k];
       else if (MODE == kModeNCP) q = (xc[k] - vmua) * vis;                      // (x - mua) / sigma
-      else q = vfma(al2[k] - (last ? mlast : splat(1.0f)), vmua, xc[k]);        // b = 1: x - (1 - a) mua
-      qc[k] = (last && MODE == kModeNCP) ? q * mlast : q;
+      else if (MODE == kModeB1) q = vfma(al2[k] - (last ? mlast : splat(1.0f)), vmua, xc[k]);   // b = 1: x - (1 - a) mua
+      else {                                                                    // a mua + (x - mua) sigma^(b - 1)
+        const v2f e = (bl2[k] - splat(1.0f)) * vls2;
+        const v2f sc = v2f{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+        q = vfma(sc, xc[k] - vmua, al2[k] * vmua);
+      }
+      qc[k] = (last && (MODE == kModeNCP || MODE == kModeVIP)) ? q * mlast : q;
     }
   }
 };

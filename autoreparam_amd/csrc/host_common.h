@@ -54,6 +54,8 @@ struct LaneOps {
                              const HmcParams& P, hipStream_t s);
   // hmc for "a free, b = 1" (nullptr when the lane model has no such form)
   void (*hmc_b1)(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s);
+  // the general per-element (a, b) on the packed chain layer, where a lane model has it (election); nullptr: the generic kernel
+  void (*hmc_vip_pk)(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s);
 };
 
 template <class Lane>
@@ -179,6 +181,7 @@ LaneOps election_lane_ops() {
     o.hmc_cp = ARP_EL(kModeCP);
     o.hmc_ncp = ARP_EL(kModeNCP);
     o.hmc_b1 = ARP_EL(kModeB1);
+    o.hmc_vip_pk = ARP_EL(kModeVIP);
 #undef ARP_EL
     // --method=i: centred / non-centred interleaving on the packed layer (pk_chain.h: pk_interleaved_kernel)
     o.interleaved_cp_ncp = [](const void* args, const float* a0, const float* b0, const float*, const float*,

@@ -424,8 +424,11 @@ struct PkBlock {
 // STATS: the instantiation that keeps the statistics accumulators in LDS (P.stats is set); its LDS footprint allows two
 // workgroups per CU, so it is compiled for at most two waves per SIMD.  Without STATS a run that asks for statistics
 // takes the plane-per-sample route of kernels.h (lane models whose accumulators do not fit: PkBlock::kStatsFit).
+#ifndef ARP_PK_VIP_MINW2
+#define ARP_PK_VIP_MINW2 (-1)      // experiment: kModeVIP (0) compiles the general-(a, b) form for two waves per SIMD
+#endif
 template <class T, int MODE, bool STATS = false>
-__global__ __launch_bounds__(kBlock, STATS && T::MINW > 2 ? 2 : T::MINW) void pk_hmc_kernel(
+__global__ __launch_bounds__(kBlock, (STATS || MODE == ARP_PK_VIP_MINW2) && T::MINW > 2 ? 2 : T::MINW) void pk_hmc_kernel(
     typename T::Args A, const float* __restrict__ av, const float* __restrict__ bv, HmcParams P) {
   constexpr int K = T::K, NP = T::NP, ND = T::ND, NG = T::NG;
   // chain of this lane (a launch holds fewer than 2^31 / K chains: 32-bit lane arithmetic)
