@@ -152,6 +152,14 @@ LaneOps radon_lane_ops() {
       if (SL && P.stats && stats_lds_enabled()) hipLaunchKernelGGL((pk_hmc_kernel<T, kModeNCP, SL>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, nullptr, nullptr, P);
       else hipLaunchKernelGGL((pk_hmc_kernel<T, kModeNCP>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, nullptr, nullptr, P);
     };
+    // cVIP / dVIP runs: a free per county (m has unit scale, so b is inert: "a free, b = 1" and the untied form are the
+    // same kernel)
+    o.hmc_vip_pk = [](const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s) {
+      const dim3 g(Launch<RadonLane<K, NL>>::blocks(P.C));
+      if (SL && P.stats && stats_lds_enabled()) hipLaunchKernelGGL((pk_hmc_kernel<T, kModeVIP, SL>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, a, b, P);
+      else hipLaunchKernelGGL((pk_hmc_kernel<T, kModeVIP>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, a, b, P);
+    };
+    o.hmc_b1 = o.hmc_vip_pk;
     o.interleaved_cp_ncp = [](const void* args, const float*, const float*, const float*, const float*,
                               const HmcParams& P, hipStream_t s) {
       const dim3 g(Launch<RadonLane<K, NL>>::blocks(P.C));

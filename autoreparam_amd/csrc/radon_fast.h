@@ -36,9 +36,11 @@ struct RadonPk {
   using Args = RadonArgs;
 
   v2f n2[NP], sx2[NP], sy2[NP], u2[NP];
+  v2f a2[NP];       // general form (MODE kModeVIP: cVIP / dVIP runs, a free per county; m has unit scale, so b is inert): dead otherwise
   v2f mlast;        // 1/0: which elements of the LAST pair are real counties
   float sxy, sxx;
   float c_sy, c_suy;   // sum_j Sy_j, sum_j u_j Sy_j over all counties (grad(0) of the NCP form; wave-uniform)
+  float c_sya, c_suya; // the same sums weighted by (1 - a_j): grad(0) of the general form (equal in all lanes of a chain)
   int slot;
   bool last_ok;
 
@@ -48,19 +50,25 @@ struct RadonPk {
   static constexpr ARP_DEV int loff(int i) { return K * i; }
   ARP_DEV bool lvalid(int i) const { return i < NL - 1 ? true : last_ok; }
 
-  ARP_DEV void init(const Args& A, const float*, const float*, int slot_) {
+  ARP_DEV void init(const Args& A, const float* av, const float*, int slot_) {
     slot = slot_;
     const int J = A.J;
     last_ok = slot + K * (NL - 1) < J;
     sxy = A.sxy; sxx = A.sxx;
     c_sy = A.sy_tot; c_suy = A.suy_tot;
+    float wsy = 0.0f, wsuy = 0.0f;
 #pragma unroll
     for (int i = 0; i < 2 * NP; ++i) {
       const int j = slot + K * i;
       const bool ok = i < NL && j < J;
       const float nj = ok ? A.n[j] : 0.0f, sxj = ok ? A.sx[j] : 0.0f, syj = ok ? A.sy[j] : 0.0f, uj = ok ? A.u[j] : 0.0f;
       n2[i >> 1][i & 1] = nj; sx2[i >> 1][i & 1] = sxj; sy2[i >> 1][i & 1] = syj; u2[i >> 1][i & 1] = uj;
+      const float aj = (ok && av) ? av[LBASE + j] : 0.0f;
+      a2[i >> 1][i & 1] = aj;
+      wsy = fmaf(1.0f - aj, syj, wsy);
+      wsuy = fmaf((1.0f - aj) * uj, syj, wsuy);
     }
+    c_sya = group_sum<K>(wsy); c_suya = group_sum<K>(wsuy);
     if (NL & 1) mlast = v2f{last_ok ? 1.0f : 0.0f, 0.0f};
     else mlast = v2f{1.0f, last_ok ? 1.0f : 0.0f};
   }
@@ -103,10 +111,12 @@ struct RadonPk {
       const v2f mu = vfma(u2[k], vb1, (k == NP - 1 && MODE == kModeCP) ? vmua_last : vmua);
       const v2f t = vfma(vnb2, sx2[k], sy2[k]);
       v2f r, m;
-      if (MODE == kModeCP) { r = mt - mu; m = mt; } else { r = mt; m = mt + mu; }
+      if (MODE == kModeCP) { r = mt - mu; m = mt; }
+      else if (MODE == kModeNCP) { r = mt; m = mt + mu; }
+      else { r = vfma(-a2[k], mu, mt); m = r + mu; }           // general a: xt ~ N(a mu, 1), m = xt + (1 - a) mu
       const v2f l = vfma(-n2[k], m, t);
       const v2f gm = l - r;
-      const v2f h = (MODE == kModeCP) ? r : l;
+      const v2f h = (MODE == kModeCP) ? r : ((MODE == kModeNCP) ? l : vfma(-a2[k], gm, l));   // d logp / d mu
       if (k == 0) {
         ah[0] = h; auh[0] = u2[k] * h; ams[0] = m * sx2[k];
       } else {
@@ -134,10 +144,12 @@ struct RadonPk {
       const float mu = fmaf(uk, b1, MODE == kModeCP ? vmua_last[0] : mua);
       const float t = fmaf(-b2, sxk, syk);
       float r, m;
-      if (MODE == kModeCP) { r = mt - mu; m = mt; } else { r = mt; m = mt + mu; }
+      if (MODE == kModeCP) { r = mt - mu; m = mt; }
+      else if (MODE == kModeNCP) { r = mt; m = mt + mu; }
+      else { r = fmaf(-a2[k][0], mu, mt); m = r + mu; }
       const float l = fmaf(-n2[k][0], m, t);
       const float gm = l - r;
-      const float h = (MODE == kModeCP) ? r : l;
+      const float h = (MODE == kModeCP) ? r : ((MODE == kModeNCP) ? l : fmaf(-a2[k][0], gm, l));
       th_t = h; tuh_t = uk * h; tms_t = m * sxk;
       if (PASS == 0) {
         const float pn = fmaf(ek, gm, pc[k][0]);
@@ -164,7 +176,8 @@ struct RadonPk {
     } else {
       gg_[0] = g0; gg_[1] = g1; gg_[2] = g2;
       // logp = 1/2 q . (g + g(0)); g(0) = (0, 0, Sxy, Sy_j) centred, (sum Sy, sum u Sy, Sxy, Sy_j) non-centred
-      const float c0 = MODE == kModeCP ? 0.0f : c_sy, c1 = MODE == kModeCP ? 0.0f : c_suy;
+      const float c0 = MODE == kModeCP ? 0.0f : (MODE == kModeNCP ? c_sy : c_sya);
+      const float c1 = MODE == kModeCP ? 0.0f : (MODE == kModeNCP ? c_suy : c_suya);
       float top = mua * (g0 + c0);
       top = fmaf(b1, g1 + c1, top);
       top = fmaf(b2, g2 + sxy, top);
@@ -215,8 +228,10 @@ struct RadonPk {
     xg[0] = qg[0]; xg[1] = qg[1]; xg[2] = qg[2];
     const v2f vb1 = splat(qg[1]), vmua = splat(qg[0]);
 #pragma unroll
-    for (int k = 0; k < NP; ++k)
-      xc[k] = (MODE == kModeNCP) ? qc[k] + vfma(u2[k], vb1, k == NP - 1 ? vmua * mlast : vmua) : qc[k];
+    for (int k = 0; k < NP; ++k) {
+      const v2f mu = vfma(u2[k], vb1, k == NP - 1 ? vmua * mlast : vmua);
+      xc[k] = (MODE == kModeNCP) ? qc[k] + mu : ((MODE == kModeCP) ? qc[k] : vfma(splat(1.0f) - a2[k], mu, qc[k]));
+    }
   }
 };
 
