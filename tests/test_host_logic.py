@@ -170,3 +170,52 @@ def test_unsupported_flag_fails_loudly():
     from autoreparam_amd import flags as flags_mod, main as cli
     with pytest.raises(NotImplementedError):
         cli.main(["--model=8schools", "--reparameterise_variational"], flags=flags_mod.FlagValues())
+
+
+def test_streaming_ess_chain_subset_is_keyed_by_global_chain_id(monkeypatch):
+    """inference._ess_subset: which chains of a streaming run keep their whole trace for the autocorrelation ESS -- the
+    chains with GLOBAL id < --ess_chains, so the reported figure does not depend on how the job is split over ranks;
+    halved until [S, k, D] fits 40 % of the device; 0 (batch means only) when asked for or when not even 64 chains fit."""
+    import types
+    import torch
+    from autoreparam_amd import inference
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda dev: types.SimpleNamespace(total_memory=288 * 2 ** 30))
+    S, D = 50000, 125
+    # one rank: the first 1 024 chains
+    assert inference._ess_subset(S, 16384, D, "cuda:0", 0, 1024) == (1024, 1024)
+    # two ranks of 8 192: the subset lies on rank 0 alone
+    assert inference._ess_subset(S, 8192, D, "cuda:0", 0, 1024) == (1024, 1024)
+    assert inference._ess_subset(S, 8192, D, "cuda:0", 8192, 1024) == (1024, 0)
+    # a subset larger than the first rank's block spills into the second
+    assert inference._ess_subset(S, 512, D, "cuda:0", 0, 1024) == (1024, 512)
+    assert inference._ess_subset(S, 512, D, "cuda:0", 512, 1024) == (1024, 512)
+    assert inference._ess_subset(S, 512, D, "cuda:0", 1024, 1024) == (1024, 0)
+    # memory: 8 192 chains x 50 000 x 125 x 4 B = 205 GB > 40 % of 288 GiB -> halved to 4 096 (102 GB)
+    assert inference._ess_subset(S, 16384, D, "cuda:0", 0, 8192)[0] == 4096
+    # --ess_chains=0, or a device on which not even 64 chains fit: batch means only
+    assert inference._ess_subset(S, 16384, D, "cuda:0", 0, 0) == (0, 0)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda dev: types.SimpleNamespace(total_memory=2 ** 30))
+    assert inference._ess_subset(S, 16384, D, "cuda:0", 0, 1024) == (0, 0)
+
+
+def test_debug_switches_need_arp_debug(monkeypatch, capsys):
+    from autoreparam_amd import util
+    monkeypatch.setenv("ARP_SHARE_GPU", "1")
+    monkeypatch.delenv("ARP_DEBUG", raising=False)
+    assert util.debug_switch("ARP_SHARE_GPU") is None and "IGNORED" in capsys.readouterr().err
+    monkeypatch.setenv("ARP_DEBUG", "1")
+    assert util.debug_switch("ARP_SHARE_GPU") == "1" and "DEBUG SWITCH" in capsys.readouterr().err
+    monkeypatch.delenv("ARP_SHARE_GPU")
+    assert util.debug_switch("ARP_SHARE_GPU") is None and capsys.readouterr().err == ""
+
+
+def test_result_files_are_replaced_atomically(tmp_path):
+    """save_hmc_results goes through a temporary file + os.replace: a reader never sees a half-written JSON, and no
+    temporary file is left behind."""
+    import json, os
+    from autoreparam_amd import main as cli
+    p = str(tmp_path / "r.json")
+    cli.save_hmc_results(file_path=p, ess_min=1.0, ess_estimator="autocorrelation")
+    cli.save_hmc_results(file_path=p, ess_min=2.0, ess_estimator="autocorrelation")
+    assert json.load(open(p)) == {"ess_min": [1.0, 2.0], "ess_estimator": ["autocorrelation", "autocorrelation"]}
+    assert os.listdir(str(tmp_path)) == ["r.json"]
