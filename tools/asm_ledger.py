@@ -14,8 +14,11 @@ import re
 import sys
 from collections import Counter, OrderedDict
 
-COST = OrderedDict([("pk_f32", 4.4), ("trans", 8.2), ("dpp", 4.2), ("mad_u64", 5.4), ("half_rate", 4.2), ("mov", 2.6),
-                    ("valu_other", 2.6)])
+# cycles per wave-instruction per SIMD at EXACTLY two resident waves (256-register kernels), long runs, quoted at 2.4 GHz
+# (i.e. times: 1 cycle = 0.4167 ns) -- tools/pk_vs_fma_2waves.hip, round 4.  (tools/valu_bench.hip's "waves/SIMD" rows let
+# the dispatcher pack small kernels unevenly; its figures were 4.4 / 8.2 / 4.2 / 5.4 / 4.2 / 2.6.)
+COST = OrderedDict([("pk_f32", 4.43), ("trans", 8.17), ("dpp", 4.41), ("mad_u64", 4.42), ("half_rate", 4.19), ("fma3", 3.02),
+                    ("mov", 2.48), ("valu_other", 2.48)])
 TRANS = ("v_exp_", "v_log_", "v_sqrt_", "v_rsq_", "v_rcp_", "v_sin_", "v_cos_")
 HALF = ("v_lshl", "v_lshr", "v_ashr", "v_alignbit", "v_cvt_", "v_min_", "v_max_", "v_cmp", "v_cndmask", "v_bfi", "v_bfe",
         "v_readlane", "v_writelane", "v_readfirstlane", "v_mul_lo_u32", "v_mul_hi_u32")
@@ -38,6 +41,8 @@ def classify(ins):
             return "half_rate"
         if op.startswith("v_mfma"):
             return "mfma"
+        if op.startswith(("v_fma_f32", "v_fmamk_f32", "v_fmaak_f32")):
+            return "fma3"          # three source operands: 3.0 cycles against 2.5 for the two-source forms
         return "valu_other"
     if op.startswith("ds_"):
         return "lds"
