@@ -75,7 +75,7 @@ class ViIO(C.Structure):
 SYMBOLS = ["arp_version", "arp_last_error", "arp_model_create", "arp_model_destroy", "arp_model_dim",
            "arp_model_logp_const", "arp_model_set_param", "arp_logp_grad", "arp_transform",
            "arp_hmc_run", "arp_interleaved_run", "arp_vi_run", "arp_ess", "arp_ess_ws", "arp_ess_workspace_bytes",
-           "arp_adapt_probe"]
+           "arp_adapt_probe", "arp_clock_probe"]
 
 _lib = None
 
@@ -110,6 +110,7 @@ def lib():
     L.arp_ess_ws.restype = C.c_int
     L.arp_ess_workspace_bytes.argtypes = [C.c_int64, C.c_int64]
     L.arp_ess_workspace_bytes.restype = C.c_int64
+    L.arp_clock_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
     L.arp_adapt_probe.argtypes = [C.POINTER(HmcConfig), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L

@@ -245,6 +245,20 @@ class Engine(object):
         return out
 
 
+def clock_probe(device, ms=10.0):
+    """GHz the chip holds under a vector-bound load (arp_clock_probe: packed FMAs on every SIMD for ~`ms` milliseconds, one
+    wave reading s_memtime / s_memrealtime around its loop).  A measurement hook for bench.py: every roofline figure assumes
+    a clock, and the boxes differ in the one they hold."""
+    dev = torch.device(device)
+    out = torch.zeros(3, dtype=torch.int64, device=dev)
+    iters = max(1, int(ms * 1e-3 / (64 * 2 * 4.43 / 2.4e9)))       # 64 packed FMAs per iteration, two waves per SIMD
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().arp_clock_probe(iters, C.c_void_p(out.data_ptr()), _stream()))
+        torch.cuda.synchronize(dev)
+    cyc, ticks = int(out[0].item()), int(out[1].item())
+    return (cyc / ticks) * 0.1 if ticks > 0 else None
+
+
 def stats_summary(stats, n, batch):
     """(mean, var, ess) [C, D] float64 tensors from an `arp_hmc_io.stats` buffer after `n` recorded samples:
     mean = ref + s1/n, var = (s2 - s1^2/n)/(n-1), ESS by batch means, n var / (batch var(batch means)), capped at n."""

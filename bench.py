@@ -420,6 +420,12 @@ def main():
     elapsed = time.perf_counter() - t0
     per_launch_ms = [float(a.elapsed_time(b)) for a, b in ev]
     kern_ms = float(np.mean(per_launch_ms))
+    # the shader clock this box holds under a vector-bound load, measured now, while the chip is at the temperature and power
+    # state of the timed region (arp_clock_probe: s_memtime / s_memrealtime around 10 ms of packed FMAs on every SIMD)
+    try:
+        clock_live = engine.clock_probe(dev, 10.0)
+    except Exception:
+        clock_live = None
 
     # end-of-run statistics exchange (the only collectives of the path, parallel.py): all-gather of a per-chain
     # statistic (here the acceptance rate; a sampling run gathers the per-chain minimum ESS the same way) and the
@@ -724,6 +730,11 @@ def main():
             out_rccl = world
         else:
             out_rccl = None
+        roof["clock_ghz_live"] = clock_live
+        roof["clock_live_note"] = ("shader clock held under 10 ms of packed FMAs on every SIMD right after the timed region "
+                                   "(arp_clock_probe); the 157.3 TFLOP/s peak assumes 2.4 GHz: frac x 2.4 / clock_ghz_live is the "
+                                   "fraction of what THIS box can issue")
+        roof["frac_of_peak_at_live_clock"] = (achieved_tf / (FP32_PEAK_TFLOPS * clock_live / 2.4)) if clock_live else None
         if prof:
             roof["profile"] = prof
             # shader clock held under this kernel's load (GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the profiled pass);

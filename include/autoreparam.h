@@ -224,6 +224,12 @@ int arp_ess_ws(const float* trace, int64_t n_samples, int64_t n_series, int64_t 
 int arp_adapt_probe(const arp_hmc_config* cfg, const float* log_accept, int n, float* adapt, float* kappa_out,
                     void* stream);
 
+/* Measurement hook (no reference counterpart): the shader clock the chip holds under a vector-bound load.  Runs packed FMAs
+ * on every SIMD (two resident waves each) for `iters` loop iterations of 64 instructions (~ 0.27 us each) while one wave
+ * reads s_memtime (shader cycles) and s_memrealtime (100 MHz) around its loop; cycles_ticks (device, 3 x uint64) receives
+ * {shader cycles, 100 MHz ticks, 1}.  bench.py reports cycles / ticks x 0.1 GHz next to every roofline figure. */
+int arp_clock_probe(int iters, unsigned long long* cycles_ticks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -206,3 +206,13 @@ def test_long_series_ess_on_the_matrix_cores(gpu):
     # a series that never decorrelates within the trace (a trend): every lag positive until the weights run out
     t = torch.linspace(0, 1, 2500, device=gpu).reshape(-1, 1, 1) + 0.01 * torch.randn(2500, 2, 3, device=gpu)
     np.testing.assert_allclose(util.effective_sample_size(t).cpu().numpy(), ess_ref.ess_fft(t.cpu().numpy()), rtol=5e-3)
+
+
+def test_clock_probe_reports_a_plausible_shader_clock(gpu):
+    """arp_clock_probe (measurement hook of bench.py): shader cycles over 100 MHz ticks of a vector-bound load -- an MI355X
+    holds 1.9 - 2.4 GHz under it; bad arguments fail loudly."""
+    import ctypes as C
+    from autoreparam_amd import engine, _lib
+    ghz = engine.clock_probe(gpu, 5.0)
+    assert ghz is not None and 1.2 < ghz < 2.6, ghz
+    assert _lib.lib().arp_clock_probe(0, C.c_void_p(0), C.c_void_p(0)) != 0
