@@ -449,6 +449,7 @@ extern "C" int arp_ess_ws(const float* trace, int64_t n_samples, int64_t n_serie
   const bool long_series = n_samples + 72 > kEssRows * 64;
   const long long SR = ess_row_floats(n_samples);
   if (long_series && workspace) {
+    if (SR / 64 > 65535) { set_error("arp_ess_ws: at most 4 194 240 samples per series on the workspace path"); return 1; }
     if (((uintptr_t)workspace & 255) != 0) { set_error("arp_ess_ws: the workspace must be 256-byte aligned"); return 1; }
     const EssWsLayout Lw(n_series);
     rows_cap = workspace_bytes > (int64_t)Lw.off_rows ? ((workspace_bytes - (int64_t)Lw.off_rows) / (SR * 4)) & ~63ll : 0;
