@@ -512,7 +512,7 @@ def main():
         # and one log1p each + 51 x 10) + 4 D for the leapfrog update
         espec = models._spec_election()
         eeng = engine.Engine(espec, dev)
-        Ce, Le, Te = 131072, 4, 128   # launch length as for german credit above
+        Ce, Le, Te = 131072, 4, 1024   # launch length as the CLI's (rounds 1 - 3 timed 128-transition launches: 1.77e10 against 1.98e10)
         rse = np.random.RandomState(2)
         eflop = 4500.0 + 4.0 * espec.D
         el = {}
@@ -525,6 +525,7 @@ def main():
             ste = engine.ChainState(torch.as_tensor((0.05 * rse.randn(Ce, espec.D)).astype(np.float32), device=dev))
             epse = np.full(espec.D, 0.02, np.float32)
             kwe = dict(seed=5, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9)
+            ems_short = _time_launches(lambda: eeng.hmc_run(ste, epse, Le, 128, **kwe), 3, 1)     # rounds 1 - 3's launch length
             ems = _time_launches(lambda: eeng.hmc_run(ste, epse, Le, Te, **kwe), 3, 1)
             rate = Ce * Te * Le / (ems * 1e-3)
             ib, ib_cyc = election_issue_bound(name, Le)
@@ -532,7 +533,9 @@ def main():
             # profile): the nominal 2.4 GHz overstates what back-to-back issue could deliver on this box
             prof_clk = ((load_profile({}) or {}).get("derived") or {}).get("clock_ghz_estimate")
             ib_held = election_issue_bound(name, Le, prof_clk)[0] if prof_clk else None
-            el[name] = {"kernel_ms": ems, "leapfrog_steps_per_s": rate,
+            el[name] = {"kernel_ms": ems, "leapfrog_steps_per_s": rate, "transitions_per_launch": Te,
+                        "at_round3_launch_length": {"transitions_per_launch": 128, "kernel_ms": ems_short,
+                                                    "leapfrog_steps_per_s": Ce * 128 * Le / (ems_short * 1e-3)},
                         "roofline": {"bound": "valu", "achieved": Ce * Te * Le * eflop / (ems * 1e-3) / 1e12,
                                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                      "frac": Ce * Te * Le * eflop / (ems * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
@@ -557,22 +560,34 @@ def main():
     if secondary:
         others = {}
 
-        def time_model(tag, mspec, reparam, Cm, Lm, Tm, step, flop_lf, note):
+        def time_model(tag, mspec, reparam, Cm, Lm, Tm, step, flop_lf, note, T_long=1024):
+            """One entry: the fused HMC kernel at `T_long` transitions per launch (what the CLI's launches look like: up to
+            4 096 per launch), and -- for continuity with rounds 1 - 3, which timed these models at 16 - 256 transitions per
+            launch, i.e. inside the clock ramp and with the state load / store a sixth of the launch -- at `Tm` as well
+            (tools/launch_length_sweep.py: radon_stddvs 1.09e10 at 16 transitions per launch, 1.43e10 at 1 024)."""
             try:
                 me = engine.Engine(mspec, dev)
                 me.set_param(0, reparam)
-                rsm = np.random.RandomState(3)
-                stm = engine.ChainState(torch.as_tensor((0.1 * rsm.randn(Cm, mspec.D)).astype(np.float32), device=dev))
-                epm = np.full(mspec.D, step, np.float32)
-                kwm = dict(seed=5, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9)
-                msm = _time_launches(lambda: me.hmc_run(stm, epm, Lm, Tm, **kwm), 3, 1)
-                rate = Cm * Tm * Lm / (msm * 1e-3)
-                others[tag] = {"chains": Cm, "num_leapfrog_steps": Lm, "transitions_per_launch": Tm, "kernel_ms": msm,
-                               "leapfrog_steps_per_s": rate, "accept_rate": float(stm.accept_count.float().mean().item() / stm.step),
+                res = {}
+                for label, Tn in (("short", Tm), ("long", T_long)):
+                    rsm = np.random.RandomState(3)
+                    stm = engine.ChainState(torch.as_tensor((0.1 * rsm.randn(Cm, mspec.D)).astype(np.float32), device=dev))
+                    epm = np.full(mspec.D, step, np.float32)
+                    kwm = dict(seed=5, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9)
+                    msm = _time_launches(lambda: me.hmc_run(stm, epm, Lm, Tn, **kwm), 3, 1)
+                    res[label] = (Tn, msm, Cm * Tn * Lm / (msm * 1e-3), float(stm.accept_count.float().mean().item() / stm.step))
+                    del stm
+                Tn, msm, rate, accr = res["long"]
+                others[tag] = {"chains": Cm, "num_leapfrog_steps": Lm, "transitions_per_launch": Tn, "kernel_ms": msm,
+                               "leapfrog_steps_per_s": rate, "accept_rate": accr,
                                "roofline": {"bound": "valu", "achieved": rate * flop_lf / 1e12, "peak": FP32_PEAK_TFLOPS,
                                             "unit": "TFLOP/s", "frac": rate * flop_lf / 1e12 / FP32_PEAK_TFLOPS,
-                                            "algorithmic_flop_per_leapfrog": flop_lf}, "note": note}
-                del me, stm
+                                            "algorithmic_flop_per_leapfrog": flop_lf},
+                               "at_round3_launch_length": {"transitions_per_launch": res["short"][0], "kernel_ms": res["short"][1],
+                                                           "leapfrog_steps_per_s": res["short"][2],
+                                                           "frac": res["short"][2] * flop_lf / 1e12 / FP32_PEAK_TFLOPS},
+                               "note": note}
+                del me
             except Exception as e:
                 others[tag] = {"error": repr(e)}
 
