@@ -748,7 +748,9 @@ def main():
         roof["clock_ghz_live"] = clock_live
         roof["clock_live_note"] = ("shader clock held under 10 ms of packed FMAs on every SIMD right after the timed region "
                                    "(arp_clock_probe); the 157.3 TFLOP/s peak assumes 2.4 GHz: frac x 2.4 / clock_ghz_live is the "
-                                   "fraction of what THIS box can issue")
+                                   "fraction of what THIS box can issue.  An upper estimate of the clock under the headline kernel "
+                                   "itself, which holds ~ 7 % less with its LDS traffic and trace stores "
+                                   "(profiles/r04_box_to_box.txt)")
         roof["frac_of_peak_at_live_clock"] = (achieved_tf / (FP32_PEAK_TFLOPS * clock_live / 2.4)) if clock_live else None
         if prof:
             roof["profile"] = prof
