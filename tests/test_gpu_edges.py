@@ -203,6 +203,11 @@ def test_long_series_ess_on_the_matrix_cores(gpu):
     # leading block of chains of a wider trace, taken in place (a streaming run's kept trace)
     sub = util.effective_sample_size(xd[:, :7, :]).cpu().numpy()
     assert np.array_equal(sub, got[:7])
+    # one slowly mixing series per wave (64 series per chain, one of them slow): the wave skips its dense continuation and
+    # lists the series at lag 16 -- the tail starts from block 1 instead of block 3
+    rho64 = np.zeros(64); rho64[5] = 0.99; rho64[40] = 0.6
+    y = torch.as_tensor(ess_ref.ar1(4000, (3, 64), rho64, seed=13), dtype=torch.float32)
+    np.testing.assert_allclose(util.effective_sample_size(y.to(gpu)).cpu().numpy(), ess_ref.ess_fft(y.numpy()), rtol=2e-3)
     # a series that never decorrelates within the trace (a trend): every lag positive until the weights run out
     t = torch.linspace(0, 1, 2500, device=gpu).reshape(-1, 1, 1) + 0.01 * torch.randn(2500, 2, 3, device=gpu)
     np.testing.assert_allclose(util.effective_sample_size(t).cpu().numpy(), ess_ref.ess_fft(t.cpu().numpy()), rtol=5e-3)
