@@ -314,7 +314,7 @@ def _sample(run_segment, st, S, B, thin, C, D, dev, keep_chains, n_acc, chunk_ro
     k_total, k_ess = _ess_subset(S, C, D, dev, chain_offset, ess_chains)
     k = max(k_ess, keep_chains)            # --num_chains_to_save chains keep their trace on every rank, as before
     stats = torch.zeros(6, C, D, dtype=torch.float32, device=dev)
-    kept = torch.zeros(S, k, D, dtype=torch.float32, device=dev)
+    kept = torch.empty(S, k, D, dtype=torch.float32, device=dev)      # every row is written by the run (25.6 GB at config 3: no fill)
     racc = [torch.zeros(C, dtype=torch.int32, device=dev) for _ in range(n_acc)]
     extra = dict(stats=stats, stats_batch=batch, n_samples=S, trace_chains=k)
     for j in range(n_acc):
