@@ -461,6 +461,10 @@ def main():
         lnt, _ = make_launcher(T, thin, record=False)
         ms = _time_launches(lnt, 5, 2)
         extras["no_trace"] = {"transitions_per_launch": T, "kernel_ms": ms, "leapfrog_steps_per_s": C * T * LL / (ms * 1e-3)}
+        if D == 71 and num_ls == 4 and args.lanes in (0, 4):
+            # the same instruction mix minus the row stores (~ 20 instructions per step): how much of the launch the rows
+            # account for beyond their instructions
+            extras["no_trace"]["issue_bound_frac"] = extras["no_trace"]["leapfrog_steps_per_s"] / headline_issue_bound(2.4)[0]
         lst, _ = make_launcher(T, thin, stats=True)
         ms = _time_launches(lst, 5, 2)
         extras["in_kernel_stats"] = {"transitions_per_launch": T, "thin": thin, "stats_batch": 64, "kernel_ms": ms,
