@@ -430,6 +430,55 @@ def test_posterior_moments_against_long_cpu_run(gpu, mname, kind, L, Cn):
         assert (np.abs(mean[big] / mean_g[big] - 1) < 0.01).all()
 
 
+@pytest.mark.parametrize("mname", ["radon_PA", "election"])
+def test_general_ab_packed_kernels_sample_the_same_posterior(gpu, oracle_lib, mname):
+    """The packed general-(a, b) forms (round 4: pk_hmc_kernel<RadonPk / ElectionPk, kModeVIP>, what cVIP / dVIP and untied
+    runs execute): the posterior of the CENTRED coordinates does not depend on the parameterisation -- radon PA against
+    its closed form, election against the long float64 fixture -- from states started in VIP coordinates."""
+    import os
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec(mname)
+    eng = _eng(mname, gpu)
+    a, b = helpers.params(sp, "VIP", seed=3)
+    eng.set_param(0, (a, b))
+    D = sp.D
+    rs = np.random.RandomState(2)
+    if mname == "radon_PA":
+        orc = oracle_lib.OracleModel(sp)
+        ac, bc = helpers.params(sp, "CP")
+        _, g0 = orc.logp_grad(np.zeros((1, D)), ac, bc)
+        _, gI = orc.logp_grad(np.eye(D), ac, bc)
+        Pm = -(gI - g0)
+        mean_g = np.linalg.solve(Pm, g0[0]); sd_g = np.sqrt(np.diag(np.linalg.inv(Pm))); mcse_g = np.zeros(D)
+        Cn, L, burn, S = 8192, 8, 400, 200
+        x0 = mean_g + 1.5 * sd_g * rs.randn(Cn, D)
+        eps0 = (0.6 * sd_g).astype(np.float32)
+    else:
+        gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "posterior_golden.npz"))
+        mean_g, sd_g, mcse_g = gold["election/mean"], gold["election/sd"], gold["election/mcse"]
+        Cn, L, burn, S = 2048, 8, 1500, 300
+        x0 = mean_g + 0.5 * sd_g * rs.randn(Cn, D)
+        eps0 = (0.25 * sd_g).astype(np.float32)
+    q0 = eng.transform(x0.astype(np.float32), which=0, to_centered=False)          # centred -> VIP coordinates
+    back = eng.transform(q0, which=0, to_centered=True).cpu().numpy()
+    np.testing.assert_allclose(back, x0, rtol=2e-4, atol=2e-4 * np.abs(x0).max())
+    st = engine.ChainState(q0)
+    tr = torch.zeros(S, Cn, D, device=gpu)
+    eng.hmc_run(st, eps0, L, 1 + burn + 2 * (S - 1), seed=21, adapt_kind=_lib.ADAPT_DUAL, n_adapt=burn - 100, n_burnin=burn,
+                thin=2, trace=tr, trace_centered=True)
+    acc = st.accept_count.double().mean().item() / st.step
+    assert 0.55 < acc < 0.95, acc
+    cm = tr.double().mean(dim=0).cpu().numpy()
+    mean = cm.mean(axis=0)
+    mcse = cm.std(axis=0, ddof=1) / np.sqrt(Cn)
+    sd = tr.double().reshape(-1, D).std(dim=0).cpu().numpy()
+    z = np.abs(mean - mean_g) / (np.sqrt(mcse ** 2 + mcse_g ** 2) + 0.01 * sd_g)
+    assert z.max() < 5.0, (int(z.argmax()), float(z.max()))
+    assert np.abs(sd / sd_g - 1).max() < 0.10
+    if mname == "radon_PA":
+        assert np.abs(mean[:3] - mean_g[:3]).max() <= 0.01 * np.abs(mean_g[:3]).max()      # "posterior means within 1 %"
+
+
 @pytest.mark.parametrize("mname,lanes", [("radon_PA", 4), ("radon_PA", 8), ("election", 4), ("german", 4), ("8schools", 2)])
 def test_in_kernel_statistics_match_trace_and_oracle(oracle_lib, gpu, mname, lanes):
     """arp_hmc_io.stats / rec_accept_count / trace_chains: the statistics the kernel accumulates while sampling
