@@ -62,9 +62,11 @@ struct ElectricLane {
   float lat_last;   // 1 if the lane's last slice is a pair effect, 0 if it is the observation-only group P or padding
   ARP_DEV float lat(int i) const { return i < NL - 1 ? 1.0f : lat_last; }
   float si[kElG], cs[kElG];   // 1/100^b and 100^(1-b) of b_k
+  float nk[kElG];             // observations of the lane's groups by grade: sum_j nn_j s_{g_j} = sum_k nk_k s_k
   int slot, P;
 
-  // table entry of (slice i, slot): [wm0..3][og0..3][n0 y0 n1 y1][ss - - -], 20 floats apart.
+  // table entry of (slice i, slot): [wm0..3][og0..3][n0 y0 n1 y1][ss z nn -], 20 floats apart (z = 1 - sum_k og_k: 1 for a
+  // group whose grade falls on one_hot's all-zero row, nn = n0 + n1).
   // Bank conflicts (MI355X_MICROARCH.md, LDS): a ds_read_b128 is served in groups of 16 lanes over 64 banks; the K
   // distinct entries a group touches must fall on distinct 4-bank windows.  At round 3's stride of 16 dwords slots s
   // and s + 4 shared a window (2-way on each of the three b128 reads) and the lone `ss` went out as a ds_read_b32
@@ -76,29 +78,35 @@ struct ElectricLane {
     __shared__ __attribute__((aligned(16))) float tab[NL * K * kEntry];
     return tab;
   }
-  // the entry's index is laundered: the table is loop invariant, and left to itself the compiler hoists every read out
-  // of the leapfrog loop into registers -- the very registers the table is there to save
-  ARP_DEV int entry(int i) const {
-    int e = (i * K + slot) * kEntry;
+  // The lane's offset into the table is laundered ONCE per use of the model (gradient, coordinate change): the table is
+  // loop invariant, and left to itself the compiler hoists every read out of the leapfrog loop into registers -- the
+  // very registers the table is there to save.  The slices sit at compile-time distances behind it, so a pair's four
+  // reads share one address register and differ in their immediate offsets.
+  ARP_DEV int table_off() const {
+    int e = slot * kEntry;
     asm volatile("" : "+v"(e));
     return e;
   }
-  ARP_DEV void onehot(int i, float (&wm)[kElG], float (&og)[kElG]) const {
-    const float4* t = reinterpret_cast<const float4*>(onehot_table() + entry(i));
+  static ARP_DEV const float4* entry(int t0, int i) {
+    return reinterpret_cast<const float4*>(onehot_table() + t0 + i * (K * kEntry));
+  }
+  ARP_DEV void onehot(int t0, int i, float (&wm)[kElG], float (&og)[kElG]) const {
+    const float4* t = entry(t0, i);
     const float4 a = t[0], b = t[1];
     wm[0] = a.x; wm[1] = a.y; wm[2] = a.z; wm[3] = a.w;
     og[0] = b.x; og[1] = b.y; og[2] = b.z; og[3] = b.w;
   }
-  // the pair's two cells: counts and means of the control / treated scores, pooled within-cell sum of squares
-  ARP_DEV void cells(int i, float& n0, float& y0, float& n1, float& y1, float& ss) const {
-    const float4* e = reinterpret_cast<const float4*>(onehot_table() + entry(i));
+  // the pair's two cells: counts and means of the control / treated scores, pooled within-cell sum of squares; z and nn
+  // as above
+  ARP_DEV void cells(int t0, int i, float& n0, float& y0, float& n1, float& y1, float& ss, float& z, float& nn) const {
+    const float4* e = entry(t0, i);
     const float4 c = e[2];
     float4 d = e[3];
     // the whole quad passes through an (empty) asm statement, so the compiler cannot narrow the read to a ds_read_b32
     // (served over 32 banks: 4-way conflicts at this stride) again
     asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
     n0 = c.x; y0 = c.y; n1 = c.z; y1 = c.w;
-    ss = d.x;
+    ss = d.x; z = d.y; nn = d.z;
   }
 
   // flattened index of replicated scalar i: mua, sigma_y in front of a[P], b behind it
@@ -123,11 +131,24 @@ struct ElectricLane {
         }
         float* e = tab + (i * K + slot) * kEntry + 8;
         e[0] = has ? A.n0[j] : 0.0f; e[1] = has ? A.y0[j] : 0.0f; e[2] = has ? A.n1[j] : 0.0f; e[3] = has ? A.y1[j] : 0.0f;
-        e[4] = has ? A.ss[j] : 0.0f; e[5] = 0.0f; e[6] = 0.0f; e[7] = 0.0f;
+        float ogs = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kElG; ++k) ogs += has ? A.og[k * stride + j] : 0.0f;
+        e[4] = has ? A.ss[j] : 0.0f; e[5] = has ? 1.0f - ogs : 0.0f; e[6] = has ? A.n0[j] + A.n1[j] : 0.0f; e[7] = 0.0f;
         e[8] = e[9] = e[10] = e[11] = 0.0f;
       }
     }
     lat_last = slot + K * (NL - 1) < P ? 1.0f : 0.0f;
+#pragma unroll
+    for (int k = 0; k < kElG; ++k) nk[k] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int j = slot + K * i;
+      if (j <= P) {
+#pragma unroll
+        for (int k = 0; k < kElG; ++k) nk[k] = fmaf(A.og[k * stride + j], A.n0[j] + A.n1[j], nk[k]);
+      }
+    }
     __syncthreads();
     set_param(av, bv);
   }
@@ -142,35 +163,40 @@ struct ElectricLane {
     for (int i = 0; i < NL; ++i) al[i] = lvalid(i) ? av[LBASE + slot + K * i] : 0.0f;
   }
 
+  // The grade scalars reach a group through one-hot FMAs.  exp(-2 s_g) is formed once per grade, not once per group:
+  // sum_k og_k wk_k + z is the very value exp(-2 sum_k og_k s_k) has (one weight is 1, the others 0; z = 1 covers the
+  // all-zero row, exp(0)), so a gradient takes 4 exponentials instead of NL; likewise sum_j nn_j s_{g_j} is taken per
+  // grade (nk) and the treatment slope's w e1 is scaled by the grade's w after the scatter.
   template <bool LOGP>
   ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const {
-    float bb[kElG], dM[kElG], dS[kElG], dB[kElG];
+    float bb[kElG], wk[kElG], dM[kElG], dS[kElG], dB[kElG];
 #pragma unroll
-    for (int k = 0; k < kElG; ++k) { bb[k] = cs[k] * q[2 * kElG + k]; dM[k] = 0.0f; dS[k] = 0.0f; dB[k] = 0.0f; }
+    for (int k = 0; k < kElG; ++k) {
+      bb[k] = cs[k] * q[2 * kElG + k]; wk[k] = fast_exp(-2.0f * q[kElG + k]);
+      dM[k] = 0.0f; dS[k] = 0.0f; dB[k] = 0.0f;
+    }
     float lp = 0.0f;
+    const int t0 = table_off();
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       float wm[kElG], og[kElG];
-      onehot(i, wm, og);
-      float mu = 0.0f, sg = 0.0f, bg = 0.0f;
+      onehot(t0, i, wm, og);
+      float n0, y0, n1, y1, ss, z, nn;
+      cells(t0, i, n0, y0, n1, y1, ss, z, nn);
+      float mu = wm[0] * q[0], w = fmaf(og[0], wk[0], z), bg = og[0] * bb[0];   // (a product, not an FMA onto zero)
 #pragma unroll
-      for (int k = 0; k < kElG; ++k) {
+      for (int k = 1; k < kElG; ++k) {
         mu = fmaf(wm[k], q[k], mu);
-        sg = fmaf(og[k], q[kElG + k], sg);
+        w = fmaf(og[k], wk[k], w);
         bg = fmaf(og[k], bb[k], bg);
       }
       const float r = fmaf(-al[i], mu, q[NG + i]);   // group P / padding: q = 0, al = 0, wm = 0 -> r = 0
       const float aj = r + mu;
-      const float w = fast_exp(-2.0f * sg);
-      float n0, y0, n1, y1, ss;
-      cells(i, n0, y0, n1, y1, ss);
       const float r0 = y0 - aj, r1 = (y1 - aj) - bg;
       const float e0 = n0 * r0, e1 = n1 * r1;
       const float dA = w * (e0 + e1);
       const float Q = fmaf(e0, r0, fmaf(e1, r1, ss));
-      const float nn = n0 + n1;
       const float dSv = fmaf(w, Q, -nn);
-      const float dBv = w * e1;
       const float ga = lat(i) * (dA - r);
       g[NG + i] = ga;
       const float hm = fmaf(-al[i], ga, dA);   // d / d mu_j
@@ -178,9 +204,9 @@ struct ElectricLane {
       for (int k = 0; k < kElG; ++k) {
         dM[k] = fmaf(wm[k], hm, dM[k]);
         dS[k] = fmaf(og[k], dSv, dS[k]);
-        dB[k] = fmaf(og[k], dBv, dB[k]);
+        dB[k] = fmaf(og[k], e1, dB[k]);
       }
-      if (LOGP) lp += fmaf(-0.5f * r, r, fmaf(-0.5f * w, Q, -nn * sg));
+      if (LOGP) lp += fmaf(-0.5f * r, r, -0.5f * w * Q);
     }
     float pri = 0.0f;
 #pragma unroll
@@ -188,8 +214,8 @@ struct ElectricLane {
       const float u = q[2 * kElG + k] * si[k];
       g[k] = group_sum<K>(dM[k]) - q[k];
       g[kElG + k] = group_sum<K>(dS[k]) - q[kElG + k];
-      g[2 * kElG + k] = fmaf(cs[k], group_sum<K>(dB[k]), -u * si[k]);
-      if (LOGP) pri += fmaf(q[k], q[k], fmaf(q[kElG + k], q[kElG + k], u * u));
+      g[2 * kElG + k] = fmaf(cs[k], group_sum<K>(wk[k] * dB[k]), -u * si[k]);
+      if (LOGP) { pri += fmaf(q[k], q[k], fmaf(q[kElG + k], q[kElG + k], u * u)); lp = fmaf(-nk[k], q[kElG + k], lp); }
     }
     if (LOGP) lp = group_sum<K>(lp) - 0.5f * pri;
     return lp;
@@ -203,10 +229,11 @@ struct ElectricLane {
 #pragma unroll
     for (int k = 0; k < kElG; ++k)
       db[2 * kElG + k] = -4.605170185988092f * fmaf(q[2 * kElG + k], g[2 * kElG + k], 1.0f);
+    const int t0 = table_off();
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       float wm[kElG], og[kElG];
-      onehot(i, wm, og);
+      onehot(t0, i, wm, og);
       float mu = 0.0f;
 #pragma unroll
       for (int k = 0; k < kElG; ++k) mu = fmaf(wm[k], q[k], mu);
@@ -217,10 +244,11 @@ struct ElectricLane {
   ARP_DEV void to_centered(const float (&q)[ND], float (&x)[ND]) const {
 #pragma unroll
     for (int k = 0; k < kElG; ++k) { x[k] = q[k]; x[kElG + k] = q[kElG + k]; x[2 * kElG + k] = cs[k] * q[2 * kElG + k]; }
+    const int t0 = table_off();
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       float wm[kElG], og[kElG];
-      onehot(i, wm, og);
+      onehot(t0, i, wm, og);
       float mu = 0.0f;
 #pragma unroll
       for (int k = 0; k < kElG; ++k) mu = fmaf(wm[k], q[k], mu);
@@ -230,10 +258,11 @@ struct ElectricLane {
   ARP_DEV void from_centered(const float (&x)[ND], float (&q)[ND]) const {
 #pragma unroll
     for (int k = 0; k < kElG; ++k) { q[k] = x[k]; q[kElG + k] = x[kElG + k]; q[2 * kElG + k] = x[2 * kElG + k] / cs[k]; }
+    const int t0 = table_off();
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       float wm[kElG], og[kElG];
-      onehot(i, wm, og);
+      onehot(t0, i, wm, og);
       float mu = 0.0f;
 #pragma unroll
       for (int k = 0; k < kElG; ++k) mu = fmaf(wm[k], x[k], mu);

@@ -606,7 +606,7 @@ def main():
                    "per county 6 sufficient statistics and one exp: ~45 flop per county and gradient; 8 lanes per chain, county tables in LDS, two waves per SIMD")
         el = models._spec_electric()
         time_model("electric_NCP_65536", el, "NCP", 65536, 8, 16, 0.01, 97 * 60.0 + 12 * 10.0 + 4.0 * el.D,
-                   "97 groups x ~60 flop (two cells, one-hot grade look-ups as 12 FMAs, one exp) + 12 grade scalars; 8 lanes per chain, tables in LDS")
+                   "97 groups x ~60 flop (two cells, one-hot grade look-ups as 12 FMAs; exp(-2 s) once per grade) + 12 grade scalars; 8 lanes per chain, tables in LDS")
         ts = models._spec_time_series()
         time_model("time_series_NCP_65536", ts, "NCP", 65536, 8, 16, 0.05, 60 * 80.0 + 4.0 * ts.D,
                    "60 time steps x ~80 flop of the general form (centring recurrence and its adjoint as block scans); the run takes the compile-time non-centred form (no per-step exp, unit block maps), 4 lanes per chain")
