@@ -19,7 +19,9 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+if len(sys.argv) != 2:
+    sys.exit(__doc__)
+tag = sys.argv[1]
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
