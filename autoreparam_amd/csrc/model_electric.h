@@ -51,7 +51,8 @@ struct ElectricLane {
   // only the last slice can be padding: NL == ceil(groups / K) is enforced by the host
   ARP_DEV bool lvalid(int i) const { return i < NL - 1 ? true : last_ok; }
   bool last_ok;
-  static constexpr bool HAS_MODES = false;
+  static constexpr bool HAS_MODES = true;         // compile-time centred / non-centred forms (grad_m below)
+  static constexpr bool HAS_MODE_STATE = false;   // their scales of b are constants
   static constexpr bool HAS_CARRY = false;
   static constexpr bool HAS_FUSED = false;
   static constexpr bool HAS_VI = true;
@@ -64,6 +65,11 @@ struct ElectricLane {
   float si[kElG], cs[kElG];   // 1/100^b and 100^(1-b) of b_k
   float nk[kElG];             // observations of the lane's groups by grade: sum_j nn_j s_{g_j} = sum_k nk_k s_k
   int slot, P;
+  // the parameterisation as the kernel sees it: run-time (a, b) in the general form; centred (a = b = 1: a_j = at_j,
+  // b_k = bt_k) and non-centred (a = b = 0: a_j = at_j + mu_j, b_k = 100 bt_k) as constants
+  template <int MODE> ARP_DEV float alv(int i) const { return MODE == kModeCP ? 1.0f : MODE == kModeNCP ? 0.0f : al[i]; }
+  template <int MODE> ARP_DEV float csv(int k) const { return MODE == kModeCP ? 1.0f : MODE == kModeNCP ? 100.0f : cs[k]; }
+  template <int MODE> ARP_DEV float siv(int k) const { return MODE == kModeCP ? 0.01f : MODE == kModeNCP ? 1.0f : si[k]; }
 
   // table entry of (slice i, slot): [wm0..3][og0..3][n0 y0 n1 y1][ss z nn -], 20 floats apart (z = 1 - sum_k og_k: 1 for a
   // group whose grade falls on one_hot's all-zero row, nn = n0 + n1).
@@ -168,11 +174,13 @@ struct ElectricLane {
   // all-zero row, exp(0)), so a gradient takes 4 exponentials instead of NL; likewise sum_j nn_j s_{g_j} is taken per
   // grade (nk) and the treatment slope's w e1 is scaled by the grade's w after the scatter.
   template <bool LOGP>
-  ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const {
+  ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const { return grad_m<LOGP, kModeVIP>(q, g); }
+  template <bool LOGP, int MODE>
+  ARP_DEV float grad_m(const float (&q)[ND], float (&g)[ND]) const {
     float bb[kElG], wk[kElG], dM[kElG], dS[kElG], dB[kElG];
 #pragma unroll
     for (int k = 0; k < kElG; ++k) {
-      bb[k] = cs[k] * q[2 * kElG + k]; wk[k] = fast_exp(-2.0f * q[kElG + k]);
+      bb[k] = csv<MODE>(k) * q[2 * kElG + k]; wk[k] = fast_exp(-2.0f * q[kElG + k]);
       dM[k] = 0.0f; dS[k] = 0.0f; dB[k] = 0.0f;
     }
     float lp = 0.0f;
@@ -190,7 +198,7 @@ struct ElectricLane {
         w = fmaf(og[k], wk[k], w);
         bg = fmaf(og[k], bb[k], bg);
       }
-      const float r = fmaf(-al[i], mu, q[NG + i]);   // group P / padding: q = 0, al = 0, wm = 0 -> r = 0
+      const float r = fmaf(-alv<MODE>(i), mu, q[NG + i]);   // group P / padding: q = 0, wm = 0 -> mu = 0, r = 0
       const float aj = r + mu;
       const float r0 = y0 - aj, r1 = (y1 - aj) - bg;
       const float e0 = n0 * r0, e1 = n1 * r1;
@@ -199,7 +207,7 @@ struct ElectricLane {
       const float dSv = fmaf(w, Q, -nn);
       const float ga = lat(i) * (dA - r);
       g[NG + i] = ga;
-      const float hm = fmaf(-al[i], ga, dA);   // d / d mu_j
+      const float hm = fmaf(-alv<MODE>(i), ga, dA);   // d / d mu_j
 #pragma unroll
       for (int k = 0; k < kElG; ++k) {
         dM[k] = fmaf(wm[k], hm, dM[k]);
@@ -211,10 +219,10 @@ struct ElectricLane {
     float pri = 0.0f;
 #pragma unroll
     for (int k = 0; k < kElG; ++k) {
-      const float u = q[2 * kElG + k] * si[k];
+      const float u = q[2 * kElG + k] * siv<MODE>(k);
       g[k] = group_sum<K>(dM[k]) - q[k];
       g[kElG + k] = group_sum<K>(dS[k]) - q[kElG + k];
-      g[2 * kElG + k] = fmaf(cs[k], group_sum<K>(wk[k] * dB[k]), -u * si[k]);
+      g[2 * kElG + k] = fmaf(csv<MODE>(k), group_sum<K>(wk[k] * dB[k]), -u * siv<MODE>(k));
       if (LOGP) { pri += fmaf(q[k], q[k], fmaf(q[kElG + k], q[kElG + k], u * u)); lp = fmaf(-nk[k], q[kElG + k], lp); }
     }
     if (LOGP) lp = group_sum<K>(lp) - 0.5f * pri;
@@ -241,9 +249,12 @@ struct ElectricLane {
     }
   }
 
-  ARP_DEV void to_centered(const float (&q)[ND], float (&x)[ND]) const {
+  ARP_DEV void to_centered(const float (&q)[ND], float (&x)[ND]) const { to_centered_m<kModeVIP>(q, x); }
+  ARP_DEV void from_centered(const float (&x)[ND], float (&q)[ND]) const { from_centered_m<kModeVIP>(x, q); }
+  template <int MODE>
+  ARP_DEV void to_centered_m(const float (&q)[ND], float (&x)[ND]) const {
 #pragma unroll
-    for (int k = 0; k < kElG; ++k) { x[k] = q[k]; x[kElG + k] = q[kElG + k]; x[2 * kElG + k] = cs[k] * q[2 * kElG + k]; }
+    for (int k = 0; k < kElG; ++k) { x[k] = q[k]; x[kElG + k] = q[kElG + k]; x[2 * kElG + k] = csv<MODE>(k) * q[2 * kElG + k]; }
     const int t0 = table_off();
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -252,12 +263,13 @@ struct ElectricLane {
       float mu = 0.0f;
 #pragma unroll
       for (int k = 0; k < kElG; ++k) mu = fmaf(wm[k], q[k], mu);
-      x[NG + i] = fmaf(1.0f - al[i], mu, q[NG + i]);
+      x[NG + i] = fmaf(1.0f - alv<MODE>(i), mu, q[NG + i]);
     }
   }
-  ARP_DEV void from_centered(const float (&x)[ND], float (&q)[ND]) const {
+  template <int MODE>
+  ARP_DEV void from_centered_m(const float (&x)[ND], float (&q)[ND]) const {
 #pragma unroll
-    for (int k = 0; k < kElG; ++k) { q[k] = x[k]; q[kElG + k] = x[kElG + k]; q[2 * kElG + k] = x[2 * kElG + k] / cs[k]; }
+    for (int k = 0; k < kElG; ++k) { q[k] = x[k]; q[kElG + k] = x[kElG + k]; q[2 * kElG + k] = x[2 * kElG + k] / csv<MODE>(k); }
     const int t0 = table_off();
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -266,7 +278,7 @@ struct ElectricLane {
       float mu = 0.0f;
 #pragma unroll
       for (int k = 0; k < kElG; ++k) mu = fmaf(wm[k], x[k], mu);
-      q[NG + i] = lvalid(i) ? fmaf(-(1.0f - al[i]), mu, x[NG + i]) : 0.0f;
+      q[NG + i] = lvalid(i) ? fmaf(-(1.0f - alv<MODE>(i)), mu, x[NG + i]) : 0.0f;
     }
   }
 };
