@@ -431,7 +431,10 @@ extern "C" int64_t arp_ess_workspace_bytes(int64_t n_samples, int64_t n_series) 
   using namespace arp;
   if (n_samples <= 0 || n_series <= 0) return 0;
   if (n_samples + 72 <= kEssRows * 64) return 0;          // short series finish inside the first-stage kernel
-  return (int64_t)(EssWsLayout(n_series).off_rows + (size_t)n_series * (size_t)ess_row_floats(n_samples) * 4);
+  // series rows are gathered 64 at a time, so the row area holds a whole number of 64-row blocks (at least one):
+  // a caller that allocates exactly this many bytes gets every listed series in ONE chunk, also for n_series < 64
+  const size_t rows = ((size_t)n_series + 63) & ~(size_t)63;
+  return (int64_t)(EssWsLayout(n_series).off_rows + rows * (size_t)ess_row_floats(n_samples) * 4);
 }
 
 extern "C" int arp_ess_ws(const float* trace, int64_t n_samples, int64_t n_series, int64_t row_stride, float* ess,

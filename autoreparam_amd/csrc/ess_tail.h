@@ -39,6 +39,7 @@ struct EssDefer {
 
 constexpr int kEssTailBlocks = 16;                       // 16-lag blocks per round
 constexpr int kEssTailLags = 16 * kEssTailBlocks;        // lags completed per round
+constexpr int kEssTailFlush = 1024;                      // 64-sample steps between folds of the float32 accumulators (multiple of 4)
 
 __host__ __device__ inline long long ess_row_floats(long long S) { return (S + 63) & ~63ll; }
 
@@ -107,41 +108,49 @@ void ess_tail_kernel(const float* __restrict__ ws, long long S, EssDefer W, unsi
     float w[16], a = ld(0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) w[i] = ld(lag0 + 16 * i);
-    for (int s = 0; s < ns; s += 4) {
+    // The accumulators are float32 chains; they are folded into s_lag every kEssTailFlush steps (4 kEssTailFlush products
+    // per element), so no chain is longer than that however long the series is (the workspace path admits 4.19 M samples:
+    // one unbroken chain would be 262 144 products, a worst-case relative error of 1.6 % on sum |y y'|).  Series up to
+    // 64 kEssTailFlush samples -- the reference's 50 000 among them -- take exactly one fold, as before.
+    for (int s0 = 0; s0 < ns; s0 += kEssTailFlush) {
+      const int s1 = min(ns, s0 + kEssTailFlush);
+      for (int s = s0; s < s1; s += 4) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int sb = 64 * (s + u);
-        // the four new B operands of the next step and its A operand go in flight under this step's MFMAs
-        float nw[4];
+        for (int u = 0; u < 4; ++u) {
+          const int sb = 64 * (s + u);
+          // the four new B operands of the next step and its A operand go in flight under this step's MFMAs
+          float nw[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) nw[k] = ld(sb + lag0 + 16 * (16 + k));
-        const float na = ld(sb + 64);
+          for (int k = 0; k < 4; ++k) nw[k] = ld(sb + lag0 + 16 * (16 + k));
+          const float na = ld(sb + 64);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[(i + 4 * u) & 15], acc[i], 0, 0, 0);
+          for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[(i + 4 * u) & 15], acc[i], 0, 0, 0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[(4 * u + k) & 15] = nw[k];
-        a = na;
-      }
-    }
-    // diagonals of the 16 blocks -> lag sums.  Block i, diagonal d = n - m: lag 16 (jb + i) + d -> s_lag[16 i + d + 15].
-    // D layout of v_mfma_f32_16x16x4_f32: lane l, register r holds D[4 (l / 16) + r][l % 16].
-#pragma unroll
-    for (int i = 0; i < kEssTailBlocks; ++i) {
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s_tile[(4 * (lane >> 4) + r) * 17 + (lane & 15)] = acc[i][r];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (lane < 31) {
-        const int d = lane - 15;
-        float sum = 0.0f;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-          const int n = m + d;
-          sum += (n >= 0 && n < 16) ? s_tile[m * 17 + (n & 15)] : 0.0f;
+          for (int k = 0; k < 4; ++k) w[(4 * u + k) & 15] = nw[k];
+          a = na;
         }
-        s_lag[16 * i + lane] += sum;
+      }
+      // diagonals of the 16 blocks -> lag sums.  Block i, diagonal d = n - m: lag 16 (jb + i) + d -> s_lag[16 i + d + 15].
+      // D layout of v_mfma_f32_16x16x4_f32: lane l, register r holds D[4 (l / 16) + r][l % 16].
+#pragma unroll
+      for (int i = 0; i < kEssTailBlocks; ++i) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_tile[(4 * (lane >> 4) + r) * 17 + (lane & 15)] = acc[i][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 31) {
+          const int d = lane - 15;
+          float sum = 0.0f;
+#pragma unroll
+          for (int m = 0; m < 16; ++m) {
+            const int n = m + d;
+            sum += (n >= 0 && n < 16) ? s_tile[m * 17 + (n & 15)] : 0.0f;
+          }
+          s_lag[16 * i + lane] += sum;
+        }
+        acc[i] = ess_f4{0.0f, 0.0f, 0.0f, 0.0f};
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

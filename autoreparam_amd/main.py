@@ -159,7 +159,9 @@ def _ess_report(info, model_config, flags, dev):
     every rank calls it.)"""
     if info is None:
         return {}
-    out = {"ess_estimator": info.estimator}
+    # every per-run key is a list with one entry per run (the reference's contract): whole-trace runs append None here
+    out = {"ess_estimator": info.estimator, "ess_min_batch_means": None, "sem_min_batch_means": None,
+           "batch_means_batch": None}
     n_local = int(info.chains)
     out["ess_chains"] = int(parallel.all_reduce_sum(float(n_local), dev).item())
     if info.batch_means is not None:

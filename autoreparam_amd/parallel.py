@@ -15,7 +15,18 @@ import torch.distributed as dist
 def _collective_device(device):
     """Where a tensor has to live for the initialised backend: the rank's GPU for RCCL ("nccl"), the host for gloo
     (the CPU tests of the rank logic)."""
-    return None if (device is None or dist.get_backend() == "gloo") else device
+    if dist.get_backend() == "gloo":
+        return None
+    if device is None:                       # RCCL moves device memory only: default to the rank's current GPU
+        return torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def live():
+    """True when a process group exists: the exchange then runs through the backend's collectives -- also for a group of
+    ONE rank (a single-GPU launch under torch.distributed.run), which is how the RCCL calls below are exercised on a
+    one-GPU box (tests/test_gpu_scaling.py); without a group every function returns its local values."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def world():
@@ -26,7 +37,7 @@ def world():
 
 def barrier():
     """All ranks of the job (no-op for a single process)."""
-    if world()[1] > 1:
+    if live():
         dist.barrier()
 
 
@@ -50,7 +61,7 @@ def all_gather_chains(local, n_total, device=None):
     ESS chain subset of a streaming run: the chains with global id < --ess_chains) -- the lengths are gathered first."""
     rank, ws = world()
     t = torch.as_tensor(local)
-    if ws == 1:
+    if not live():
         return t
     device = _collective_device(device)
     if device is not None:
@@ -73,7 +84,7 @@ def all_gather_chains(local, n_total, device=None):
 def all_reduce_sum(value, device=None):
     rank, ws = world()
     t = torch.as_tensor(value, dtype=torch.float64)
-    if ws == 1:
+    if not live():
         return t
     device = _collective_device(device)
     if device is not None:
@@ -105,7 +116,7 @@ def summarize(normalized_ess_parts, is_accepted, num_samples, num_chains_total, 
 def gather_parts(parts, num_chains_total, device=None):
     """Every rank's [C_local, *event] arrays -> the [C, *event] arrays of the whole job, in chain order (the per-element
     ESS that rank 0 writes to _ess.npz: <= 4 bytes per chain and element, once per run)."""
-    if world()[1] == 1:
+    if not live():
         return [np.asarray(p) for p in parts]
     return [all_gather_chains(torch.as_tensor(np.asarray(p)), num_chains_total, device).cpu().numpy() for p in parts]
 

@@ -76,8 +76,8 @@ ELECTION_MIX = {
 # (1 cycle = 1 / 2.4 ns) measured at whatever clock the chip holds under a vector-bound load, so
 #     sum(count x cost) / 2.4 GHz / measured time
 # is a utilisation that does not depend on the clock and cannot exceed 1 (the costs are each class's best back-to-back
-# rate).  Pricing the same costs at the held clock instead (round 3's reviewer asked for it) double-counts the clock: the
-# figure is kept under `optimistic_if_costs_were_true_cycles` and is NOT the one to quote.
+# rate).  Pricing the same costs at the held clock instead double-counts the clock (it read 1.02 for one election form --
+# a utilisation above 1); that figure is no longer printed, its derivation stays in profiles/r04_issue_costs.txt.
 ISSUE_COST_2W = {"pk": 4.43, "trans": 8.17, "dpp": 4.41, "mad_u64": 4.42, "half_rate": 4.19, "fma3": 3.02, "mov": 2.48, "other": 2.48}
 # The headline kernel's own instruction mix: VALU instructions per WAVE (16 chains) and interleaved step (2 x 4 leapfrogs)
 # by issue class, from the ISA (tools/asm_ledger.py, profiles/r04_headline_ledger.txt; the hardware's SQ_INSTS_VALU says
@@ -304,6 +304,22 @@ def load_profile(tag_cfg):
     return prof
 
 
+def self_launch(n_gpus, argv):
+    """Run this script on `n_gpus` ranks of this node through torch.distributed.run (one process per GPU, RCCL), the way
+    the driver launches it for N > 1; returns the launcher's return code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -327,11 +343,19 @@ def main():
                                                          "(arp_hmc_io.stats) instead of writing trace rows")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` outside a launcher: start the N ranks ourselves, as a CHILD process and before
+        # anything in this process has touched the GPU (never an exec), relay the child's output (rank 0's one JSON
+        # line goes to the inherited stdout) and leave with its return code
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    # under a launcher (RANK and MASTER_PORT set) the process group is created for ANY world size: a one-rank launch
+    # runs the same end-of-run exchange through RCCL that an N-rank launch does
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
     from autoreparam_amd.util import debug_switch
     if debug_switch("ARP_SHARE_GPU") and torch.cuda.device_count():
         local_rank %= torch.cuda.device_count()               # tests only (ARP_DEBUG=1): several ranks on one GPU (gloo backend)
@@ -339,7 +363,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     cdev = dev                                                # where the tensors of a collective live
     dist = None
-    if world > 1:
+    if world > 1 or under_launcher:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = debug_switch("ARP_DIST_BACKEND") or "nccl"  # "nccl" is RCCL; "gloo": tests that share one GPU
@@ -533,10 +557,6 @@ def main():
             ems = _time_launches(lambda: eeng.hmc_run(ste, epse, Le, Te, **kwe), 3, 1)
             rate = Ce * Te * Le / (ems * 1e-3)
             ib, ib_cyc = election_issue_bound(name, Le)
-            # the clock the chip holds under a vector-bound load (GRBM_GUI_ACTIVE / 8 / kernel time of the newest headline
-            # profile): the nominal 2.4 GHz overstates what back-to-back issue could deliver on this box
-            prof_clk = ((load_profile({}) or {}).get("derived") or {}).get("clock_ghz_estimate")
-            ib_held = election_issue_bound(name, Le, prof_clk)[0] if prof_clk else None
             el[name] = {"kernel_ms": ems, "leapfrog_steps_per_s": rate, "transitions_per_launch": Te,
                         "at_round3_launch_length": {"transitions_per_launch": 128, "kernel_ms": ems_short,
                                                     "leapfrog_steps_per_s": Ce * 128 * Le / (ems_short * 1e-3)},
@@ -548,9 +568,6 @@ def main():
                         "issue_bound": {"leapfrog_steps_per_s": ib, "frac": rate / ib, "clock_ghz": 2.4,
                                         "frac_note": "time based (costs are times measured on this chip, quoted at 2.4 GHz): the "
                                                      "figure to quote",
-                                        "optimistic_if_costs_were_true_cycles": {
-                                            "clock_ghz": prof_clk, "frac": rate / ib_held if ib_held else None,
-                                            "clock_source": "newest profiles/rNN_headline.json: derived.clock_ghz_estimate"},
                                         "issue_cycles_per_wave_transition": ib_cyc, "mix_per_wave": ELECTION_MIX[name],
                                         "cycles_per_instruction": ISSUE_CYCLES,
                                         "note": "per state and gradient: 1 v_exp + 4 v_rcp (+ 8 v_log per state pair in the "
@@ -767,16 +784,13 @@ def main():
             # how close the launch comes to issuing its own instruction mix back to back (<= 1 by construction)
             rate1 = C * T * LL / (kern_ms * 1e-3)
             ib24, cyc = headline_issue_bound(2.4)
-            clk = roof.get("clock_ghz_estimate")
             roof["issue_bound"] = {"frac": rate1 / ib24, "leapfrog_steps_per_s": ib24,
                                    "cycles_per_wave_step_at_2.4GHz": cyc, "mix_per_wave_step": HEADLINE_MIX,
                                    "cost_cycles_at_2.4GHz": HEADLINE_COST,
                                    "source": "profiles/r04_headline_ledger.txt (ISA ledger), tools/pk_vs_fma_2waves.hip (costs)",
                                    "note": "time based: the costs are times measured on this chip at two resident waves per SIMD "
                                            "(quoted as cycles at 2.4 GHz), so frac = priced time / measured time whatever clock "
-                                           "the chip holds; <= 1 by construction",
-                                   "optimistic_if_costs_were_true_cycles": ({"clock_ghz": clk, "frac": rate1 / headline_issue_bound(clk)[0]}
-                                                                            if clk else None)}
+                                           "the chip holds; <= 1 by construction"}
         out = {
             "metric": "leapfrog-steps/sec (all chains) + ESS/sec, radon(%s) %d chains%s" % (
                 args.dataset, args.chains, " per GPU" if args.scaling == "weak" else " in total"),

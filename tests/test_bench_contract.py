@@ -34,3 +34,23 @@ def test_oracle_only_in_the_cpu_baseline_leg():
         # inside cpu_baseline() or the child-process code string it builds
         head = s[:m.start()]
         assert head.rfind("def cpu_baseline(") > head.rfind("\ndef main("), "oracle imported outside the cpu_baseline leg"
+
+
+def test_bench_launches_its_own_ranks_when_asked_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` outside a launcher starts torch.distributed.run as a CHILD process (before anything
+    touched the GPU) and leaves with its return code: on this GPU-less box the two ranks fail with torch's own "no GPU"
+    error, and the parent no longer refuses with `--gpus 2 but WORLD_SIZE=1`."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, cwd=ROOT, timeout=300, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert r.returncode == 0
+        return
+    assert r.returncode != 0
+    assert "but WORLD_SIZE=" not in r.stderr
+    if not torch.cuda.is_available():
+        assert "No HIP GPUs are available" in r.stderr or "Found no NVIDIA driver" in r.stderr or "no GPU" in r.stderr.lower(), r.stderr[-1500:]
+        assert "torch.distributed.elastic" in r.stderr or "ChildFailedError" in r.stderr      # the failure came from the children

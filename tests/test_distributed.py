@@ -207,7 +207,9 @@ def test_cli_rank_logic_two_ranks_equal_one(tmp_path):
     import json
     r = json.load(open(os.path.join(two, "CP_tied.json")))
     assert r["ess_estimator"] == ["autocorrelation", "autocorrelation"] and r["ess_chains"] == [7, 3]
-    assert len(r["ess_min_batch_means"]) == 1 and r["batch_means_batch"] == [4]
+    # one entry per run in every list: None for the whole-trace run, the figure for the streaming one
+    assert r["ess_min_batch_means"][0] is None and r["ess_min_batch_means"][1] > 0 and r["batch_means_batch"] == [None, 4]
+    assert len(r["ess_min"]) == len(r["ess_estimator"]) == len(r["sem_min_batch_means"]) == 2
     assert a["CP_tied_ess.npz"]["theta"].shape == (3, 8)             # the last run's: the 3-chain subset
     assert a["NCP_tied_ess.npz"]["theta"].shape == (5, 8) and np.array_equal(a["NCP_tied_ess.npz"]["theta"], b["NCP_tied_ess.npz"]["theta"])
     for r in range(2):   # every rank returns the statistics over ALL chains

@@ -213,6 +213,45 @@ def test_long_series_ess_on_the_matrix_cores(gpu):
     np.testing.assert_allclose(util.effective_sample_size(t).cpu().numpy(), ess_ref.ess_fft(t.cpu().numpy()), rtol=5e-3)
 
 
+def test_workspace_size_function_is_enough_for_few_series(gpu):
+    """arp_ess_workspace_bytes alone sizes the workspace (include/autoreparam.h): one german-credit chain (25 series
+    of a long trace, fewer than the 64 rows the gather works in) must not be refused as `workspace too small`, and a
+    count that is not a multiple of 64 must go in one chunk (same figures as the chunked and the workspace-free routes)."""
+    import ctypes as C
+    from oracle import ess_ref
+    from autoreparam_amd import _lib
+    L = _lib.lib()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n, S in ((25, 5000), (1, 3000), (70, 2600)):
+        rho = np.linspace(0.99, 0.9, n)
+        x = torch.as_tensor(ess_ref.ar1(S, (1, n), rho, seed=3 + n), dtype=torch.float32)
+        xd = x.to(gpu)
+        need = int(L.arp_ess_workspace_bytes(S, n))
+        assert need > 0
+        ws = torch.empty(need, dtype=torch.uint8, device=gpu)
+        out = torch.empty(1, n, device=gpu)
+        _lib.check(L.arp_ess_ws(C.c_void_p(xd.data_ptr()), S, n, n, C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                need, stream))
+        np.testing.assert_allclose(out.cpu().numpy(), ess_ref.ess_fft(x.numpy()), rtol=2e-3)
+        out0 = torch.empty(1, n, device=gpu)
+        _lib.check(L.arp_ess(C.c_void_p(xd.data_ptr()), S, n, n, C.c_void_p(out0.data_ptr()), stream))
+        np.testing.assert_allclose(out.cpu().numpy(), out0.cpu().numpy(), rtol=1e-4)
+
+
+def test_matrix_core_tail_at_the_reference_trace_length_and_beyond(gpu):
+    """The tail's float32 accumulators are folded every 65 536 samples (ess_tail.h: kEssTailFlush): the reference's
+    50 000-sample trace (one fold) and a 150 000-sample one (three folds) against the float64 FFT oracle, slowly mixing
+    series with a large offset included."""
+    from oracle import ess_ref
+    from autoreparam_amd import util
+    for S in (50000, 150000):
+        rho = np.array([0.999, 0.99, 0.9, 0.3])
+        x64 = ess_ref.ar1(S, (2, 4), rho, seed=S) * [1.0, 5.0, 0.2, 1.0] + [0.0, 40.0, -3.0, 0.0]
+        x = torch.as_tensor(x64, dtype=torch.float32)
+        got = util.effective_sample_size(x.to(gpu)).cpu().numpy()
+        np.testing.assert_allclose(got, ess_ref.ess_fft(x.numpy()), rtol=2e-3)
+
+
 def test_clock_probe_reports_a_plausible_shader_clock(gpu):
     """arp_clock_probe (measurement hook of bench.py): shader cycles over 100 MHz ticks of a vector-bound load -- an MI355X
     holds 1.9 - 2.4 GHz under it; bad arguments fail loudly."""

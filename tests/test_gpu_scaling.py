@@ -137,3 +137,73 @@ def test_two_rank_bench_line(scaling):
     # the whole-job value: all ranks' leapfrog steps over the slowest rank's wall time
     assert abs(j["value"] - 2 * per_gpu * 32 * 8 * 3 / (j["ms_per_step"] * 3e-3)) <= 1e-6 * j["value"]
     assert 0.3 < j["accept_rate"] < 1.0
+
+
+_RCCL_SCRIPT = r"""
+import json, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["ARP_ROOT"])
+from autoreparam_amd import parallel
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+try:
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+except TypeError:
+    dist.init_process_group("nccl", rank=0, world_size=1)
+assert parallel.live() and parallel.world() == (0, 1) and dist.get_backend() == "nccl"
+rs = np.random.RandomState(0)
+# all-gather of a per-chain statistic: fixed-length blocks (float32) and variable-length ones (sizes gathered first, int64)
+x = rs.rand(1000).astype(np.float32)
+g = parallel.all_gather_chains(torch.as_tensor(x), 1000, dev)
+assert g.is_cuda and np.array_equal(g.cpu().numpy(), x)
+g = parallel.all_gather_chains(torch.as_tensor(x[:37]), None, dev)
+assert g.is_cuda and np.array_equal(g.cpu().numpy(), x[:37])
+g2 = parallel.all_gather_chains(torch.as_tensor(x.reshape(250, 4)), 250)        # device defaulted to the current GPU
+assert g2.is_cuda and np.array_equal(g2.cpu().numpy(), x.reshape(250, 4))
+# float64 all-reduce (acceptance counts)
+t = parallel.all_reduce_sum(12345678.25, dev)
+assert t.is_cuda and t.dtype == torch.float64 and float(t.item()) == 12345678.25
+# the summaries main.py forms from them
+ess = [rs.rand(64, 1).astype(np.float32) + 1.0, rs.rand(64, 5).astype(np.float32) + 1.0]
+acc = rs.rand(20, 64) < 0.7
+e, s, a, mins = parallel.summarize(ess, acc, 20, 64, device=dev)
+want = np.minimum(ess[0].min(1), ess[1].min(1))
+assert np.array_equal(mins, want) and abs(e - want.mean()) < 1e-6 and abs(a - 100.0 * acc.sum() / (20 * 64)) < 1e-9
+parts = parallel.gather_parts(ess, 64, dev)
+assert all(np.array_equal(p, q) for p, q in zip(parts, ess))
+parallel.barrier()
+torch.cuda.synchronize()
+print(json.dumps({"dist_backend": dist.get_backend(), "ranks": dist.get_world_size(), "ok": True}))
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_collectives_run_at_world_size_one():
+    """backend="nccl" IS RCCL: a process group of ONE rank on the box's GPU drives every collective of parallel.py --
+    the padded float32 all-gather, the int64 gather of block lengths, the float64 all-reduce, gather_parts, summarize,
+    the barrier -- through real RCCL calls on device tensors (a group of one takes no short-cut: parallel.live())."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               ARP_ROOT=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], env=env, cwd=ROOT, timeout=600, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j == {"dist_backend": "nccl", "ranks": 1, "ok": True}
+
+
+def test_one_rank_bench_under_the_launcher_reports_rccl():
+    """bench.py under torch.distributed.run with ONE rank: the process group is created (RCCL), the end-of-run exchange
+    of the timed run goes through it, and the line says so (`dist_backend: "nccl"`, `rccl_ranks: 1`)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr=127.0.0.1",
+           "--master-port=%d" % _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--chains", "4096", "--transitions", "32", "--headline-only", "--no-cpu-baseline", "--no-ess"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["dist_backend"] == "nccl" and j["rccl_ranks"] == 1 and j["n_gpus"] == 1 and j["ranks"] == 1
+    assert j["stats_allgather_s"] > 0 and 0.3 < j["accept_rate"] < 1.0
