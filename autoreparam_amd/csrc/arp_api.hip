@@ -13,6 +13,24 @@ void set_error(const std::string& msg) { g_err = msg; }
 
 static const double kHalfLog2Pi = 0.9189385332046727;
 
+// geometry of the last arp_vi_run of this thread (arp_vi_geometry: a measurement hook)
+struct ViGeometry { int v[6]; };
+static thread_local ViGeometry g_vi_geometry = {{0, 0, 0, 0, 0, 0}};
+
+// integer experiment switch, honoured under ARP_DEBUG=1 only and announced on stderr
+static bool debug_int(const char* name, int* out) {
+  const char* e = getenv(name);
+  if (!e || !e[0]) return false;
+  const char* d = getenv("ARP_DEBUG");
+  if (!(d && d[0] == '1' && d[1] == 0)) {
+    fprintf(stderr, "libautoreparam_hip: %s=%s IGNORED (experiment switch; set ARP_DEBUG=1 to enable it)\n", name, e);
+    return false;
+  }
+  fprintf(stderr, "libautoreparam_hip: DEBUG SWITCH %s=%s is in effect\n", name, e);
+  *out = atoi(e);
+  return true;
+}
+
 // pick the instantiation: requested lanes-per-chain (or a default from the chain
 // count) and the smallest slice size that covers `groups`.
 // `exact`: the family needs NL == ceil(groups / K), rounded up to a multiple of `unit` (only a lane's last slice may be
@@ -384,6 +402,7 @@ int arp_model_destroy(arp_model* m) {
   if (!m) return 0;
   if (m->dev_tables) (void)hipFree(m->dev_tables);
   for (int w = 0; w < 2; ++w) if (m->dev_ab[w]) (void)hipFree(m->dev_ab[w]);
+  if (m->vi_ws) (void)hipFree(m->vi_ws);
   delete m;
   return 0;
 }
@@ -578,6 +597,7 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   const LaneOps* o = pick(*fam, m->n_groups, Kmax, 1 << 30, m->model != ARP_MODEL_GERMAN_CREDIT, 131072,
                           m->model == ARP_MODEL_TIME_SERIES ? 2 : 1);
   if (!o || !o->vi) { set_error("no VI kernel instantiation covers this group count"); return 1; }
+  if (m->D > o->vi_dmax) { set_error("arp_vi_run: model dimension exceeds this model's VI kernel instantiation"); return 1; }
   ViParams P;
   P.n_steps = cfg->n_steps; P.n_mc = cfg->n_mc; P.learn_a = cfg->learn_a; P.tied_b = cfg->tied_b; P.a_prior = cfg->a_prior; P.D = m->D;
   P.seed = cfg->seed;
@@ -607,8 +627,76 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
       }
     }
   }
-  o->vi(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, cfg->n_lr, (hipStream_t)stream);
-  ARP_HIP_OK(hipGetLastError());
+  // ---- geometry of the launch (kernels.h: vi_kernel): G sample groups x R row parts per learning rate
+  const int B = o->vi_block, K = o->K;
+  const int CPW = B / K;                                 // draws a workgroup takes per pass
+  const int unit = kViBlock / B;                         // G must be a multiple of this when a lane takes several draws
+  int G = (cfg->n_mc + CPW - 1) / CPW;                   // one pass
+  int R = 1;
+  if (o->vi_parts) {
+    // German credit: the observations' 128-row tiles are split too, so that a learning rate's group has about 32
+    // workgroups (five learning rates: 160 CUs) and a gradient is two tiles of matrix-core work per wave
+    const int nt = (m->german.N + kGermanTileRows - 1) / kGermanTileRows;
+    R = std::min(nt, std::max(1, 32 / G));
+  }
+  int dbg = 0;
+  if (debug_int("ARP_VI_G", &dbg) && dbg > 0 && !o->vi_parts) G = std::min(G, dbg);      // experiments (ARP_DEBUG=1 only)
+  if (debug_int("ARP_VI_R", &dbg) && dbg > 0 && o->vi_parts) R = dbg;
+  hipDeviceProp_t prop;
+  ARP_HIP_OK(hipGetDeviceProperties(&prop, m->device));
+  int occ = o->vi_occ ? o->vi_occ() : 0;
+  if (occ <= 0) { set_error("arp_vi_run: the VI kernel does not fit on this device (occupancy query)"); return 1; }
+  // every workgroup of a group has to be resident together (they wait for each other twice per step).  One or two per
+  // CU is an LDS or register-file limit, which the query gets right; at more than that it can be one workgroup per CU
+  // high (MI355X_MICROARCH.md, residency: the scalar-register edge), so one is given away
+  const long long capacity = (long long)(occ > 2 ? occ - 1 : occ) * prop.multiProcessorCount;
+  while ((long long)G * R > capacity && R > 1) R = (R + 1) / 2;
+  if ((long long)G * R > capacity && o->vi_parts) {
+    set_error("arp_vi_run: n_mc draws of this model do not fit on the device in one pass");   // 4 096 draws: 128 workgroups
+    return 1;
+  }
+  if ((long long)G * R > capacity) G = (int)std::max<long long>(unit, capacity / R / unit * unit);
+  if ((long long)G * CPW < cfg->n_mc && G % unit != 0) G = (G + unit - 1) / unit * unit;   // several draws per lane: whole turns
+  if ((long long)G * R > capacity) { set_error("arp_vi_run: one learning rate's workgroups do not fit on this device"); return 1; }
+  const int GR = G * R;
+  const int groups_per_launch = (int)std::max<long long>(1, std::min<long long>(cfg->n_lr, capacity / GR));
+  const int nq = cfg->learn_a ? 4 : 2;
+  const int Tp = (nq * m->D + 1 + 15) & ~15;
+  const size_t need = GR > 1 ? 256 + groups_per_launch * vi_xch_group_granules(GR, Tp) * 8 : 256;
+  if (m->vi_ws_bytes < need) {
+    if (m->vi_ws) { ARP_HIP_OK(hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(m->vi_ws); m->vi_ws = nullptr; m->vi_ws_bytes = 0; }
+    ARP_HIP_OK(hipMalloc(&m->vi_ws, need));
+    m->vi_ws_bytes = need;
+  }
+  P.G = G; P.R = R; P.xch_tp = Tp;
+  P.err = (int*)m->vi_ws;
+  P.xch = GR > 1 ? (unsigned long long*)((char*)m->vi_ws + 256) : nullptr;
+  g_vi_geometry = {B, G, R, groups_per_launch, (int)std::min<long long>((long long)cfg->n_lr * GR, capacity), occ};
+  for (int lr0 = 0; lr0 < cfg->n_lr; lr0 += groups_per_launch) {
+    const int ng = std::min(groups_per_launch, cfg->n_lr - lr0);
+    // every polled word starts at zero (epochs start at 1): the flag and this launch's granules
+    ARP_HIP_OK(hipMemsetAsync(m->vi_ws, 0, need, (hipStream_t)stream));
+    P.lr0 = lr0;
+    o->vi(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, ng, (hipStream_t)stream);
+    ARP_HIP_OK(hipGetLastError());
+    if (GR > 1) {
+      // the hand-offs' waits are bounded: a group that was not resident together reports it here instead of hanging
+      int err = 0;
+      ARP_HIP_OK(hipMemcpyAsync(&err, m->vi_ws, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+      ARP_HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+      if (err) {
+        set_error("arp_vi_run: a hand-off between the workgroups of a learning rate timed out (the group was not resident "
+                  "together: is another kernel holding the device?)");
+        return 1;
+      }
+    }
+  }
+  return 0;
+}
+
+int arp_vi_geometry(int32_t* out6) {
+  if (!out6) { set_error("arp_vi_geometry: null argument"); return 1; }
+  for (int i = 0; i < 6; ++i) out6[i] = g_vi_geometry.v[i];
   return 0;
 }
 

@@ -92,6 +92,43 @@ ARP_DEV uint32_t rng_next(Rng& r) {
   return res;
 }
 
+// Jump-ahead.  With v = c 2^32 + x one step is v' = A x + c = A v mod m for m = A 2^32 - 1 (A 2^32 = 1 mod m, so
+// multiplying by A divides by 2^32), hence n steps are v -> A^n v mod m: one modular multiplication instead of n steps.
+// mwc_montmul(a, b) = a b 2^-64 mod m by two rounds of P <- (P >> 32) + A (P mod 2^32) on the 128-bit product -- the
+// generator's own step applied to a wider value; mwc_pow(n) = A^n 2^64 mod m (Montgomery form), so that
+// mwc_montmul(v, mwc_pow(n)) = A^n v mod m.  (tests/test_rng.py restates this in Python integers against n single steps;
+// the VI kernel, which skips the words other lanes consume, is held to the oracle's sequential draws.)
+constexpr uint64_t kMwcM = ((uint64_t)kMwcA << 32) - 1u;
+constexpr uint64_t kMwcMontOne = 0u - kMwcM;                                   // 2^64 mod m (m < 2^64 < 2 m)
+constexpr uint64_t kMwcMontA = (uint64_t)(((unsigned __int128)kMwcA * kMwcMontOne) % kMwcM);
+ARP_DEV uint64_t mwc_montmul(uint64_t a, uint64_t b) {
+  const uint64_t lo = a * b, hi = __umul64hi(a, b);
+  uint64_t t = (uint64_t)(uint32_t)lo * kMwcA;
+  uint64_t l1 = (hi << 32) | (lo >> 32), h1 = hi >> 32;        // P >> 32 = h1 : l1
+  l1 += t; h1 += l1 < t ? 1u : 0u;                             // h1 <= 2^32
+  t = (uint64_t)(uint32_t)l1 * kMwcA;
+  uint64_t c2 = h1 >> 32, l2 = (h1 << 32) + (l1 >> 32);        // (h1 : l1) >> 32 = c2 : l2
+  l2 += t; c2 += l2 < t ? 1u : 0u;                             // the value is below 2 m + 2^33 < 2^65: c2 <= 1
+  if (c2) l2 += kMwcMontOne;                                   // 2^64 = kMwcMontOne mod m; no wrap (see the bound)
+  if (l2 >= kMwcM) l2 -= kMwcM;
+  if (l2 >= kMwcM) l2 -= kMwcM;
+  return l2;
+}
+ARP_DEV uint64_t mwc_pow(unsigned n) {
+  uint64_t r = kMwcMontOne, base = kMwcMontA;
+  for (; n; n >>= 1) {
+    if (n & 1u) r = mwc_montmul(r, base);
+    base = mwc_montmul(base, base);
+  }
+  return r;
+}
+// r advanced by the n steps whose multiplier is `jump` = mwc_pow(n)
+ARP_DEV void rng_jump(Rng& r, uint64_t jump) {
+  const uint64_t v = mwc_montmul(((uint64_t)r.c << 32) | r.x, jump);
+  r.x = (uint32_t)v;
+  r.c = (uint32_t)(v >> 32);
+}
+
 ARP_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                            uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll

@@ -45,7 +45,8 @@ struct LaneOps {
   void (*hmc)(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s);
   void (*interleaved)(const void* args, const float* a0, const float* b0, const float* a1, const float* b1,
                       const HmcParams& P, hipStream_t s);
-  void (*vi)(const void* args, const float* a, const float* b, const ViParams& P, int n_lr, hipStream_t s);
+  // mean-field VI: `n_groups` learning rates x (P.G x P.R) workgroups of vi_block threads (kernels.h: vi_kernel)
+  void (*vi)(const void* args, const float* a, const float* b, const ViParams& P, int n_groups, hipStream_t s);
   // compile-time parameterisations (nullptr when the lane model has none): hmc for CP / NCP,
   // interleaved for the (CP, NCP) pair
   void (*hmc_cp)(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s);
@@ -56,7 +57,18 @@ struct LaneOps {
   void (*hmc_b1)(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s);
   // the general per-element (a, b) on the packed chain layer, where a lane model has it (election); nullptr: the generic kernel
   void (*hmc_vip_pk)(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s);
+  // shape of the VI kernel's workgroups: threads, whether the lane model splits a gradient's observations into row
+  // parts (German credit), and how many workgroups of it one CU holds (occupancy query)
+  int vi_block = 0;
+  int vi_dmax = 0;
+  bool vi_parts = false;
+  int (*vi_occ)() = nullptr;
 };
+
+// threads of a VI workgroup: 128 (two waves: with 16 - 32 workgroups per learning rate five learning rates cover
+// 80 - 160 CUs) unless the lane model names its own
+template <class L, class = void> struct lane_vi_block { static constexpr int value = 128; };
+template <class L> struct lane_vi_block<L, std::void_t<decltype(L::VI_BLOCK)>> { static constexpr int value = L::VI_BLOCK; };
 
 template <class Lane>
 struct Launch {
@@ -80,10 +92,23 @@ struct Launch {
     hipLaunchKernelGGL(interleaved_kernel<Lane>, dim3(blocks(P.C)), dim3(kBlock), 0, s,
                        *(const typename Lane::Args*)args, a0, b0, a1, b1, P);
   }
-  static void vi(const void* args, const float* a, const float* b, const ViParams& P, int n_lr, hipStream_t s) {
+  static constexpr int kViB = lane_vi_block<Lane>::value;
+  static void vi(const void* args, const float* a, const float* b, const ViParams& P, int n_groups, hipStream_t s) {
     if constexpr (Lane::HAS_VI)
-      hipLaunchKernelGGL(vi_kernel<Lane>, dim3(n_lr), dim3(kViBlock), 0, s,
+      hipLaunchKernelGGL((vi_kernel<Lane, kViB>), dim3(n_groups * P.G * P.R), dim3(kViB), 0, s,
                          *(const typename Lane::Args*)args, a, b, P);
+  }
+  static int vi_occ() {
+    int n = 0;
+    if constexpr (Lane::HAS_VI)
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, vi_kernel<Lane, kViB>, kViB, 0) != hipSuccess) n = 0;
+    return n;
+  }
+  static void set_vi(LaneOps& o) {
+    if constexpr (Lane::HAS_VI) {
+      o.vi = &vi; o.vi_block = kViB; o.vi_parts = lane_has_part<Lane>::value; o.vi_occ = &vi_occ;
+      o.vi_dmax = lane_vi_dmax<Lane>::value;
+    }
   }
   template <int MODE>
   static void hmc_m(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s) {
@@ -98,14 +123,14 @@ struct Launch {
   // only the VI launcher (a lane sized for the VI kernel's workgroup; nothing else is instantiated)
   static LaneOps vi_only() {
     LaneOps o{Lane::K, Lane::NGRP, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if constexpr (Lane::HAS_VI) o.vi = &vi;
+    set_vi(o);
     return o;
   }
   template <class L, class = void> struct has_b1 : std::false_type {};
   template <class L> struct has_b1<L, std::enable_if_t<L::HAS_MODE_B1>> : std::true_type {};
   static LaneOps ops() {
     LaneOps o{Lane::K, Lane::NGRP, &logp_grad, &transform, &hmc, &interleaved, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if constexpr (Lane::HAS_VI) o.vi = &vi;
+    set_vi(o);
     if constexpr (has_b1<Lane>::value) o.hmc_b1 = &hmc_m<kModeB1>;
     if constexpr (Lane::HAS_MODES) {
       o.hmc_cp = &hmc_m<kModeCP>;
@@ -235,6 +260,9 @@ struct arp_model {
   arp::ElectricArgs electric{};
   arp::TimeSeriesArgs time_series{};
   std::vector<float> host_tables;
+  // hand-off workspace of the VI kernel (granules + the error flag in its first 256 bytes), grown on demand
+  void* vi_ws = nullptr;
+  size_t vi_ws_bytes = 0;
   double const_base = 0.0;                       // parameterisation independent part of the dropped constant
   std::vector<std::pair<int, double>> top_scale; // (flattened index, log prior scale) of top-level latents
 };

@@ -3,12 +3,15 @@
 #include "host_common.h"
 
 namespace arp {
-// chain kernels from the lanes sized for 4 waves per workgroup, the VI kernel from the 4-lane
-// (matrix-core) instantiation sized for its 8 waves
-static LaneOps with_vi(LaneOps o, const LaneOps& vi) { o.vi = vi.vi; return o; }
+// chain kernels from the lanes sized for 4 waves per workgroup, the VI kernel from the 4-lane (matrix-core)
+// instantiation in its row-part form, sized for the VI workgroup
+static LaneOps with_vi(LaneOps o, const LaneOps& vi) {
+  o.vi = vi.vi; o.vi_block = vi.vi_block; o.vi_parts = vi.vi_parts; o.vi_occ = vi.vi_occ; o.vi_dmax = vi.vi_dmax;
+  return o;
+}
 const std::vector<LaneOps>& german_ops() {
   static const std::vector<LaneOps> t = {
-      with_vi(Launch<GermanLane<4, 16>>::ops(), Launch<GermanLane<4, 16, kViBlock / 64>>::vi_only()),
+      with_vi(Launch<GermanLane<4, 16>>::ops(), Launch<GermanLane<4, 16, kGermanViBlock / 64, true>>::vi_only()),
       Launch<GermanLane<8, 8>>::ops(), Launch<GermanLane<16, 4>>::ops(),
   };
   return t;

@@ -796,13 +796,36 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
 // Mean-field VI (inference.find_best_learning_rate, inference.py:26-154, on
 // util.get_mean_field_elbo, util.py:232-268): q(z) = prod N(loc, softplus(rho)),
 // ELBO estimated with n_mc reparameterised draws, Adam on -ELBO with the
-// reference's three-stage learning-rate decay, NaN gradients zeroed.  One
-// workgroup runs one learning rate for all optimisation steps, so the whole
-// sweep is a single launch instead of n_lr x n_steps session round trips.
-// With learn_a the VIP parameter a = sigmoid(w) is optimised too (cVIP,
+// reference's three-stage learning-rate decay, NaN gradients zeroed.  All
+// learning rates and all optimisation steps run in ONE launch (instead of
+// n_lr x n_steps session round trips), and every learning rate is spread over
+// the chip:
+//
+//   * a learning rate's n_mc draws are split over G sample groups and, for a model whose gradient is a sum over
+//     observations that a lane model can restrict (German credit: Lane::HAS_PART), over R row parts: G x R
+//     workgroups of B threads form the learning rate's GROUP; consecutive blockIdx, so a group is dispatched together;
+//   * every workgroup reduces its draws' gradient terms in a fixed order (lanes of a wave by butterfly, waves in wave
+//     order) and PUBLISHES the partial sums; workgroup w of the group owns the items t = w, w + GR, ... and adds the
+//     GR partials of each IN WORKGROUP ORDER, publishes the totals, and every workgroup reads all totals back and
+//     applies the same Adam update redundantly -- so a fit is bitwise reproducible from run to run (float atomics
+//     would add in arrival order) and nothing but two hand-offs per step crosses workgroups;
+//   * a hand-off is the data-is-the-flag form of the inter-workgroup recipe (cdna_hip_programming.md, Guideline 16,
+//     R2): every value travels as ONE aligned 8-byte {epoch = step + 1, float} granule written by an agent-scope
+//     relaxed atomic store (global_store_dwordx2 sc1: write-through, the per-XCD L2s are not coherent) and read by
+//     agent-scope relaxed atomic loads (sc1) that are repeated until the tag is the step's; no fence, no flag, no
+//     grid barrier.  Two buffers alternate by step parity: a workgroup can only be one hand-off ahead of the slowest
+//     member of its group.  Waits are bounded (kViSpinTicks of the 100 MHz clock): a group whose members are not all
+//     resident gives up, flags ViParams::err, and the host reports it instead of a hang.  The host sizes the grid so
+//     that every group fits on the device at once (arp_api.hip: arp_vi_run).
+//
+// The draws are part of the sampler's specification and do not depend on G, R or B: draw s of a step uses stream
+// s mod (kViBlock / K) (one MWC stream per (learning rate, stream, slot)) at its (s / (kViBlock / K))-th turn, the
+// layout of the one-workgroup kernel of rounds 1 - 4 (oracle_impl.h: orc_vi_run, block = 512); a lane skips the words
+// other lanes consume.  With learn_a the VIP parameter a = sigmoid(w) is optimised too (cVIP,
 // program_transformations.py:507-510).
 // ---------------------------------------------------------------------------
 constexpr int kViDmax = kMaxD;
+constexpr unsigned long long kViSpinTicks = 200000000ull;   // 2 s of s_memrealtime per wait
 
 struct ViParams {
   int n_steps, n_mc, learn_a, tied_b, a_prior, D;
@@ -813,13 +836,32 @@ struct ViParams {
   float* prior;                // [n_lr][n_steps] log prior density of the learnable parameters per step, or nullptr
   const int* a_group;          // [D] leader element of every element's shared `a` (its own index when not shared), or nullptr
   const int* b_group;          // the same for the separately learned `b`
+  int G, R;                    // sample groups and row parts per learning rate: G x R workgroups form its group
+  int lr0;                     // learning rate of this launch's first group
+  unsigned long long* xch;     // hand-off granules, zeroed before the launch: per group [2][G R][Tp] partials + [2][Tp] totals
+  int xch_tp;                  // Tp: items per workgroup, padded (items: nq x D sums + the ELBO sum)
+  int* err;                    // device flag, set when a hand-off wait ran out
 };
 
+// workspace of one launch, in 8-byte granules (shared with the host)
+__host__ __device__ inline size_t vi_xch_group_granules(int GR, int Tp) { return (size_t)2 * GR * Tp + (size_t)2 * Tp; }
+
+// Sum over the 64 / K chains of a wave -- the lanes with the same slot -- on the vector pipe alone: inside a row of 16
+// lanes by DPP (quad permutations below 4 lanes per chain, row rotations by 4 and by 8), across the four rows by gfx950's
+// v_permlane16_swap / v_permlane32_swap (the two halves of a swapped pair are each other's partner rows).  No LDS round
+// trip: a ds_bpermute butterfly waited out the LDS latency four times per value (a third of a German-credit VI step).
+// Every lane of the wave's FIRST chain ends with the total (lanes of other chains may round in another order).
 template <int K>
-ARP_DEV float chain_sum(float v) {  // sum over the 64/K chains of a wave, result in every lane
-#pragma unroll
-  for (int off = K; off < 64; off <<= 1) v += __shfl_xor(v, off);
-  return v;
+ARP_DEV float chain_sum(float v) {
+  static_assert(K == 1 || K == 2 || K == 4 || K == 8 || K == 16, "lanes per chain");
+  if (K <= 1) v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+  if (K <= 2) v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  if (K <= 4) v += dpp_mov<0x124>(v);    // row_ror:4
+  if (K <= 8) v += dpp_mov<0x128>(v);    // row_ror:8
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // d/dx log of the reference's --discrete_prior density on a learnable parameter x in (0,1) (main.py:244-253):
@@ -837,116 +879,235 @@ ARP_DEV float discrete_prior_logp(float x) {
   return fast_log(l0 + 148.4131591025766f + l1) - 5.013385943110028f;   // log(2 + e^5)
 }
 
-template <class Lane>
-__global__ __launch_bounds__(kViBlock) void vi_kernel(
+// Hand-off granules: {tag = epoch, value} in one aligned 8-byte word, agent-scope relaxed atomics on GLOBAL pointers
+// (global_store_dwordx2 / global_load_dwordx2 with sc1).
+typedef __attribute__((address_space(1))) unsigned long long vi_gu64;
+ARP_DEV vi_gu64* vi_global(unsigned long long* p) { return (vi_gu64*)p; }
+ARP_DEV void vi_put(vi_gu64* g, unsigned epoch, float v) {
+  __hip_atomic_store(g, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+ARP_DEV unsigned long long vi_get(vi_gu64* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// n <= CH granules at g[0], g[stride], ...: all loads of a sweep in flight together, sweeps repeated until every tag is
+// the epoch's; the values, in order, are handed to `take`.  false: the wait ran out (a member of the group is not running).
+template <int CH, class F>
+ARP_DEV bool vi_gather(vi_gu64* g, size_t stride, int n, unsigned epoch, F take) {
+  unsigned long long x[CH];
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) x[j] = j < n ? vi_get(g + (size_t)j * stride) : ((unsigned long long)epoch << 32);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) ok = ok && (unsigned)(x[j] >> 32) == epoch;
+    if (ok) break;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > kViSpinTicks) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+#pragma unroll
+  for (int j = 0; j < CH; ++j)
+    if (j < n) take(__uint_as_float((unsigned)x[j]));
+  return true;
+}
+
+// largest state dimension the VI kernel serves for a lane model (the host checks it): kViDmax unless the model says less
+template <class L, class = void> struct lane_vi_dmax { static constexpr int value = kViDmax; };
+template <class L> struct lane_vi_dmax<L, std::void_t<decltype(L::VI_DMAX)>> { static constexpr int value = L::VI_DMAX; };
+template <class L, class = void> struct lane_has_part { static constexpr bool value = false; };
+template <class L> struct lane_has_part<L, std::void_t<decltype(L::HAS_PART)>> { static constexpr bool value = L::HAS_PART; };
+
+#ifdef ARP_VI_TIMING
+// timing experiments only (tools/build_variants.sh vit=-DARP_VI_TIMING): shader cycles per phase of a step, summed by
+// thread 0 of the launch's first workgroup and printed when the kernel ends
+#define VI_T0() unsigned long long vt_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, vt0_ = __builtin_readcyclecounter()
+#define VI_T(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); vt_[k] += n_ - vt0_; vt0_ = n_; } while (0)
+#define VI_TPRINT(steps) do { if (blockIdx.x == 0 && threadIdx.x == 0) { printf("vi_kernel cycles/step:"); \
+    for (int k_ = 0; k_ < 12; ++k_) printf(" [%d] %.0f", k_, (double)vt_[k_] / (steps)); printf("\n"); } } while (0)
+#else
+#define VI_T0() do {} while (0)
+#define VI_T(k) do {} while (0)
+#define VI_TPRINT(steps) do {} while (0)
+#endif
+
+template <class Lane, int B>
+__global__ __launch_bounds__(B) void vi_kernel(
     typename Lane::Args A, const float* __restrict__ av, const float* __restrict__ bv, ViParams P) {
   constexpr int K = Lane::K, ND = Lane::ND, NG = Lane::NG;
-  __shared__ float s_loc[kViDmax], s_sig[kViDmax], s_lsig[kViDmax], s_a[kViDmax], s_b[kViDmax];
-  __shared__ float s_acc[4][kViDmax];   // sum g, sum g*eps, sum dlogp/da, sum dlogp/db
-  // every wave's partial sums, added up in wave order: the fit is bitwise reproducible from run to run (float atomics
-  // across the waves would add in arrival order)
-  __shared__ float s_part[kViBlock / 64][4][kViDmax];
-  __shared__ float s_elbo_w[kViBlock / 64], s_pri[kViDmax];
+  constexpr int W = B / 64;                    // waves per workgroup
+  constexpr int PPT = (lane_vi_dmax<Lane>::value + B - 1) / B;   // parameters owned by a thread: d = tid + u B
+  constexpr int CPW = B / K;                   // draws a workgroup takes per pass
+  constexpr int cpp = kViBlock / K;            // draw layout: streams per slot (see above)
+  constexpr int NDW = (ND + 1) / 2 * 2;        // 32-bit words a lane consumes per draw
+  static_assert(B % 64 == 0 && B % K == 0 && kViBlock % B == 0, "workgroup shape");
+  constexpr int DM = lane_vi_dmax<Lane>::value;
+  __shared__ float s_loc[DM], s_sig[DM], s_lsig[DM], s_a[DM], s_b[DM];
+  // every wave's partial sums (sum g, sum g*eps, sum dlogp/da, sum dlogp/db), added up in wave order
+  __shared__ float s_part[W][4][DM];
+  __shared__ float s_elbo_w[W], s_pri[DM];
   __shared__ float s_elbo, s_prior;
-  __shared__ float s_red[2][kViDmax];   // shared (a, b) groups: per-element gradient contributions, then the leaders' values
-  const int D = P.D, tid = threadIdx.x, lr_i = blockIdx.x;
+  __shared__ float s_red[2][DM];   // shared (a, b) groups: per-element gradient contributions, then the leaders' values
+  __shared__ int s_fail;
+  const int D = P.D, tid = threadIdx.x;
+  const int GR = P.G * P.R;
+  const int grp = blockIdx.x / GR, wg = blockIdx.x - grp * GR, sg = wg / P.R, rp = wg - sg * P.R;
+  const int lr_i = P.lr0 + grp;
   const int slot = tid % K, chain0 = tid / K;
-  constexpr int chains_per_pass = kViBlock / K;
-  const int passes = (P.n_mc + chains_per_pass - 1) / chains_per_pass;
+  const int spp = P.G * CPW;                           // draws the group takes per pass
+  const int passes = (P.n_mc + spp - 1) / spp;
+  const int SP = (P.n_mc + cpp - 1) / cpp;             // turns of a stream per step
+  const int s0 = sg * CPW + chain0;                    // this lane's first draw
+  const int p0 = s0 / cpp, pstride = spp / cpp;        // its turn, and turns between its consecutive draws (passes > 1:
+  //                                                      the host makes spp a multiple of cpp, so the stream stays)
+  const float pw = rp == 0 ? 1.0f : 0.0f;              // the entropy terms count once per draw
 
-  // parameter owned by this thread (tid < D): Adam moments live in registers
-  float loc = 0.f, rho = 0.f, w = 0.f, wb = 0.f, m1[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (tid < D) {
-    loc = P.loc[(size_t)lr_i * D + tid];
-    rho = P.rho[(size_t)lr_i * D + tid];
-    if (P.learn_a) w = P.w[(size_t)lr_i * D + tid];
-    if (P.wb) wb = P.wb[(size_t)lr_i * D + tid];
-    s_a[tid] = av[tid]; s_b[tid] = bv[tid];
-  }
-  const float base_lr = P.lr[lr_i];
-  ARP_LANE_SMEM(Lane);
-  // untied parameterisation variables that the reference creates with the shape of a SCALAR loc / scale while the
-  // random variable is a vector (program_transformations.py:486-533): one value shared by the part, owned by its
-  // first element (the leader); members are contiguous
-  int lead[2] = {tid, tid}, gsize[2] = {1, 1};
-  if (tid < D) {
-    const int* grp[2] = {P.a_group, P.wb ? P.b_group : nullptr};
-    for (int k = 0; k < 2; ++k) {
-      if (!grp[k]) continue;
-      lead[k] = grp[k][tid];
-      int n = 0;
-      for (int d = tid; d < D && grp[k][d] == tid; ++d) ++n;
-      gsize[k] = lead[k] == tid ? n : 0;
+  // parameters owned by this thread: Adam moments live in registers
+  float loc[PPT], rho[PPT], w[PPT], wb[PPT], m1[PPT][4], m2[PPT][4];
+  int lead[PPT][2], gsize[PPT][2];
+#pragma unroll
+  for (int u = 0; u < PPT; ++u) {
+    const int d = tid + u * B;
+    loc[u] = rho[u] = w[u] = wb[u] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { m1[u][k] = 0.f; m2[u][k] = 0.f; }
+    lead[u][0] = lead[u][1] = d; gsize[u][0] = gsize[u][1] = 1;
+    if (d < D) {
+      loc[u] = P.loc[(size_t)lr_i * D + d];
+      rho[u] = P.rho[(size_t)lr_i * D + d];
+      if (P.learn_a) w[u] = P.w[(size_t)lr_i * D + d];
+      if (P.wb) wb[u] = P.wb[(size_t)lr_i * D + d];
+      s_a[d] = av[d]; s_b[d] = bv[d];
+      // untied parameterisation variables that the reference creates with the shape of a SCALAR loc / scale while the
+      // random variable is a vector (program_transformations.py:486-533): one value shared by the part, owned by its
+      // first element (the leader); members are contiguous
+      const int* gp[2] = {P.a_group, P.wb ? P.b_group : nullptr};
+      for (int k = 0; k < 2; ++k) {
+        if (!gp[k]) continue;
+        lead[u][k] = gp[k][d];
+        int n = 0;
+        for (int e = d; e < D && gp[k][e] == d; ++e) ++n;
+        gsize[u][k] = lead[u][k] == d ? n : 0;
+      }
     }
   }
+  if (tid == 0) s_fail = 0;
+  const float base_lr = P.lr[lr_i];
+  ARP_LANE_SMEM(Lane);
   Lane M;
   __syncthreads();
   lane_tables(M, A, s_lane_tab);
   M.init(A, s_a, s_b, slot);
-  Rng rng[1];
-  // one stream per (learning rate, first-pass sample, slot); later passes continue it
-  rng[0] = rng_seed(P.seed ^ 0x5649564956495649ull, ((unsigned long long)lr_i << 32) | (unsigned)chain0,
-                    (uint32_t)slot, (uint32_t)K);
+  if constexpr (lane_has_part<Lane>::value) { M.set_part(rp, P.R); M.make_resident(); }
+  // one stream per (learning rate, stream of the layout, slot)
+  Rng rng = rng_seed(P.seed ^ 0x5649564956495649ull, ((unsigned long long)lr_i << 32) | (unsigned)(s0 % cpp),
+                     (uint32_t)slot, (uint32_t)K);
+  // one draw per lane and step (the usual shape): the lane stands at its own turn from the start and each step ends
+  // with ONE jump over the SP - 1 turns of the other lanes (arp_device.h: rng_jump) instead of stepping through them
+  const bool single = passes == 1;
+  const uint64_t jump_step = mwc_pow((unsigned)((SP - 1) * NDW));
+  if (single && p0 < SP) rng_jump(rng, mwc_pow((unsigned)(p0 * NDW)));
   float b1t = 1.0f, b2t = 1.0f;
+  const int nq = P.learn_a ? 4 : 2;
+  const int T = nq * D + 1, Tp = P.xch_tp;
+  vi_gu64* const part_base = GR > 1 ? vi_global(P.xch) + (size_t)grp * vi_xch_group_granules(GR, Tp) : nullptr;
+  bool failed = false;
 
-  for (int step = 0; step < P.n_steps; ++step) {
-    if (tid < D) {
-      float sp = rho > 20.0f ? rho : fast_log(1.0f + fast_exp(rho));   // softplus
-      s_loc[tid] = loc; s_sig[tid] = sp; s_lsig[tid] = fast_log(sp);
-      if (P.learn_a) {
-        float a = sigmoidf_(w);
-        s_a[tid] = a;
-        if (P.tied_b) s_b[tid] = a;
-        if (P.wb) s_b[tid] = sigmoidf_(wb);
+  VI_T0();
+  for (int step = 0; step < P.n_steps && !failed; ++step) {
+    VI_T(11);
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const int d = tid + u * B;
+      if (d < D) {
+        float sp = rho[u] > 20.0f ? rho[u] : fast_log(1.0f + fast_exp(rho[u]));   // softplus
+        s_loc[d] = loc[u]; s_sig[d] = sp; s_lsig[d] = fast_log(sp);
+        if (P.learn_a) {
+          float a = sigmoidf_(w[u]);
+          s_a[d] = a;
+          if (P.tied_b) s_b[d] = a;
+          if (P.wb) s_b[d] = sigmoidf_(wb[u]);
+        }
       }
     }
     __syncthreads();
-    if (P.prior && tid < D) {
+    if (P.prior) {
       // log prior of the learnable parameters at the values this step's ELBO is evaluated with (inference.py:50-54);
       // a shared parameter is one variable and counts once
-      float lpr = 0.f;
-      if (P.learn_a) {
-        lpr = lead[0] == tid ? discrete_prior_logp(s_a[tid]) : 0.f;
-        if (P.wb && lead[1] == tid) lpr += discrete_prior_logp(s_b[tid]);
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) {
+        const int d = tid + u * B;
+        if (d < D) {
+          float lpr = 0.f;
+          if (P.learn_a) {
+            lpr = lead[u][0] == d ? discrete_prior_logp(s_a[d]) : 0.f;
+            if (P.wb && lead[u][1] == d) lpr += discrete_prior_logp(s_b[d]);
+          }
+          s_pri[d] = lpr;
+        }
       }
-      s_pri[tid] = lpr;
     }
     if (P.learn_a) M.set_param(s_a, s_b);
+    VI_T(0);
 
-    float lc[ND], sg[ND], ls[ND];
-    load_row(M, s_loc, lc); load_row(M, s_sig, sg); load_row(M, s_lsig, ls);
     float acc[4][ND];
-#pragma unroll
-    for (int i = 0; i < ND; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; acc[2][i] = 0.f; acc[3][i] = 0.f; }
     float elbo = 0.f;
-    for (int pass = 0; pass < passes; ++pass) {
-      const bool live = chain0 + pass * chains_per_pass < P.n_mc;
+    int pos = 0;                                  // turns of the stream consumed so far in this step (several passes only)
+    // One pass = one draw per lane.  FIRST (the only pass unless the group is smaller than the draws): the sums START
+    // here, so nothing but the draw is live across the gradient; later passes add to them.
+    auto one_pass = [&](int pass, auto first_tag) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      const int turn = p0 + pass * pstride;
+      const bool live = s0 + pass * spp < P.n_mc;
       float eps[ND], z[ND], g[ND];
 #pragma unroll
-      for (int i = 0; i < ND; i += 2) {
-        float z0, z1;
-        uint32_t w0 = rng_next(rng[0]), w1 = rng_next(rng[0]);
-        normal_pair(w0, w1, z0, z1);
-        eps[i] = z0;
-        if (i + 1 < ND) eps[i + 1] = z1;
-      }
-      float ent = 0.f, entg = 0.f;
+      for (int i = 0; i < ND; ++i) eps[i] = 0.f;
+      if (turn < SP) {
+        if (!single)
+          for (int n = (turn - pos) * NDW; n > 0; --n) rng_next(rng);    // words of the turns other lanes take
 #pragma unroll
-      for (int i = 0; i < ND; ++i) {
-        if (i < NG) {
-          eps[i] = group_bcast0<K>(eps[i], slot);
-          entg += fmaf(0.5f * eps[i], eps[i], ls[i]);
-        } else {
-          bool ok = M.lvalid(i - NG);
-          eps[i] = ok ? eps[i] : 0.f;
-          ent += ok ? fmaf(0.5f * eps[i], eps[i], ls[i]) : 0.f;
+        for (int i = 0; i < ND; i += 2) {
+          float z0, z1;
+          uint32_t w0 = rng_next(rng), w1 = rng_next(rng);
+          normal_pair(w0, w1, z0, z1);
+          eps[i] = z0;
+          if (i + 1 < ND) eps[i + 1] = z1;
         }
-        z[i] = fmaf(sg[i], eps[i], lc[i]);
+        pos = turn + 1;
       }
+      VI_T(1);
+      float ent = 0.f, entg = 0.f;
+      {
+        float lc[ND], sg_[ND], ls[ND];
+        load_row(M, s_loc, lc); load_row(M, s_sig, sg_); load_row(M, s_lsig, ls);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          if (i < NG) {
+            eps[i] = group_bcast0<K>(eps[i], slot);
+            entg += fmaf(0.5f * eps[i], eps[i], ls[i]);
+          } else {
+            bool ok = M.lvalid(i - NG);
+            eps[i] = ok ? eps[i] : 0.f;
+            ent += ok ? fmaf(0.5f * eps[i], eps[i], ls[i]) : 0.f;
+          }
+          z[i] = fmaf(sg_[i], eps[i], lc[i]);
+        }
+      }
+      VI_T(2);
       float lp = M.template grad<true>(z, g);
+      VI_T(3);
       // one ELBO sample: log p(z) - log q(z), the 0.5 log 2pi per latent added by the host-side constant
-      float e = lp + group_sum<K>(ent) + entg;
-      if (live) {
+      // (a row part's lp is its share of log p; the entropy terms count in row part 0)
+      float e = fmaf(pw, group_sum<K>(ent) + entg, lp);
+      if (FIRST) {
+        elbo = live ? e : 0.f;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) { acc[0][i] = live ? g[i] : 0.f; acc[1][i] = live ? g[i] * eps[i] : 0.f; }
+        if (P.learn_a) {
+          float da[ND], db[ND];
+          M.dparam(z, g, da, db);
+#pragma unroll
+          for (int i = 0; i < ND; ++i) { acc[2][i] = live ? da[i] : 0.f; acc[3][i] = live ? db[i] : 0.f; }
+        }
+      } else if (live) {
         elbo += e;
 #pragma unroll
         for (int i = 0; i < ND; ++i) { acc[0][i] += g[i]; acc[1][i] = fmaf(g[i], eps[i], acc[1][i]); }
@@ -957,9 +1118,18 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
           for (int i = 0; i < ND; ++i) { acc[2][i] += da[i]; acc[3][i] += db[i]; }
         }
       }
-    }
+      VI_T(4);
+    };
+    one_pass(0, std::true_type{});
+    // (a lane model with row parts is launched with one draw per lane only -- arp_api.hip: arp_vi_run -- and does not
+    // carry the later passes' code: its sums would have to live across the matrix-core gradient)
+    if constexpr (!lane_has_part<Lane>::value)
+      for (int pass = 1; pass < passes; ++pass) one_pass(pass, std::false_type{});
+    // to the start of this lane's turn of the next step: one jump where a lane takes one draw per step
+    if (single) { if (SP > 1) rng_jump(rng, jump_step); }
+    else for (int n = (SP - pos) * NDW; n > 0; --n) rng_next(rng);
+    VI_T(1);
     // reduce over the chains of the wave, then over waves through LDS
-    const int nq = P.learn_a ? 4 : 2;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (k >= nq) break;
@@ -974,18 +1144,69 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
     }
     elbo = chain_sum<K>(elbo);
     if ((tid & 63) == 0) s_elbo_w[tid >> 6] = elbo;
+    VI_T(5);
     __syncthreads();
-    if (tid < D) {
-      for (int k = 0; k < nq; ++k) {
-        float t = s_part[0][k][tid];
-        for (int wv = 1; wv < kViBlock / 64; ++wv) t += s_part[wv][k][tid];
-        s_acc[k][tid] = t;            // read back by this thread only
+    VI_T(6);
+    float tot[PPT][4];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const int d = tid + u * B;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t = 0.f;
+        if (d < D && k < nq) {
+          t = s_part[0][k][d];
+#pragma unroll
+          for (int wv = 1; wv < W; ++wv) t += s_part[wv][k][d];
+        }
+        tot[u][k] = t;
       }
     }
+    float elbo_tot = 0.f;
     if (tid == 0) {
-      float t = s_elbo_w[0];
-      for (int wv = 1; wv < kViBlock / 64; ++wv) t += s_elbo_w[wv];
-      s_elbo = t;
+      elbo_tot = s_elbo_w[0];
+#pragma unroll
+      for (int wv = 1; wv < W; ++wv) elbo_tot += s_elbo_w[wv];
+    }
+    if (GR > 1) {
+      const unsigned epoch = (unsigned)step + 1u;
+      vi_gu64* const p1 = part_base + (size_t)(step & 1) * GR * Tp;             // [GR][Tp]
+      // ---- hand-off 1: this workgroup's partial sums -> the owners of the items
+      vi_gu64* const p2 = part_base + (size_t)2 * GR * Tp + (size_t)(step & 1) * Tp;   // [Tp]
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) {
+        const int d = tid + u * B;
+        if (d < D)
+          for (int k = 0; k < nq; ++k) vi_put(p1 + (size_t)wg * Tp + k * D + d, epoch, tot[u][k]);
+      }
+      if (tid == 0) vi_put(p1 + (size_t)wg * Tp + nq * D, epoch, elbo_tot);
+      VI_T(7);
+      // ---- the items this workgroup owns: the GR partials of each, added in workgroup order
+      for (int t = wg + GR * tid; t < T; t += GR * B) {
+        float sum = 0.f;
+        bool ok = true;
+        for (int src = 0; src < GR && ok; src += 32)
+          ok = vi_gather<32>(p1 + (size_t)src * Tp + t, (size_t)Tp, min(32, GR - src), epoch, [&](float v) { sum += v; });
+        if (!ok) { failed = true; sum = __builtin_nanf(""); }
+        vi_put(p2 + t, epoch, sum);
+      }
+      VI_T(8);
+      // ---- hand-off 2: every workgroup reads every total
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) {
+        const int d = tid + u * B;
+        if (d < D) {
+          int k = 0;
+          if (!vi_gather<4>(p2 + d, (size_t)D, nq, epoch, [&](float v) { tot[u][k++] = v; })) failed = true;
+        }
+      }
+      if (tid == B - 1 && !vi_gather<1>(p2 + nq * D, 1, 1, epoch, [&](float v) { s_elbo = v; })) failed = true;
+      if (failed) { s_fail = 1; if (P.err) *P.err = 1; }
+      VI_T(9);
+    } else if (tid == 0) {
+      s_elbo = elbo_tot;
+    }
+    if (tid == 0) {
       float pr = 0.f;
       if (P.prior) for (int d = 0; d < D; ++d) pr += s_pri[d];
       s_prior = pr;
@@ -1001,56 +1222,78 @@ __global__ __launch_bounds__(kViBlock) void vi_kernel(
     // likelihood terms of its members (contiguous, behind the leader) and takes the prior once
     const bool grouped = P.a_group || (P.wb && P.b_group);
     const float inv = 1.0f / (float)P.n_mc;
-    float ga = 0.f, gb = 0.f;
-    if (tid < D) {
-      ga = P.learn_a ? (s_acc[2][tid] + (P.tied_b ? s_acc[3][tid] : 0.f)) * inv : 0.f;
-      gb = P.wb ? s_acc[3][tid] * inv : 0.f;
-      if (grouped) { s_red[0][tid] = ga; s_red[1][tid] = gb; }
+    float ga[PPT], gb[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const int d = tid + u * B;
+      ga[u] = gb[u] = 0.f;
+      if (d < D) {
+        ga[u] = P.learn_a ? (tot[u][2] + (P.tied_b ? tot[u][3] : 0.f)) * inv : 0.f;
+        gb[u] = P.wb ? tot[u][3] * inv : 0.f;
+        if (grouped) { s_red[0][d] = ga[u]; s_red[1][d] = gb[u]; }
+      }
     }
     if (grouped) __syncthreads();
-    if (tid < D) {
-      if (grouped) {
-        for (int d = 1; d < gsize[0]; ++d) ga += s_red[0][tid + d];
-        for (int d = 1; d < gsize[1]; ++d) gb += s_red[1][tid + d];
-      }
-      const float sgm = s_sig[tid];
-      const float a = s_a[tid], bb = s_b[tid];
-      const float pa = P.a_prior ? discrete_prior_dlogp(a) : 0.f;
-      const float pb = P.a_prior ? discrete_prior_dlogp(bb) : 0.f;
-      float gr[4];
-      gr[0] = -s_acc[0][tid] * inv;
-      gr[1] = -(s_acc[1][tid] * inv + 1.0f / sgm) * sigmoidf_(rho);
-      gr[2] = P.learn_a ? -(ga + pa) * a * (1.0f - a) : 0.f;
-      gr[3] = P.wb ? -(gb + pb) * bb * (1.0f - bb) : 0.f;
-      float* par[4] = {&loc, &rho, &w, &wb};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float gk = gr[k];
-        if (!(gk == gk)) gk = 0.f;
-        m1[k] = 0.9f * m1[k] + 0.1f * gk;
-        m2[k] = 0.999f * m2[k] + 0.001f * gk * gk;
-        if (k < 2 || (k == 2 && P.learn_a) || (k == 3 && P.wb)) *par[k] -= lr_t * m1[k] / (__builtin_amdgcn_sqrtf(m2[k]) + 1e-8f);
+    for (int u = 0; u < PPT; ++u) {
+      const int d = tid + u * B;
+      if (d < D) {
+        if (grouped) {
+          for (int e = 1; e < gsize[u][0]; ++e) ga[u] += s_red[0][d + e];
+          for (int e = 1; e < gsize[u][1]; ++e) gb[u] += s_red[1][d + e];
+        }
+        const float sgm = s_sig[d];
+        const float a = s_a[d], bb = s_b[d];
+        const float pa = P.a_prior ? discrete_prior_dlogp(a) : 0.f;
+        const float pb = P.a_prior ? discrete_prior_dlogp(bb) : 0.f;
+        float gr[4];
+        gr[0] = -tot[u][0] * inv;
+        gr[1] = -(tot[u][1] * inv + 1.0f / sgm) * sigmoidf_(rho[u]);
+        gr[2] = P.learn_a ? -(ga[u] + pa) * a * (1.0f - a) : 0.f;
+        gr[3] = P.wb ? -(gb[u] + pb) * bb * (1.0f - bb) : 0.f;
+        float* par[4] = {&loc[u], &rho[u], &w[u], &wb[u]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float gk = gr[k];
+          if (!(gk == gk)) gk = 0.f;
+          m1[u][k] = 0.9f * m1[u][k] + 0.1f * gk;
+          m2[u][k] = 0.999f * m2[u][k] + 0.001f * gk * gk;
+          if (k < 2 || (k == 2 && P.learn_a) || (k == 3 && P.wb))
+            *par[k] -= lr_t * m1[u][k] / (__builtin_amdgcn_sqrtf(m2[u][k]) + 1e-8f);
+        }
       }
     }
     if (grouped) {   // members take their leader's value
       __syncthreads();
-      if (tid < D) { s_red[0][tid] = w; s_red[1][tid] = wb; }
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) { const int d = tid + u * B; if (d < D) { s_red[0][d] = w[u]; s_red[1][d] = wb[u]; } }
       __syncthreads();
-      if (tid < D) { w = s_red[0][lead[0]]; wb = s_red[1][lead[1]]; }
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) { const int d = tid + u * B; if (d < D) { w[u] = s_red[0][lead[u][0]]; wb[u] = s_red[1][lead[u][1]]; } }
     }
-    if (tid == 0) {
+    __syncthreads();
+    if (tid == 0 && wg == 0) {
       float c = P.const_base + 0.9189385332046727f * (float)D;   // + 0.5 log 2pi per latent from -log q
       for (int k = 0; k < P.n_top; ++k) c -= s_b[P.top_idx[k]] * P.top_logscale[k];
       P.elbo[(size_t)lr_i * P.n_steps + step] = s_elbo / (float)P.n_mc + c;
       if (P.prior) P.prior[(size_t)lr_i * P.n_steps + step] = s_prior;
     }
+    failed = s_fail != 0;
     __syncthreads();
+    VI_T(10);
   }
-  if (tid < D) {
-    P.loc[(size_t)lr_i * D + tid] = loc;
-    P.rho[(size_t)lr_i * D + tid] = rho;
-    if (P.learn_a) P.w[(size_t)lr_i * D + tid] = w;
-    if (P.wb) P.wb[(size_t)lr_i * D + tid] = wb;
+  VI_TPRINT(P.n_steps);
+  if (wg == 0) {
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const int d = tid + u * B;
+      if (d < D) {
+        P.loc[(size_t)lr_i * D + d] = loc[u];
+        P.rho[(size_t)lr_i * D + d] = rho[u];
+        if (P.learn_a) P.w[(size_t)lr_i * D + d] = w[u];
+        if (P.wb) P.wb[(size_t)lr_i * D + d] = wb[u];
+      }
+    }
   }
 }
 

@@ -29,6 +29,12 @@ constexpr int kGermanCols = 64;   // padded row length of the device design matr
 // (forward: 16 rows x one chunk of a 64-byte feature block; backward: 4 rows x 16 consecutive chunks per lane group),
 // checked lane by lane against the gfx950 bank rules (4 groups of 16 lanes, bank = dword address mod 64).
 constexpr int kGermanTileRows = 128;
+#ifndef ARP_GERMAN_VI_BLOCK
+#define ARP_GERMAN_VI_BLOCK 256
+#endif
+constexpr int kGermanViBlock = ARP_GERMAN_VI_BLOCK;   // threads of a VI workgroup (kernels.h: vi_kernel), 16 draws per wave: four waves,
+//   one per SIMD, and with 256 draws 4 sample groups x 8 row parts (one resident 128-row tile each) per learning rate:
+//   68 ms per fit against 80 ms with two-wave workgroups of two tiles (profiles/r05_vi_kernel.txt)
 constexpr int kGermanImgTile = 33 * 256;   // floats per tile of the image
 
 struct GermanArgs {
@@ -39,8 +45,12 @@ struct GermanArgs {
 };
 
 // W_: waves per workgroup of the kernels the lane is used in (sizes the per-wave LDS areas of the
-// matrix-core path): kBlock / 64 for the chain kernels, kViBlock / 64 for the VI kernel.
-template <int K_, int NLS_, int W_ = kBlock / 64>
+// matrix-core path): kBlock / 64 for the chain kernels, the VI kernel's own workgroup size / 64 for the VI kernel.
+// PART_: the VI kernel's form (kernels.h: vi_kernel).  The observations of one gradient are split over the
+// workgroups of a learning rate: a lane evaluates the tiles [tlo, thi) only and the prior terms of the log density and of
+// the gradient with weight `pw` (1 in the workgroup that owns row part 0, 0 elsewhere), so that the SUM over the row
+// parts of everything grad() and dparam() return is the whole model's -- they are affine in the likelihood's v.
+template <int K_, int NLS_, int W_ = kBlock / 64, bool PART_ = false>
 struct GermanLane {
   static constexpr int K = K_;
   static constexpr int NG = 1;          // overall_log_scale
@@ -60,6 +70,34 @@ struct GermanLane {
   float s0i, c0;            // 1/10^b0, 10^(1-b0)
   const float* X; const float* y; const float* Xt;
   int N, F, slot, nown;
+  int tlo_, thi_; float pw_;   // PART_ only: tile range and prior weight of this workgroup's row part
+  bool res_;                   // PART_ only: the part's (at most two) tiles stay in the LDS buffers for the whole launch
+  static constexpr bool HAS_PART = PART_;
+  static constexpr int VI_BLOCK = W_ * 64;
+  static constexpr int VI_DMAX = 128;   // LDS arrays of the VI kernel are sized for this (the real data: D = 125)
+  ARP_DEV int tlo() const { if constexpr (PART_) return tlo_; else return 0; }
+  ARP_DEV int thi() const { if constexpr (PART_) return thi_; else return (N + kGermanTileRows - 1) / kGermanTileRows; }
+  ARP_DEV float pw() const { if constexpr (PART_) return pw_; else return 1.0f; }
+  // row part `r` of `R`: whole tiles, as even as they go (a part past the data is empty and contributes nothing)
+  ARP_DEV void set_part(int r, int R) {
+    const int nt = (N + kGermanTileRows - 1) / kGermanTileRows, per = (nt + R - 1) / R;
+    tlo_ = min(nt, r * per); thi_ = min(nt, tlo_ + per); pw_ = r == 0 ? 1.0f : 0.0f;
+  }
+  ARP_DEV bool resident() const { if constexpr (PART_) return res_; else return false; }
+  // A part of one or two tiles is copied into the two LDS buffers ONCE (all threads of the workgroup call this after
+  // set_part): every later gradient finds its operands in place -- no LDS-DMA, no wait for it, no workgroup barrier, the
+  // waves of the workgroup run their draws independently.
+  ARP_DEV void make_resident() {
+    static_assert(PART_, "row-part form only");
+    const int nt = thi_ - tlo_;
+    res_ = nt >= 1 && nt <= 2;
+    if (!res_) return;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t tile_off = lds_offset(tile_mem());
+    for (int n = 0; n < nt; ++n) issue_tile(tlo_ + n, (n + nt) & 1, tile_off, wv, threadIdx.x & 63);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 
   static ARP_DEV int gg(int) { return 0; }
   ARP_DEV int lbase(int i) const { return i < NLS ? 1 + slot * NLS : 1 + F + slot * NLS; }
@@ -72,6 +110,7 @@ struct GermanLane {
     X = A.X; y = A.y; Xt = A.Xt; N = A.N; F = A.F;
     nown = F - slot * NLS;
     nown = nown < 0 ? 0 : (nown > NLS ? NLS : nown);
+    tlo_ = 0; thi_ = (N + kGermanTileRows - 1) / kGermanTileRows; pw_ = 1.0f; res_ = false;
     set_param(av, bv);
   }
   ARP_DEV void set_param(const float* av, const float* bv) {
@@ -96,7 +135,7 @@ struct GermanLane {
   static constexpr int kYBase = kXBufB;                  // outcomes of buffer 0
   static constexpr int kXchStride = kGermanCols + 4;  // exchange rows padded: conflict-free float4 access both ways
   static constexpr int kXchWaves = W_;                // waves per workgroup the exchange area covers
-  static constexpr bool HAS_VI = W_ == kViBlock / 64;   // the VI kernel is built from the lanes sized for its 8 waves
+  static constexpr bool HAS_VI = PART_;   // the VI kernel is built from the row-part form, sized for its own workgroup
   static constexpr int kXch = 16 * kXchStride + 64;   // per wave: [16 chains][row] + 64 log-density partials
   static constexpr int kXchBase = (2 * kXBufB + 2 * kYBufB) / 4;
   static constexpr int kTileFloats = K_ == 4 ? kXchBase + kXchWaves * kXch : kRows * kStride + kRows;
@@ -513,9 +552,10 @@ struct GermanLane {
   // longer in use by any wave after the barrier; tile 0 then travels while the prior part of the gradient is computed.
   ARP_DEV void first_tile() const {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nt = (N + kRows - 1) / kRows;
+    const int nt = thi() - tlo();
+    if (resident()) return;
     __syncthreads();
-    issue_tile(0, nt & 1, lds_offset(tile_mem()), wv, threadIdx.x & 63);
+    if (!PART_ || nt > 0) issue_tile(tlo(), nt & 1, lds_offset(tile_mem()), wv, threadIdx.x & 63);
   }
 
   template <bool LOGP>
@@ -530,9 +570,9 @@ struct GermanLane {
     const int c = lane >> 2, t = lane & 3;    // state layout (t == slot)
     const int gk = lane >> 4, j = lane & 15;  // MFMA layout
     const uint32_t tile_off = lds_offset(tile);
-    const int nt = (N + kRows - 1) / kRows;
+    const int t0 = tlo(), nt = thi() - t0;   // this workgroup's tiles (all of them outside the VI kernel)
     int buf = nt & 1;
-    ARP_T0(tt);   // tile 0 is on its way (first_tile)
+    ARP_T0(tt);   // tile t0 is on its way (first_tile)
 
     float4* own = reinterpret_cast<float4*>(xch + c * kXchStride + 16 * t);
     const float4* mine = reinterpret_cast<const float4*>(xch + j * kXchStride + 16 * gk);
@@ -572,13 +612,15 @@ struct GermanLane {
     v4f xb[2][4];
     float w[4];
     // tile 0 has landed everywhere; tile 1 into the other buffer
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (nt > 1) issue_tile(1, buf ^ 1, tile_off, wv, lane);
+    if (!resident()) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (nt > 1) issue_tile(t0 + 1, buf ^ 1, tile_off, wv, lane);
+    }
     ARP_T(2, tt);
-    first_reads(a_off, b_off, y_off, xa, xb, y4);
+    if (!PART_ || nt > 0) first_reads(a_off, b_off, y_off, xa, xb, y4);
     for (int n = 0; n < nt; ++n) {
-      const int rows = min(kRows, N - n * kRows);   // the image is zero filled up to the tile's last row
+      const int rows = min(kRows, N - (t0 + n) * kRows);   // the image is zero filled up to the tile's last row
       if (!LOGP || rows == kRows) {     // only the log density cares about padding rows, and only the last tile has any
         head<LOGP, false>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, lp2);
         phases<LOGP, false, 0>(a_off, b_off, y_off, gk, rows, bB, xa, xb, y4, w, acc, lp2);
@@ -592,10 +634,12 @@ struct GermanLane {
       if (n + 1 < nt) {
         // tile n+1 is in LDS for every wave and nobody reads tile n any more: its buffer takes tile n+2, and the first
         // reads of tile n+1 go out in the shadow of the last MFMAs of tile n
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!resident()) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
         tail_quarter(xb[lb][0], w[0], acc);
-        if (n + 2 < nt) issue_tile(n + 2, buf, tile_off, wv, lane);
+        if (n + 2 < nt) issue_tile(t0 + n + 2, buf, tile_off, wv, lane);
         const uint32_t dx = buf ? (uint32_t)-kBufStep : (uint32_t)kBufStep, dy = buf ? (uint32_t)-kYBufB : (uint32_t)kYBufB;
         buf ^= 1;
         __builtin_amdgcn_sched_barrier(0);
@@ -660,6 +704,26 @@ struct GermanLane {
     else lp = likelihood_generic<LOGP>(beta, v);
     ARP_T(7, tg);
     float lq = 0.0f, g_ols = 0.0f;
+    if constexpr (PART_) {
+      // row-part form: the prior terms carry the weight pw (the model's own formulas below with pw = 1)
+      const float w_ = pw();
+#pragma unroll
+      for (int i = 0; i < NLS; ++i) {
+        float e = fast_exp(-b[i] * bls[i]);
+        float zb = q[NG + NLS + i] * e;
+        float hb = fmaf(w_ * b[i], fmaf(zb, zb, -1.0f), v[i] * (1.0f - b[i]) * beta[i]);
+        bool ok = i < nown;
+        g[NG + NLS + i] = ok ? fmaf(v[i], fast_exp((1.0f - b[i]) * bls[i]), -w_ * zb * e) : 0.0f;
+        g[NG + i] = ok ? fmaf(-w_, r[i], hb) : 0.0f;
+        g_ols += ok ? fmaf(w_ * a[i], r[i], (1.0f - a[i]) * hb) : 0.0f;
+        if (LOGP) lq += ok ? fmaf(-0.5f * r[i], r[i], fmaf(-0.5f * zb, zb, -b[i] * bls[i])) : 0.0f;
+      }
+      g_ols = group_sum<K>(g_ols);
+      const float u0 = q[0] * s0i;
+      g[0] = fmaf(c0, g_ols, -w_ * u0 * s0i);
+      if (LOGP) lp += w_ * (group_sum<K>(lq) - 0.5f * u0 * u0);
+      return lp;
+    }
 #pragma unroll
     for (int i = 0; i < NLS; ++i) {
       float e = fast_exp(-b[i] * bls[i]);
@@ -683,13 +747,14 @@ struct GermanLane {
     const float ols = c0 * q[0];
 #pragma unroll
     for (int i = 0; i < ND; ++i) { da[i] = 0.0f; db[i] = 0.0f; }
-    db[0] = -2.302585092994046f * fmaf(q[0], g[0], 1.0f);
+    // (PART_: g is this row part's share of the gradient; the constant 1 of the two affine forms counts once)
+    db[0] = -2.302585092994046f * fmaf(q[0], g[0], pw());
 #pragma unroll
     for (int i = 0; i < NLS; ++i) {
       bool ok = i < nown;
       float bls = fmaf(-a[i], ols, q[NG + i]) + ols;
       da[NG + i] = ok ? -ols * g[NG + i] : 0.0f;
-      db[NG + NLS + i] = ok ? -bls * fmaf(q[NG + NLS + i], g[NG + NLS + i], 1.0f) : 0.0f;
+      db[NG + NLS + i] = ok ? -bls * fmaf(q[NG + NLS + i], g[NG + NLS + i], pw()) : 0.0f;
     }
   }
 

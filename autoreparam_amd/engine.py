@@ -230,6 +230,15 @@ class Engine(object):
         return (elbo, prior) if return_prior else elbo
 
 
+    def vi_geometry(self):
+        """Shape of this thread's last vi_run launch (arp_vi_geometry): threads per workgroup, sample groups G and row
+        parts R per learning rate, learning rates per launch, workgroups resident together, workgroups one CU holds."""
+        out = (C.c_int32 * 6)()
+        _lib.check(self._L.arp_vi_geometry(out))
+        keys = ("threads_per_workgroup", "sample_groups", "row_parts", "learning_rates_per_launch", "workgroups_resident",
+                "workgroups_per_cu")
+        return dict(zip(keys, [int(v) for v in out]))
+
     def adapt_probe(self, log_accept, adapt, kind, n_adapt, step_base=0, target=0.75, rate=0.05):
         """Test hook (arp_adapt_probe): the kernels' step-size recurrence on scripted log acceptance ratios
         `log_accept` [n_steps, n]; `adapt` [n, 4] is updated in place; returns the multipliers [n_steps, n]."""

@@ -167,11 +167,16 @@ int arp_interleaved_run(arp_model* m, const arp_hmc_config* cfg, int n_leapfrog_
 
 /* Mean-field VI (find_best_learning_rate, inference.py:26-154 on top of
  * util.get_mean_field_elbo, util.py:232-268): runs `n_lr` independent Adam
- * optimisations (one workgroup each) of `n_steps` steps in ONE launch. */
+ * optimisations of `n_steps` steps in ONE launch (several when the learning rates do not all fit on the device at
+ * once).  Every learning rate's `n_mc` draws are spread over a GROUP of workgroups that exchange their partial
+ * gradient sums twice per step inside the launch and add them in a fixed order: a fit is bitwise reproducible, and
+ * its draws do not depend on how the group is shaped.  The call is SYNCHRONOUS on `stream` when a group has more than
+ * one workgroup (it waits for the launch to check that no in-launch hand-off timed out) and returns non-zero if one
+ * did.  It keeps a hand-off workspace on the handle (freed by arp_model_destroy). */
 typedef struct arp_vi_config {
   int32_t n_lr;              /* number of learning rates */
   int32_t n_steps;           /* num_optimization_steps */
-  int32_t n_mc;              /* num_mc_samples (<= 1024) */
+  int32_t n_mc;              /* num_mc_samples (<= 4096) */
   int32_t learn_a;           /* 1: also optimise the VIP parameter a = sigmoid(w) (cVIP) */
   int32_t tied_b;            /* 1: b := a in the density (tied_pparams as intended); 0: b from set_param, or learned via io.wb */
   int32_t a_prior;           /* 0: none; 1: the reference's --discrete_prior on the learnable parameters (main.py:244-253):
@@ -197,6 +202,10 @@ typedef struct arp_vi_io {
   const int32_t* b_group;    /* the same for the separately learned b (shape of the variable's scale; only read with wb) */
 } arp_vi_io;
 int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_io* io, void* stream);
+/* Measurement hook: the shape the calling thread's last arp_vi_run gave its launch -- out6 = {threads per workgroup,
+ * sample groups G, row parts R (workgroups per learning rate = G x R), learning rates per launch, workgroups resident
+ * together (= CUs in use when one fits per CU), workgroups of the kernel one CU holds}.  (bench.py: vi_kernel.) */
+int arp_vi_geometry(int32_t* out6);
 
 /* Effective sample size of every series of a recorded trace (replaces tfp.mcmc.effective_sample_size with its
  * defaults, inference.py:240, 327): `trace` holds n_samples rows of `row_stride` floats, series i is column i

@@ -182,3 +182,111 @@ def test_discrete_prior_ranks_on_elbo_plus_prior(gpu, tmp_path):
     assert abs(np.mean(tl1[-32:]) - e1) > 1e-3          # the prior term is in the timeline (its density is ~1.02 near
     #                                                      the ends of (0, 1) and ~0.99 in the middle: small either way)
     assert abs(np.mean(tl0[-32:]) - e0) < 1e-9           # no prior: the timeline is the ELBO itself
+
+
+def _fit(eng, gpu, sp, lrs, n_steps, n_mc, seed, learn=False):
+    rs = np.random.RandomState(0)
+    loc0 = (1e-2 * rs.randn(len(lrs), sp.D)).astype(np.float32)
+    loc = torch.as_tensor(loc0.copy(), device=gpu); rho = torch.full((len(lrs), sp.D), -2.0, device=gpu)
+    w = torch.zeros(len(lrs), sp.D, device=gpu) if learn else None
+    elbo = eng.vi_run(lrs, loc, rho, n_steps, n_mc, w=w, seed=seed)
+    return elbo.cpu().numpy(), loc.cpu().numpy(), rho.cpu().numpy(), eng.vi_geometry()
+
+
+@pytest.mark.parametrize("mname,knob,values", [("radon_MN", "ARP_VI_G", (4, 8, 32)), ("election", "ARP_VI_G", (4, 16)),
+                                               ("german", "ARP_VI_R", (1, 2, 8))])
+def test_vi_fit_does_not_depend_on_the_launch_geometry(gpu, monkeypatch, mname, knob, values):
+    """The draws belong to the sampler's specification, not to the launch: a learning rate's 256 draws split over 4, 8 or
+    32 sample groups (a lane then takes 8, 4 or 1 of them per step and skips the words of the others' turns -- by
+    stepping, or by one jump of the generator) and German credit's observations over 1, 2 or 8 row parts give the same
+    fit up to the order of the sums; every geometry is bitwise reproducible."""
+    from autoreparam_amd import engine
+    sp = helpers.spec(mname)
+    eng = engine.Engine(sp, gpu)
+    eng.set_param(0, "NCP")
+    monkeypatch.setenv("ARP_DEBUG", "1")
+    out = []
+    for v in values:
+        monkeypatch.setenv(knob, str(v))
+        a = _fit(eng, gpu, sp, [0.02, 0.1], 120, 256, seed=21)
+        b = _fit(eng, gpu, sp, [0.02, 0.1], 120, 256, seed=21)
+        assert a[3]["sample_groups" if knob == "ARP_VI_G" else "row_parts"] == v
+        for x, y in zip(a[:3], b[:3]):
+            assert np.array_equal(x, y)
+        out.append(a)
+    for o in out[1:]:
+        np.testing.assert_allclose(o[0][:, :3], out[0][0][:, :3], rtol=2e-6, atol=2e-3)      # same draws: rounding only
+        np.testing.assert_allclose(o[0][:, -32:].mean(1), out[0][0][:, -32:].mean(1), rtol=1e-3, atol=0.3)
+        np.testing.assert_allclose(o[1], out[0][1], rtol=0, atol=0.03 * (np.abs(out[0][1]).max() + 1))
+
+
+@pytest.mark.parametrize("mname,n_mc", [("radon_MN", 37), ("radon_MN", 600), ("election", 100), ("german", 100),
+                                        ("8schools", 1000)])
+def test_vi_ragged_draw_counts_match_oracle(oracle_lib, gpu, mname, n_mc):
+    """num_mc_samples that do not fill the draw layout's last turn, a workgroup or a wave: same timelines as the oracle's
+    sequential draws (orc_vi_run: stream s mod (512 / lanes), turn s / (512 / lanes))."""
+    from autoreparam_amd import engine
+    sp = helpers.spec(mname)
+    eng = engine.Engine(sp, gpu)
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "NCP")
+    eng.set_param(0, (a, b))
+    lrs = [0.05]
+    rs = np.random.RandomState(0)
+    loc0 = (1e-2 * rs.randn(1, sp.D)).astype(np.float32); rho0 = np.full((1, sp.D), -2.0, np.float32)
+    loc = torch.as_tensor(loc0.copy(), device=gpu); rho = torch.as_tensor(rho0.copy(), device=gpu)
+    n_steps = 60
+    elbo = eng.vi_run(lrs, loc, rho, n_steps, n_mc, seed=8).cpu().numpy()
+    lo, ro = loc0.copy(), rho0.copy()
+    elbo_o = orc.vi_run(a, b, lrs, lo, ro, None, n_steps, n_mc, seed=8, lanes=VI_LANES[mname])
+    np.testing.assert_allclose(elbo[:, :5], elbo_o[:, :5], rtol=2e-5, atol=2e-2)
+    np.testing.assert_allclose(elbo[:, -16:].mean(1), elbo_o[:, -16:].mean(1), rtol=2e-3, atol=0.5)
+
+
+def test_vi_more_learning_rates_than_fit_on_the_device(gpu):
+    """German credit, 12 learning rates: 12 groups of 32 workgroups at one workgroup per CU do not fit on 256 CUs, so
+    the library runs them in several launches -- each learning rate's fit is bitwise the one it gets alone."""
+    from autoreparam_amd import engine
+    sp = helpers.spec("german")
+    eng = engine.Engine(sp, gpu)
+    eng.set_param(0, "NCP")
+    lrs = [0.01 * (k + 1) for k in range(12)]
+    e_all, loc_all, rho_all, g = _fit(eng, gpu, sp, lrs, 40, 256, seed=3)
+    assert g["learning_rates_per_launch"] < 12
+    assert g["sample_groups"] * g["row_parts"] * g["learning_rates_per_launch"] <= g["workgroups_per_cu"] * 256
+    assert np.isfinite(e_all).all()
+    rs = np.random.RandomState(0)
+    loc0 = (1e-2 * rs.randn(12, sp.D)).astype(np.float32)
+    for k in (0, 7, 11):
+        # alone: the stream id carries the learning rate's INDEX, so it runs as index k of a list of the same length
+        loc = torch.as_tensor(loc0.copy(), device=gpu); rho = torch.full((12, sp.D), -2.0, device=gpu)
+        lr_k = [1e-9] * 12
+        lr_k[k] = lrs[k]
+        e_k = eng.vi_run(lr_k, loc, rho, 40, 256, seed=3).cpu().numpy()
+        assert np.array_equal(e_k[k], e_all[k]) and np.array_equal(loc.cpu().numpy()[k], loc_all[k])
+
+
+def test_vi_hand_offs_under_uneven_load(gpu):
+    """The in-launch hand-offs between a learning rate's workgroups (8-byte {epoch, value} granules, agent-scope relaxed
+    atomics) with the device busy on another stream -- workgroups arrive unevenly, lines are warm in the other XCDs' L2:
+    the fit stays bit for bit the quiet one, cVIP's four sums per parameter included."""
+    from autoreparam_amd import engine
+    for mname in ("election", "german"):
+        sp = helpers.spec(mname)
+        eng = engine.Engine(sp, gpu)
+        eng.set_param(0, (np.full(sp.D, 0.5, np.float32), np.ones(sp.D, np.float32)))
+        quiet = _fit(eng, gpu, sp, [0.02, 0.05, 0.1], 150, 256, seed=13, learn=True)
+        side = torch.cuda.Stream(device=gpu)
+        x = torch.randn(2048, 2048, device=gpu)
+        stop = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            for _ in range(200):
+                x = torch.tanh(x @ x * 1e-3)
+            stop.record()
+        busy = _fit(eng, gpu, sp, [0.02, 0.05, 0.1], 150, 256, seed=13, learn=True)
+        still_busy = not stop.query()
+        torch.cuda.synchronize()
+        for a, b in zip(quiet[:3], busy[:3]):
+            assert np.array_equal(a, b)
+        assert np.isfinite(busy[0]).all()
+        del still_busy

@@ -91,3 +91,63 @@ def test_normals_moments(oracle_lib):
     assert abs(np.corrcoef(z[0::2], z[1::2])[0, 1]) < 4 / np.sqrt(n_pairs)
     assert abs(np.corrcoef(z[:-2:2], z[2::2])[0, 1]) < 4 / np.sqrt(n_pairs)
     assert np.abs(z).max() < 6.8  # u >= 2^-33: |z| <= sqrt(2*33*ln2) = 6.76
+
+
+def test_mwc64x_jump_ahead_is_n_single_steps():
+    """arp_device.h: rng_jump.  With v = c 2^32 + x a step is v -> A v mod m, m = A 2^32 - 1, so n steps are ONE modular
+    multiplication by A^n; the device forms it as a Montgomery product (two rounds of the generator's own reduction on
+    the 128-bit product).  Restated here in 64-bit-wrapping Python integers, operation for operation, and held to n
+    single steps (and to pow() for long jumps); the intermediate bounds the device code relies on are asserted."""
+    import random
+    A, M64 = 4294883355, (1 << 64) - 1
+    m = (A << 32) - 1
+    one = (0 - m) & M64
+    assert one == (1 << 64) % m
+    mont_a = (A * one) % m
+
+    def montmul(a, b):
+        p = a * b
+        lo, hi = p & M64, p >> 64
+        t = (lo & 0xffffffff) * A
+        l1, h1 = ((hi << 32) & M64) | (lo >> 32), hi >> 32
+        l1 = (l1 + t) & M64
+        h1 += 1 if l1 < t else 0
+        t = (l1 & 0xffffffff) * A
+        c2 = h1 >> 32
+        assert ((h1 << 32) & M64) + (l1 >> 32) <= M64
+        l2 = (((h1 << 32) & M64) + (l1 >> 32) + t) & M64
+        c2 += 1 if l2 < t else 0
+        assert c2 <= 1
+        if c2:
+            assert l2 + one <= M64
+            l2 += one
+        for _ in range(2):
+            if l2 >= m:
+                l2 -= m
+        assert l2 < m
+        return l2
+
+    def power(n):
+        r, base = one, mont_a
+        while n:
+            if n & 1:
+                r = montmul(r, base)
+            base = montmul(base, base)
+            n >>= 1
+        return r
+
+    rnd = random.Random(1)
+    cases = [(0xffffffff, A - 2), (1, 0), (0, 1), (0xffffffff, 0x7fffffff), (12345, 0)]
+    cases += [(rnd.getrandbits(32), rnd.getrandbits(31)) for _ in range(400)]
+    for x, c in cases:
+        for n in (0, 1, 2, 10, 34, 68, 70, 1000, 4095 * 34):
+            if n <= 1000:
+                xs, cs = x, c
+                for _ in range(n):
+                    t = xs * A + cs
+                    xs, cs = t & 0xffffffff, t >> 32
+            else:
+                v = ((c << 32) | x) * pow(A, n, m) % m
+                xs, cs = v & 0xffffffff, v >> 32
+            v = montmul((c << 32) | x, power(n))
+            assert (v & 0xffffffff, v >> 32) == (xs, cs), (x, c, n)
