@@ -17,6 +17,19 @@ static const double kHalfLog2Pi = 0.9189385332046727;
 struct ViGeometry { int v[6]; };
 static thread_local ViGeometry g_vi_geometry = {{0, 0, 0, 0, 0, 0}};
 
+// Test hook (ARP_DEBUG=1 ARP_HOST_ONLY=1, announced on stderr): model handles WITHOUT a device.  Host memory stands in
+// for the device tables, so that every entry point's argument validation and host-side sizing can be driven -- and run
+// under a sanitizer -- on a GPU-less machine (tests/test_api_fuzz.py).  Nothing can be computed with such a handle:
+// every call that gets past validation fails with HIP's own "no device" error at its first HIP call.
+static bool host_only() {
+  const char* e = getenv("ARP_HOST_ONLY");
+  const char* d = getenv("ARP_DEBUG");
+  if (!(e && e[0] == '1' && d && d[0] == '1' && d[1] == 0)) return false;
+  static bool said = false;
+  if (!said) { fprintf(stderr, "libautoreparam_hip: DEBUG SWITCH ARP_HOST_ONLY=1 is in effect (handles without a device: validation only)\n"); said = true; }
+  return true;
+}
+
 // integer experiment switch, honoured under ARP_DEBUG=1 only and announced on stderr
 static bool debug_int(const char* name, int* out) {
   const char* e = getenv(name);
@@ -134,6 +147,12 @@ static int build_radon(arp_model* m, const arp_dataset* d) {
 }
 
 static int upload_tables(arp_model* m) {
+  if (m->host_only) {
+    m->dev_tables = (float*)malloc(std::max<size_t>(1, m->host_tables.size()) * sizeof(float));
+    if (!m->dev_tables) { set_error("upload_tables: out of memory"); return 1; }
+    memcpy(m->dev_tables, m->host_tables.data(), m->host_tables.size() * sizeof(float));
+    return 0;
+  }
   ARP_HIP_OK(hipMalloc(&m->dev_tables, m->host_tables.size() * sizeof(float)));
   ARP_HIP_OK(hipMemcpy(m->dev_tables, m->host_tables.data(), m->host_tables.size() * sizeof(float),
                        hipMemcpyHostToDevice));
@@ -362,7 +381,9 @@ int arp_model_create(const arp_dataset* data, arp_model** out) {
   if (!data || !out) { set_error("arp_model_create: null argument"); return 1; }
   std::unique_ptr<arp_model> m(new arp_model());
   m->model = data->model;
-  ARP_HIP_OK(hipGetDevice(&m->device));
+  m->host_only = host_only();
+  if (m->host_only) m->device = -1;
+  else ARP_HIP_OK(hipGetDevice(&m->device));
   int rc;
   switch (data->model) {
     case ARP_MODEL_RADON: rc = build_radon(m.get(), data); break;
@@ -379,6 +400,11 @@ int arp_model_create(const arp_dataset* data, arp_model** out) {
   }
   if (rc) { arp_model_destroy(m.release()); return rc; }
   for (int w = 0; w < 2; ++w) {
+    if (m->host_only) {
+      m->dev_ab[w] = (float*)malloc(2 * (size_t)m->D * sizeof(float));
+      if (!m->dev_ab[w]) { set_error("arp_model_create: out of memory"); arp_model_destroy(m.release()); return 1; }
+      continue;
+    }
     if (hipMalloc(&m->dev_ab[w], 2 * (size_t)m->D * sizeof(float)) != hipSuccess) {
       set_error("arp_model_create: hipMalloc of the parameterisation arrays failed");
       arp_model_destroy(m.release());
@@ -400,6 +426,12 @@ int arp_model_create(const arp_dataset* data, arp_model** out) {
 
 int arp_model_destroy(arp_model* m) {
   if (!m) return 0;
+  if (m->host_only) {
+    free(m->dev_tables);
+    for (int w = 0; w < 2; ++w) free(m->dev_ab[w]);
+    delete m;
+    return 0;
+  }
   if (m->dev_tables) (void)hipFree(m->dev_tables);
   for (int w = 0; w < 2; ++w) if (m->dev_ab[w]) (void)hipFree(m->dev_ab[w]);
   if (m->vi_ws) (void)hipFree(m->vi_ws);
@@ -415,8 +447,13 @@ double arp_model_logp_const(const arp_model* m, int which) {
 
 int arp_model_set_param(arp_model* m, int which, const float* a_host, const float* b_host) {
   if (!m || which < 0 || which > 1 || !a_host || !b_host) { set_error("arp_model_set_param: bad argument"); return 1; }
-  ARP_HIP_OK(hipMemcpy(m->dev_ab[which], a_host, m->D * sizeof(float), hipMemcpyHostToDevice));
-  ARP_HIP_OK(hipMemcpy(m->dev_ab[which] + m->D, b_host, m->D * sizeof(float), hipMemcpyHostToDevice));
+  if (m->host_only) {
+    memcpy(m->dev_ab[which], a_host, m->D * sizeof(float));
+    memcpy(m->dev_ab[which] + m->D, b_host, m->D * sizeof(float));
+  } else {
+    ARP_HIP_OK(hipMemcpy(m->dev_ab[which], a_host, m->D * sizeof(float), hipMemcpyHostToDevice));
+    ARP_HIP_OK(hipMemcpy(m->dev_ab[which] + m->D, b_host, m->D * sizeof(float), hipMemcpyHostToDevice));
+  }
   m->has_param[which] = true;
   bool all1 = true, all0 = true, b1 = true;
   for (int d = 0; d < m->D; ++d) {

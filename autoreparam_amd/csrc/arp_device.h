@@ -25,6 +25,12 @@ ARP_DEV void store_f4(float4* dst, const float4& v) {
   else *dst = v;
 }
 
+template <bool STREAM>
+ARP_DEV void store_v4(v4f_nt* dst, v4f_nt v) {
+  if constexpr (STREAM) __builtin_nontemporal_store(v, dst);
+  else *dst = v;
+}
+
 // ---------------------------------------------------------------------------
 // Cross-lane helpers.  A chain is spread over K consecutive lanes (K | 16), so a
 // chain never straddles a DPP row of 16 lanes; all exchanges are VALU DPP

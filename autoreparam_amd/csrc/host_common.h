@@ -245,6 +245,7 @@ struct arp_model {
   int model = -1;
   int D = 0;
   int device = 0;
+  bool host_only = false;    // test hook (arp_api.hip: host_only): no device behind this handle
   int n_groups = 0;          // slice axis length (radon J, election 52, schools 8)
   float* dev_tables = nullptr;   // one allocation holding all frozen tables
   float* dev_ab[2] = {nullptr, nullptr};  // [2][D]: a then b, per parameterisation

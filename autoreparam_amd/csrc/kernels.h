@@ -121,14 +121,26 @@ ARP_DEV void store_row_wave(const Lane& M, float* stage, float* gdst, int cl, in
   __builtin_amdgcn_wave_barrier();
   const int lane = threadIdx.x & 63;
   if ((reinterpret_cast<uintptr_t>(gdst) & 15) == 0) {
-    for (int k = lane * 4; k < nvalid; k += 256) {
-      const float4 t = *reinterpret_cast<const float4*>(stage + k);
-      if (k + 3 < nvalid) {
-        store_f4<STREAM>(reinterpret_cast<float4*>(gdst + k), t);
-      } else {
-        gdst[k] = t.x;
-        if (k + 1 < nvalid) gdst[k + 1] = t.y;
-        if (k + 2 < nvalid) gdst[k + 2] = t.z;
+    // four 1 KiB slices at a time, their LDS reads all in flight before the first store: one read -> wait -> store per
+    // slice is an LDS round trip per KiB in a row (pk_chain.h: pk_store_rows has the measurement)
+    for (int k0 = lane * 4; k0 < nvalid; k0 += 1024) {
+      v4f_nt t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + 256 * u;
+        t[u] = *reinterpret_cast<const v4f_nt*>(stage + (k < nvalid ? k : lane * 4));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + 256 * u;
+        if (k + 3 < nvalid) {
+          store_v4<STREAM>(reinterpret_cast<v4f_nt*>(gdst + k), t[u]);
+        } else if (k < nvalid) {
+          gdst[k] = t[u][0];
+          if (k + 1 < nvalid) gdst[k + 1] = t[u][1];
+          if (k + 2 < nvalid) gdst[k + 2] = t[u][2];
+        }
       }
     }
   } else {

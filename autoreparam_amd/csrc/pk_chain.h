@@ -274,11 +274,20 @@ ARP_DEV void pk_store_rows(const T& M, float* stage, float* gdst, int cl, int D,
     lane &= 63;
     const float4* s4 = reinterpret_cast<const float4*>(stage);
     float4* g4 = reinterpret_cast<float4*>(gdst);
+    // ALL the block's LDS reads first, into registers of their own, then the stores: read -> wait -> store -> read into
+    // the same four registers (what the loop compiled to through round 4) is five LDS round trips in a row, each also
+    // waiting for the store before it to have taken its data -- 600 - 1 000 cycles per row that the other wave of the
+    // SIMD, recording the same step, cannot cover.  The registers are free here: a row is stored between transitions.
+    // (a lane past the block's end re-reads and re-stores its FIRST 16 bytes: the same bytes to the same place, so
+    // neither the reads nor the stores are predicated and nothing branches)
+    constexpr int NIT = (NV / 4 + 63) / 64;
+    v4f_nt t[NIT];      // (a native vector: an array of HIP's float4 structs was left in scratch by one instantiation)
+    auto word = [&](int it) { const int k = lane + 64 * it; return ((it + 1) * 64 <= NV / 4 || k < NV / 4) ? k : lane; };
 #pragma unroll
-    for (int it = 0; it < (NV / 4 + 63) / 64; ++it) {
-      const int k = lane + 64 * it;
-      if ((it + 1) * 64 <= NV / 4 || k < NV / 4) store_f4<STREAM>(g4 + k, s4[k]);
-    }
+    for (int it = 0; it < NIT; ++it) t[it] = reinterpret_cast<const v4f_nt*>(s4)[word(it)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) store_v4<STREAM>(reinterpret_cast<v4f_nt*>(g4) + word(it), t[it]);
     __builtin_amdgcn_wave_barrier();
   } else if (nvalid == (64 / K) * D && (nvalid & 3) == 0 && (reinterpret_cast<uintptr_t>(gdst) & 15) == 0) {
     // a full wave of a county count that leaves padding slices (D < DCAP: PA at 8 lanes per chain, the strong-scaling
@@ -301,11 +310,15 @@ ARP_DEV void pk_store_rows(const T& M, float* stage, float* gdst, int cl, int D,
     const float4* s4 = reinterpret_cast<const float4*>(stage);
     float4* g4 = reinterpret_cast<float4*>(gdst);
     const int n4 = nvalid >> 2;
+    constexpr int NIT = (NV / 4 + 63) / 64;
+    v4f_nt t[NIT];
+    // n4 >= 64 here (a full wave's rows): `lane` is always inside the block
+    auto word = [&](int it) { const int k = lane + 64 * it; return k < n4 ? k : lane; };
 #pragma unroll
-    for (int it = 0; it < (NV / 4 + 63) / 64; ++it) {
-      const int k = lane + 64 * it;
-      if (k < n4) store_f4<STREAM>(g4 + k, s4[k]);
-    }
+    for (int it = 0; it < NIT; ++it) t[it] = reinterpret_cast<const v4f_nt*>(s4)[word(it)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) store_v4<STREAM>(reinterpret_cast<v4f_nt*>(g4) + word(it), t[it]);
     __builtin_amdgcn_wave_barrier();
   } else {   // ragged tail of the launch, or an unaligned destination: general offsets, out-of-line copy
     float* row = stage + cl * D;

@@ -153,15 +153,27 @@ def _ess_chain_count(info, model_config, flags):
     return flags.num_chains
 
 
-def _ess_report(info, model_config, flags, dev):
-    """Build-specific keys next to the reference's `ess_min`: which estimator it is and on how many chains, and -- for a
-    streaming run -- the batch-means figure of ALL chains from the in-kernel accumulators.  (A collective when ws > 1:
-    every rank calls it.)"""
+def _ess_report(info, model_config, flags, dev, ess_parts=None):
+    """Build-specific keys next to the reference's `ess_min`: which estimator it is and on how many chains, how many of
+    them never moved after burn-in, and -- for a streaming run -- the batch-means figure of ALL chains from the in-kernel
+    accumulators.  (A collective when ws > 1: every rank calls it.)"""
     if info is None:
         return {}
+    n_const = None
+    if ess_parts is not None:
+        # A chain that accepts nothing after burn-in has a constant recorded series: tfp's estimator gives 0 / 0 = nan and
+        # util.get_min_ess counts the chain as 0.  With a step size frozen at the end of adaptation that happens to a few
+        # chains per thousand in funnel-shaped posteriors (profiles/r05_stuck_chains.txt: the algorithm, not the
+        # arithmetic) -- the summary says so instead of hiding them in the mean.
+        parts = [np.asarray(e) for e in ess_parts]
+        n = parts[0].shape[0] if parts else 0
+        local = sum(bool(any(np.isnan(p[c]).any() for p in parts)) for c in range(n))
+        n_const = int(parallel.all_reduce_sum(float(local), dev).item())
+        if n_const:
+            util.print_("    {} chain(s) never moved after burn-in (constant series: ESS nan, counted as 0 by get_min_ess)".format(n_const))
     # every per-run key is a list with one entry per run (the reference's contract): whole-trace runs append None here
     out = {"ess_estimator": info.estimator, "ess_min_batch_means": None, "sem_min_batch_means": None,
-           "batch_means_batch": None}
+           "batch_means_batch": None, "ess_constant_chains": n_const}
     n_local = int(info.chains)
     out["ess_chains"] = int(parallel.all_reduce_sum(float(n_local), dev).item())
     if info.batch_means is not None:
@@ -235,7 +247,7 @@ def run_hmc(model_config, results_dir, file_path, tuning=False, flags=FLAGS):
         normalized_ess_final, kernel_results.inner_results.is_accepted, flags.num_samples, flags.num_chains, device=dev,
         ess_chains_total=n_ess)
     util.print_("ESS per 1000 gradients: {} +/- {}".format(ess_min, sem_min))
-    extra = _ess_report(info, model_config, flags, dev)
+    extra = _ess_report(info, model_config, flags, dev, normalized_ess_final)
     if ws > 1 and not tuning:
         # _ess.npz / _ess.txt hold every chain's per-element ESS: collect the other ranks' blocks (a collective: all ranks)
         normalized_ess_final = parallel.gather_parts(normalized_ess_final, n_ess, flags.device)
@@ -279,7 +291,7 @@ def run_interleaved_hmc_with_leapfrog_steps(model_config, results_dir, num_leapf
     n_ess = _ess_chain_count(info, model_config, flags)
     ess_min, sem_min, acc_cp, _ = parallel.summarize(normalized_ess_final, is_accepted_cp, flags.num_samples,
                                                      flags.num_chains, device=dev, ess_chains_total=n_ess)
-    extra = _ess_report(info, model_config, flags, dev)
+    extra = _ess_report(info, model_config, flags, dev, normalized_ess_final)
     acc_ncp = float(parallel.all_reduce_sum(float(np.sum(is_accepted_ncp)), dev).item()) * 100.0 / float(
         flags.num_samples * flags.num_chains)
     util.print_("ESS: {} +/- {}".format(ess_min, sem_min))

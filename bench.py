@@ -634,28 +634,34 @@ def main():
         rs_ab = np.random.RandomState(7)
         ab_el = (rs_ab.uniform(0.2, 0.8, es2.D).astype(np.float32), rs_ab.uniform(0.2, 0.8, es2.D).astype(np.float32))
         time_model("election_untied_general_ab_131072", es2, ab_el, 131072, 4, 128, 0.02, 4500.0 + 4.0 * es2.D,
-                   "untied cVIP: a and b free per element (exp(b log sigma) per state and pass); generic kernel, LDS cell tables")
+                   "untied cVIP: a and b free per element (exp(b log sigma) per state and pass); the packed chain layer's "
+                   "general form, pk_hmc_kernel<ElectionPk<4,13>, kModeVIP> (arp_api.hip routes kModeVIP to hmc_vip_pk)")
         pa = models._spec_radon("PA")
         ab_pa = (rs_ab.uniform(0.2, 0.8, pa.D).astype(np.float32), rs_ab.uniform(0.2, 0.8, pa.D).astype(np.float32))
         time_model("radon_PA_general_ab_65536", pa, ab_pa, 65536, 8, 256, 0.02, radon_flop_per_leapfrog(pa.D - 3, pa.D),
-                   "cVIP / dVIP with a free per element (m has unit scale: b is inert); generic float-array kernel against the "
-                   "packed CP kernel's plain_hmc entry above")
+                   "cVIP / dVIP with a free per element (m has unit scale: b is inert); pk_hmc_kernel<RadonPk<4,17>, kModeVIP> "
+                   "against the packed CP kernel's plain_hmc entry above")
         extras["other_models"] = others
 
     # The mean-field VI kernel (find_best_learning_rate, inference.py:26-154): all learning rates x all optimisation steps in
-    # ONE launch, one workgroup per learning rate -- 5 of the 256 CUs, by design (256 Monte-Carlo draws per step, every
-    # step depends on the last: a latency-bound recurrence, not a throughput kernel).  Priced on its gradient evaluations.
+    # ONE launch; every learning rate's 256 draws are spread over a group of workgroups (G sample groups x R row parts of
+    # German credit's observations) that exchange their partial gradient sums twice per step inside the launch (8-byte
+    # {epoch, value} granules, agent-scope atomics, fixed summation order: DESIGN.md section 3).  Every step depends on the
+    # last, so the kernel is LATENCY bound: the figure to read is us_per_optimisation_step; the flop fraction is against
+    # the whole chip and says how little of it a 256-draw gradient can use.
     if secondary:
         try:
             vflags_lrs = [0.02, 0.05, 0.1, 0.2, 0.4]
             n_opt, n_mc = 3000, 256
             vi = {}
-            for tag, vspec, flop in (("radon_PA_CP", spec, radon_flop_per_leapfrog(J, D) - 4.0 * D),
-                                     ("german_NCP", models._spec_german(), 4.0 * 1000 * 62)):
+            e88 = models._spec_election()
+            for tag, vspec, flop, r04_ms in (("radon_PA_CP", spec, radon_flop_per_leapfrog(J, D) - 4.0 * D, 27.9),
+                                             ("german_NCP", models._spec_german(), 4.0 * 1000 * 62, 645.0),
+                                             ("election_NCP", e88, 4500.0, 100.0)):
                 veng = engine.Engine(vspec, dev)
                 veng.set_param(0, "CP" if tag.startswith("radon") else "NCP")
                 times = []
-                for rep in range(2):
+                for rep in range(3):
                     loc = torch.zeros(len(vflags_lrs), vspec.D, device=dev)
                     rho = torch.full((len(vflags_lrs), vspec.D), -2.0, device=dev)
                     torch.cuda.synchronize()
@@ -663,14 +669,22 @@ def main():
                     a_.record(); veng.vi_run(vflags_lrs, loc, rho, n_opt, n_mc, seed=1); b_.record(); torch.cuda.synchronize()
                     times.append(a_.elapsed_time(b_))
                 ms = min(times)
+                geo = veng.vi_geometry()
+                wgs = len(vflags_lrs) * geo["sample_groups"] * geo["row_parts"]
+                per_cu = max(1, geo["workgroups_per_cu"])
                 grads = len(vflags_lrs) * n_opt * n_mc
                 vi[tag] = {"kernel_ms": ms, "learning_rates": len(vflags_lrs), "steps": n_opt, "mc_samples": n_mc,
                            "gradients_per_s": grads / (ms * 1e-3), "us_per_optimisation_step": 1e3 * ms / n_opt,
+                           "round4_one_workgroup_per_learning_rate_ms": r04_ms,
+                           "geometry": geo,
                            "roofline": {"bound": "latency", "achieved": grads * flop / (ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS,
                                         "unit": "TFLOP/s", "frac": grads * flop / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                                        "workgroups": len(vflags_lrs), "cus_used_of_256": len(vflags_lrs),
-                                        "note": "one workgroup per learning rate: each optimisation step is 256 gradients + an "
-                                                "Adam update that the next step depends on; frac is against the whole chip"}}
+                                        "workgroups": wgs,
+                                        # the dispatcher fills empty CUs first: `wgs` workgroups of which a CU holds `per_cu`
+                                        "cus_used_of_256": min(256, wgs) if wgs <= 256 else min(256, (wgs + per_cu - 1) // per_cu),
+                                        "note": "G x R workgroups per learning rate; each optimisation step is 256 gradients, two "
+                                                "in-launch hand-offs of the partial sums and an Adam update the next step depends "
+                                                "on; frac is against the whole chip"}}
                 del veng
             extras["vi_kernel"] = vi
         except Exception as e:

@@ -61,7 +61,10 @@ def batch_means_ess(x, batch):
 
 e_ac = util.effective_sample_size(trace).double()
 stuck = torch.isnan(e_ac).any(dim=1)            # a chain that never moved after burn-in: constant series, ESS 0/0 (as in TFP)
-print("chains with a constant series (ESS = nan, counted as 0 by get_min_ess): %d of %d" % (int(stuck.sum().item()), C))
+print("chains with a constant series (ESS = nan, counted as 0 by get_min_ess): %d of %d -> ids %s" % (
+    int(stuck.sum().item()), C, torch.nonzero(stuck).flatten().tolist()))
+print("   (they never accept after burn-in: the frozen averaged step is too long where they stand -- the algorithm, in float64 too:"
+      " profiles/r05_stuck_chains.txt; ess_min above counts them as 0, the tau / batch-means lines below leave them out)")
 e_ac = e_ac[~stuck]
 trace = trace[:, ~stuck]
 tau_ac = (S / e_ac).mean(dim=0)
