@@ -128,7 +128,7 @@ ARP_DEV void store_row_wave(const Lane& M, float* stage, float* gdst, int cl, in
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int k = k0 + 256 * u;
-        t[u] = *reinterpret_cast<const v4f_nt*>(stage + (k < nvalid ? k : lane * 4));
+        t[u] = *reinterpret_cast<const v4f_nt*>(stage + (k < nvalid ? k : 0));      // (past the block: any word of it, never stored)
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -278,11 +278,11 @@ ARP_DEV void pk_store_rows(const T& M, float* stage, float* gdst, int cl, int D,
     // the same four registers (what the loop compiled to through round 4) is five LDS round trips in a row, each also
     // waiting for the store before it to have taken its data -- 600 - 1 000 cycles per row that the other wave of the
     // SIMD, recording the same step, cannot cover.  The registers are free here: a row is stored between transitions.
-    // (a lane past the block's end re-reads and re-stores its FIRST 16 bytes: the same bytes to the same place, so
-    // neither the reads nor the stores are predicated and nothing branches)
+    // (a lane past the block's end re-reads and re-stores the block's LAST 16 bytes: the same bytes to the same place,
+    // so neither the reads nor the stores are predicated and nothing branches)
     constexpr int NIT = (NV / 4 + 63) / 64;
     v4f_nt t[NIT];      // (a native vector: an array of HIP's float4 structs was left in scratch by one instantiation)
-    auto word = [&](int it) { const int k = lane + 64 * it; return ((it + 1) * 64 <= NV / 4 || k < NV / 4) ? k : lane; };
+    auto word = [&](int it) { const int k = lane + 64 * it; return ((it + 1) * 64 <= NV / 4 || k < NV / 4) ? k : NV / 4 - 1; };
 #pragma unroll
     for (int it = 0; it < NIT; ++it) t[it] = reinterpret_cast<const v4f_nt*>(s4)[word(it)];
     __builtin_amdgcn_sched_barrier(0);
@@ -312,8 +312,7 @@ ARP_DEV void pk_store_rows(const T& M, float* stage, float* gdst, int cl, int D,
     const int n4 = nvalid >> 2;
     constexpr int NIT = (NV / 4 + 63) / 64;
     v4f_nt t[NIT];
-    // n4 >= 64 here (a full wave's rows): `lane` is always inside the block
-    auto word = [&](int it) { const int k = lane + 64 * it; return k < n4 ? k : lane; };
+    auto word = [&](int it) { const int k = lane + 64 * it; return k < n4 ? k : n4 - 1; };      // n4 >= 1 here
 #pragma unroll
     for (int it = 0; it < NIT; ++it) t[it] = reinterpret_cast<const v4f_nt*>(s4)[word(it)];
     __builtin_amdgcn_sched_barrier(0);

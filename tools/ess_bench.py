@@ -2,6 +2,10 @@
 """GPU box: arp_ess on the headline trace (radon PA interleaved, 65 536 chains x 1 000 recorded samples = 18.6 GB) and on
 synthetic AR(1) traces of the same shape whose mixing is known -- how the time splits between the first sweep (every
 series) and the later ones (waves with a slowly mixing series).  One library per process (ARP_LIB_PATH selects a variant)."""
+import os as _os, sys as _sys
+if _os.environ.get('ARP_LIB_PATH') and _os.environ.get("ARP_DEBUG") != "1":
+    # the library honours its experiment switches under ARP_DEBUG=1 only: without it this run would silently measure the default
+    _sys.exit("tools/ess_bench.py: ARP_LIB_PATH is set but ARP_DEBUG=1 is not -- the library would ignore the switch; set ARP_DEBUG=1")
 import os
 import sys
 import time

@@ -2,6 +2,10 @@
 """GPU box: what the in-kernel statistics cost.  Headline radon(PA) interleaved launch and the election plain-HMC launch,
 each with no recording / statistics (thin 2, representative batch) -- run once per value of ARP_STATS_LDS (the library
 reads it at load): 1 = accumulators in LDS (packed kernels), 0 = the plane-per-sample route."""
+import os as _os, sys as _sys
+if _os.environ.get('ARP_STATS_LDS') and _os.environ.get("ARP_DEBUG") != "1":
+    # the library honours its experiment switches under ARP_DEBUG=1 only: without it this run would silently measure the default
+    _sys.exit("tools/stats_cost.py: ARP_STATS_LDS is set but ARP_DEBUG=1 is not -- the library would ignore the switch; set ARP_DEBUG=1")
 import os
 import sys
 import time
