@@ -73,7 +73,7 @@ class ViIO(C.Structure):
 
 # every symbol include/autoreparam.h declares
 SYMBOLS = ["arp_version", "arp_last_error", "arp_model_create", "arp_model_destroy", "arp_model_dim",
-           "arp_model_logp_const", "arp_model_set_param", "arp_logp_grad", "arp_transform",
+           "arp_model_logp_const", "arp_model_set_param", "arp_model_set_option", "arp_logp_grad", "arp_transform",
            "arp_hmc_run", "arp_interleaved_run", "arp_vi_run", "arp_vi_geometry", "arp_ess", "arp_ess_ws", "arp_ess_workspace_bytes",
            "arp_adapt_probe", "arp_clock_probe"]
 
@@ -98,6 +98,7 @@ def lib():
     L.arp_model_logp_const.argtypes = [C.c_void_p, C.c_int]
     L.arp_model_logp_const.restype = C.c_double
     L.arp_model_set_param.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p]
+    L.arp_model_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
     L.arp_logp_grad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_int, C.c_void_p]
     L.arp_transform.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]

@@ -265,10 +265,61 @@ static int build_german(arp_model* m, const arp_dataset* d) {
       img[32 * 256 + r] = d->y_host[n];
     }
   }
+  // the bf16 x 3 image (model_german.h): usable when at most 8 columns are not exact in ONE bf16 piece
+  const size_t f32_floats = m->host_tables.size();
+  std::vector<int> split;
+  for (int f = 0; f < F; ++f) {
+    bool exact = true;
+    for (int n = 0; n < N && exact; ++n) {
+      uint32_t h, mm_, l;
+      bf3_split(d->X_host[(size_t)n * F + f], h, mm_, l);
+      exact = mm_ == 0u && l == 0u;
+    }
+    if (!exact) split.push_back(f);
+  }
+  const bool bf3 = (int)split.size() <= kBf3MaxSplit;
+  const int ntb = (N + kBf3Rows - 1) / kBf3Rows;
+  for (int q = 0; q < kBf3MaxSplit; ++q) m->german.sidx[q] = bf3 && q < (int)split.size() ? split[q] : -1;
+  if (bf3) {
+    m->host_tables.resize(f32_floats + (size_t)ntb * kBf3ImgTile, 0.0f);
+    auto put = [](unsigned char* img, size_t byte_off, uint32_t bits) {      // the bf16 = high half of the f32 pattern
+      img[byte_off] = (unsigned char)(bits >> 16); img[byte_off + 1] = (unsigned char)(bits >> 24);
+    };
+    for (int t = 0; t < ntb; ++t) {
+      unsigned char* img = reinterpret_cast<unsigned char*>(m->host_tables.data() + f32_floats + (size_t)t * kBf3ImgTile);
+      for (int r = 0; r < kBf3Rows; ++r) {
+        const int n = t * kBf3Rows + r;
+        if (n >= N) break;
+        // where observation r sits in a backward fragment: k-step s, lane group g, element jj
+        const int s_ = r >> 5, rr = r & 31;
+        const int g = rr < 16 ? rr >> 2 : (rr - 16) >> 2, jj = rr < 16 ? rr & 3 : 4 + ((rr - 16) & 3);
+        for (int f = 0; f < F; ++f) {
+          uint32_t h, mm_, l;
+          bf3_split(d->X_host[(size_t)n * F + f], h, mm_, l);
+          put(img, kBf3XhF + (size_t)r * 128 + ((((size_t)f >> 3) ^ (((size_t)r >> 1) & 7)) << 4) + (f & 7) * 2, h);
+          put(img, kBf3XhB + (size_t)s_ * 4096 + (size_t)f * 64 + (((size_t)g ^ (((size_t)f >> 2) & 3)) << 4) + jj * 2, h);
+        }
+        for (int q = 0; q < (int)split.size(); ++q) {
+          uint32_t h, mm_, l;
+          bf3_split(d->X_host[(size_t)n * F + split[q]], h, mm_, l);
+          const size_t rowb = kBf3XaF + (size_t)r * 64, sw = ((size_t)r >> 2) & 3;
+          put(img, rowb + ((0 ^ sw) << 4) + q * 2, mm_);       // [xm | xm | xl | 0]
+          put(img, rowb + ((1 ^ sw) << 4) + q * 2, mm_);
+          put(img, rowb + ((2 ^ sw) << 4) + q * 2, l);
+          for (int part = 0; part < 2; ++part) {                // output rows q (xm) and 8 + q (xl)
+            const size_t o = (size_t)part * 8 + q;
+            put(img, kBf3XaB + (size_t)s_ * 1024 + o * 64 + (((size_t)g ^ ((o >> 2) & 3)) << 4) + jj * 2, part ? l : mm_);
+          }
+        }
+        reinterpret_cast<float*>(img + kBf3Y)[r] = d->y_host[n];
+      }
+    }
+  }
   if (upload_tables(m)) return 1;
   m->german.X = m->dev_tables;
   m->german.y = m->dev_tables + (size_t)N * kGermanCols;
   m->german.Xt = m->dev_tables + plain;
+  m->german.Xb = bf3 ? m->dev_tables + f32_floats : nullptr;
   m->german.N = N; m->german.F = F;
   m->const_base = -(1.0 + 2.0 * F) * kHalfLog2Pi;
   m->top_scale = {{0, log(10.0)}};
@@ -441,6 +492,22 @@ int arp_model_destroy(arp_model* m) {
 
 int arp_model_dim(const arp_model* m) { return m ? m->D : -1; }
 
+int arp_model_set_option(arp_model* m, const char* key, const char* value) {
+  if (!m || !key || !value) { set_error("arp_model_set_option: null argument"); return 1; }
+  if (!strcmp(key, "german_math")) {
+    if (m->model != ARP_MODEL_GERMAN_CREDIT) { set_error("arp_model_set_option: german_math applies to german credit only"); return 1; }
+    if (!strcmp(value, "auto")) m->german_math = 0;
+    else if (!strcmp(value, "f32")) m->german_math = 1;
+    else if (!strcmp(value, "bf16x3")) {
+      if (!m->german.Xb) { set_error("arp_model_set_option: this design matrix has more than 8 columns that need three bf16 pieces"); return 1; }
+      m->german_math = 2;
+    } else { set_error("arp_model_set_option: german_math is one of auto, f32, bf16x3"); return 1; }
+    return 0;
+  }
+  set_error("arp_model_set_option: unknown key");
+  return 1;
+}
+
 double arp_model_logp_const(const arp_model* m, int which) {
   return (m && which >= 0 && which < 2) ? m->logp_const[which] : NAN;
 }
@@ -484,6 +551,9 @@ static const LaneOps* select_ops(arp_model* m, int K_req, int C) {
   // time_series likewise: 4 lanes per chain (one wave per SIMD at 16 384 chains) beat 8 and 16 in every form wherever
   // they fill the SIMDs once (round 3 sweep, profiles/r03_time_series_sweep.txt)
   const long long fill = (m->model == ARP_MODEL_RADON || m->model == ARP_MODEL_TIME_SERIES) ? 65536 : 131072;
+  // German credit at 4 lanes per chain: the likelihood on bf16 matrix cores with three-piece operands where the data
+  // allow it (model_german.h), unless the caller asked for the f32 matrix-core form (arp_model_set_option)
+  if (m->model == ARP_MODEL_GERMAN_CREDIT && K_req == 4 && m->german.Xb && m->german_math != 1) return &german_bf3_ops();
   const LaneOps* o = pick(*fam, m->n_groups, K_req, C, m->model != ARP_MODEL_GERMAN_CREDIT, fill,
                           m->model == ARP_MODEL_TIME_SERIES ? 2 : 1);
   if (!o) set_error("no kernel instantiation for this (lanes_per_chain, group count): add <Model>Lane<K, ceil(groups/K)> to the model's inst_*.hip");

@@ -234,6 +234,7 @@ const std::vector<LaneOps>& radon_ops();
 const std::vector<LaneOps>& schools_ops();
 const std::vector<LaneOps>& election_ops();
 const std::vector<LaneOps>& german_ops();
+const LaneOps& german_bf3_ops();   // 4 lanes per chain, likelihood on bf16 matrix cores with three-piece operands
 const std::vector<LaneOps>& radon_sd_ops();
 const std::vector<LaneOps>& funnel_ops();
 const std::vector<LaneOps>& electric_ops();
@@ -245,7 +246,8 @@ struct arp_model {
   int model = -1;
   int D = 0;
   int device = 0;
-  bool host_only = false;    // test hook (arp_api.hip: host_only): no device behind this handle
+  bool host_only = false;
+  int german_math = 0;       // 0 auto (bf16 x 3 where the data allow), 1 f32 matrix cores, 2 bf16 x 3 (arp_model_set_option)    // test hook (arp_api.hip: host_only): no device behind this handle
   int n_groups = 0;          // slice axis length (radon J, election 52, schools 8)
   float* dev_tables = nullptr;   // one allocation holding all frozen tables
   float* dev_ab[2] = {nullptr, nullptr};  // [2][D]: a then b, per parameterisation

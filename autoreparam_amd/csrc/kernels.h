@@ -629,7 +629,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
   ARP_T(8, tk);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     unsigned long long* t = exp_t();
-    printf("TIMING total %llu | pre %llu bar %llu start %llu tiles %llu vx %llu post %llu | lik %llu\n", t[8], t[0], t[1], t[2], t[3], t[4], t[5], t[7]);
+    printf("TIMING total %llu | pre %llu bar %llu start %llu tiles %llu vx %llu post %llu | lik %llu | 9:%llu 10:%llu 11:%llu 12:%llu 13:%llu 14:%llu\n", t[8], t[0], t[1], t[2], t[3], t[4], t[5], t[7], t[9], t[10], t[11], t[12], t[13], t[14]);
   }
 #endif
   // recompute the per-lane row addresses here instead of keeping 64-bit pointers alive (in VGPR

@@ -37,11 +37,47 @@ constexpr int kGermanViBlock = ARP_GERMAN_VI_BLOCK;   // threads of a VI workgro
 //   68 ms per fit against 80 ms with two-wave workgroups of two tiles (profiles/r05_vi_kernel.txt)
 constexpr int kGermanImgTile = 33 * 256;   // floats per tile of the image
 
+// Tile image of the bf16 x 3 likelihood (round 5; built by arp_api.hip: build_german_bf3).  Every f32 value is the exact
+// sum of three bf16 pieces x = h + m + l (8 + 8 + 8 significant bits, by truncation), and a product of two such values is
+// the sum of nine bf16 products, of which the six leading ones carry it to 2^-23: matrix-core work at 16 x the f32 rate.
+// The data make it cheaper still: a column of zeros and ones (54 one-hot columns and the intercept of German credit) IS
+// its h piece, so only the few SPLIT columns (the standardised numerics: at most 8) have m and l pieces at all, and all
+// their cross terms fit ONE extra K = 32 step per product:
+//   forward   eta = Xh (bh + bm + bl)  +  [Xm | Xm | Xl | 0] [bh ; bm ; bh ; 0]          (split columns only)
+//   backward  v   = Xh' (wh + wm + wl) +  [Xm ; Xl]' wh + [Xm ; Xl]' wm                   (16 extra output rows)
+// i.e. 7 v_mfma_f32_16x16x32_bf16 per 16 observations forward and 14 per 32 backward (224 cycles per 32 observations
+// against 2 048 on v_mfma_f32_16x16x4_f32), operands read from LDS with 11 ds_read_b128 per 32 observations and wave.
+// A tile holds 64 observations in 23 pieces of 1 KiB (the exact byte image of its LDS copy, moved by LDS-DMA):
+//   XhF [64 rows][64 features] bf16, 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7)           8 KiB  forward A operand
+//   XaF [64 rows][xm(8) | xm(8) | xl(8) | 0(8)] bf16, chunk g of row r at g ^ ((r >> 2) & 3)        4 KiB
+//   XhB [2 k-steps][64 features][4 lane groups g][8] bf16: element j of group g is observation
+//       32 s + (j < 4 ? 4 g + j : 16 + 4 g + j - 4) -- the order in which two forward blocks leave their residuals in a
+//       lane's registers --, chunk g of feature f at g ^ ((f >> 2) & 3)                             8 KiB  backward A operand
+//   XaB [2 k-steps][16 rows: xm of split column o, xl of split column o - 8][4][8] bf16, same order  2 KiB
+//   y   [64] f32                                                                                   256 B
+// (both operand reads are conflict free: 16 lanes x 16 bytes cover the 64 banks once).
+constexpr int kBf3Rows = 64;
+constexpr int kBf3Pieces = 23;
+constexpr int kBf3ImgTile = kBf3Pieces * 256;   // floats per tile of the image
+constexpr int kBf3XhF = 0, kBf3XaF = 8192, kBf3XhB = 12288, kBf3XaB = 20480, kBf3Y = 22528;   // byte offsets in a tile
+constexpr int kBf3MaxSplit = 8;
+
+// x = h + m + l exactly, each piece a bf16 (as the f32 bit pattern with a zero low half): truncation twice, the third
+// piece is what is left (at most 8 significant bits).  The same on host (the images) and device (beta, the residuals).
+__host__ __device__ inline void bf3_split(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+  union { float f; uint32_t u; } a, b_, c_;
+  a.f = x; h = a.u & 0xffff0000u;
+  b_.u = h; b_.f = x - b_.f; m = b_.u & 0xffff0000u;
+  c_.u = m; c_.f = b_.f - c_.f; l = c_.u;
+}
+
 struct GermanArgs {
   const float* X;   // [N][64] row-major, columns >= F are zero
   const float* y;   // [N]
   const float* Xt;  // tile image, ceil(N / 128) x kGermanImgTile floats
   int N, F;
+  const float* Xb;  // bf16 x 3 tile image, ceil(N / 64) x kBf3ImgTile floats, or nullptr (more than 8 split columns)
+  int sidx[kBf3MaxSplit];   // the split columns (-1: unused slot)
 };
 
 // W_: waves per workgroup of the kernels the lane is used in (sizes the per-wave LDS areas of the
@@ -50,8 +86,10 @@ struct GermanArgs {
 // workgroups of a learning rate: a lane evaluates the tiles [tlo, thi) only and the prior terms of the log density and of
 // the gradient with weight `pw` (1 in the workgroup that owns row part 0, 0 elsewhere), so that the SUM over the row
 // parts of everything grad() and dparam() return is the whole model's -- they are affine in the likelihood's v.
-template <int K_, int NLS_, int W_ = kBlock / 64, bool PART_ = false>
+// BF3_: the likelihood on bf16 matrix cores with three-piece operands (above) instead of f32 matrix cores; K = 4 only.
+template <int K_, int NLS_, int W_ = kBlock / 64, bool PART_ = false, bool BF3_ = false>
 struct GermanLane {
+  static_assert(!BF3_ || (K_ == 4 && !PART_), "the bf16 x 3 likelihood serves the 4-lane chain kernels");
   static constexpr int K = K_;
   static constexpr int NG = 1;          // overall_log_scale
   static constexpr int NLS = NLS_;      // features owned by this lane: d = slot*NLS + i
@@ -68,8 +106,9 @@ struct GermanLane {
 
   float a[NLS], b[NLS];     // a of bls_d, b of beta_d (the only ones that matter)
   float s0i, c0;            // 1/10^b0, 10^(1-b0)
-  const float* X; const float* y; const float* Xt;
+  const float* X; const float* y; const float* Xt; const float* Xb;
   int N, F, slot, nown;
+  int sidx[BF3_ ? kBf3MaxSplit : 1];
   int tlo_, thi_; float pw_;   // PART_ only: tile range and prior weight of this workgroup's row part
   bool res_;                   // PART_ only: the part's (at most two) tiles stay in the LDS buffers for the whole launch
   static constexpr bool HAS_PART = PART_;
@@ -107,7 +146,11 @@ struct GermanLane {
 
   ARP_DEV void init(const Args& A, const float* av, const float* bv, int slot_) {
     slot = slot_;
-    X = A.X; y = A.y; Xt = A.Xt; N = A.N; F = A.F;
+    X = A.X; y = A.y; Xt = A.Xt; Xb = A.Xb; N = A.N; F = A.F;
+    if constexpr (BF3_) {
+#pragma unroll
+      for (int q = 0; q < kBf3MaxSplit; ++q) sidx[q] = A.sidx[q];
+    }
     nown = F - slot * NLS;
     nown = nown < 0 ? 0 : (nown > NLS ? NLS : nown);
     tlo_ = 0; thi_ = (N + kGermanTileRows - 1) / kGermanTileRows; pw_ = 1.0f; res_ = false;
@@ -405,7 +448,11 @@ struct GermanLane {
   //   log2 of the Bernoulli term  y eta - softplus(eta)  =  log2(rc) - y z + min(z, 0)
   // accumulated in log2 units in two packed accumulators (lp2; scaled by ln 2 once per gradient).  MASK: the tile ends
   // inside the block range (last tile of the data set), rows >= `rows` are padding and must not count.
-  template <bool LOGP, bool MASK>
+  // ASM_MIN = false (the bf16 x 3 path): min(z, 0) as a compiler-visible v_med3_f32.  The inline-asm v_min_f32 reads the
+  // matrix-core result directly, and the hazard recogniser pads nothing in front of an asm statement: scheduled right
+  // behind a v_mfma_f32_16x16x32_bf16 it read the accumulator's OLD contents in the lanes written last (seen as a log
+  // density that was wrong in lanes 0 - 15 only and right again as soon as a printf moved the code).
+  template <bool LOGP, bool MASK, bool ASM_MIN = true>
   static ARP_DEV void residuals(const v4f& z, const v4f& yv, int row, int rows, float (&w)[4], v2f (&lp2)[2]) {
     float ex[4], rc[4];
     const v2f one = v2f{1.0f, 1.0f};
@@ -419,8 +466,10 @@ struct GermanLane {
 #pragma unroll
       for (int r_ = 0; r_ < 4; ++r_) lg[r_] = __builtin_amdgcn_logf(rc[r_]);   // log2(1 / (1 + ex)) = -log2(1 + ex)
 #pragma unroll
-      for (int r_ = 0; r_ < 4; ++r_)   // min(z, 0); fminf() would add a v_max to quiet NaNs first
-        asm("v_min_f32 %0, 0, %1" : "=v"(mz[r_]) : "v"(z[r_]));
+      for (int r_ = 0; r_ < 4; ++r_) {  // min(z, 0); fminf() would add a v_max to quiet NaNs first
+        if constexpr (ASM_MIN) asm("v_min_f32 %0, 0, %1" : "=v"(mz[r_]) : "v"(z[r_]));
+        else mz[r_] = __builtin_amdgcn_fmed3f(z[r_], 0.0f, -3.4028234663852886e38f);
+      }
       const v2f y01 = v2f{yv[0], yv[1]}, y23 = v2f{yv[2], yv[3]};
       v2f t01 = vfma(-y01, v2f{z[0], z[1]}, v2f{mz[0], mz[1]}) + v2f{lg[0], lg[1]};
       v2f t23 = vfma(-y23, v2f{z[2], z[3]}, v2f{mz[2], mz[3]}) + v2f{lg[2], lg[3]};
@@ -552,6 +601,12 @@ struct GermanLane {
   // longer in use by any wave after the barrier; tile 0 then travels while the prior part of the gradient is computed.
   ARP_DEV void first_tile() const {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if constexpr (BF3_) {
+      const int ntb = (N + kBf3Rows - 1) / kBf3Rows;
+      __syncthreads();
+      issue_tile_bf3(0, ntb & 1, lds_offset(tile_mem()), wv, threadIdx.x & 63);
+      return;
+    }
     const int nt = thi() - tlo();
     if (resident()) return;
     __syncthreads();
@@ -684,6 +739,311 @@ struct GermanLane {
     return lp;
   }
 
+  // ---- the bf16 x 3 likelihood (see the tile image at the top of the file) ----
+  typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+  typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+  // this wave's share of tile n of the bf16 image into buffer `buf`: pieces wv, wv + W, ...
+  ARP_DEV void issue_tile_bf3(int n, int buf, uint32_t tile_off, int wv, int lane) const {
+    const float* src = Xb + (size_t)n * kBf3ImgTile;
+    const uint32_t dst = tile_off + (uint32_t)buf * kBufStep;
+    const uint32_t voff = (uint32_t)lane * 16u;
+#pragma unroll
+    for (int p = 0; p < (kBf3Pieces + W_ - 1) / W_; ++p) {
+      const int piece = wv + p * W_;
+      if (piece < kBf3Pieces) glds16(src + piece * 256, voff, dst + (uint32_t)piece * 1024u);
+    }
+  }
+  // two bf16 (the high halves of two f32 bit patterns) in one register: element 2k low, 2k + 1 high
+  static ARP_DEV uint32_t bf_pack(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+  // eight f32 values -> their three bf16 fragments
+  static ARP_DEV void bf3_frags(const float (&x)[8], bf8 (&f)[3]) {
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bf3_split(x[i], h[i], m[i], l[i]);
+    u4v fh, fm, fl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { fh[i] = bf_pack(h[2 * i], h[2 * i + 1]); fm[i] = bf_pack(m[2 * i], m[2 * i + 1]); fl[i] = bf_pack(l[2 * i], l[2 * i + 1]); }
+    f[0] = __builtin_bit_cast(bf8, fh); f[1] = __builtin_bit_cast(bf8, fm); f[2] = __builtin_bit_cast(bf8, fl);
+  }
+  // operand fragments travel as four dwords; the LDS reads are inline asm (they stay where they are written) and every
+  // use is tied to the wait that completes them (frag_wait: the compiler sees no other dependency between the two)
+  static ARP_DEV u4v lds_frag(uint32_t addr) {
+    u4v r;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+  }
+  static ARP_DEV void frag_wait(u4v& a, u4v& b, u4v& c, u4v& d, u4v& e) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+  }
+  static ARP_DEV void frag_wait(u4v& a, u4v& b, u4v& c, u4v& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  }
+  static ARP_DEV v4f mm(u4v a, bf8 b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), b, c, 0, 0, 0);
+  }
+
+  template <bool LOGP>
+  ARP_DEV float likelihood_bf3(const float (&beta)[NLS], float (&v)[NLS]) const {
+    static_assert(NLS == 16, "K = 4 owns 16 features per lane");
+    float* tile = tile_mem();
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* xch = tile + kXchBase + wv * kXch;
+    float* lpx = xch + 16 * kXchStride;
+    const int c = lane >> 2, t = lane & 3;    // state layout (t == slot)
+    const int g = lane >> 4, j = lane & 15;   // matrix-core layout: lane group g, row / chain j
+    const uint32_t tile_off = lds_offset(tile);
+    const int nt = (N + kBf3Rows - 1) / kBf3Rows;
+    int buf = nt & 1;
+    ARP_T0(tt);
+
+    // beta, scaled by -log2 e, from the state layout to [chain][feature] in the wave's exchange area ...
+    float4* own = reinterpret_cast<float4*>(xch + c * kXchStride + 16 * t);
+    constexpr float kNegLog2e = -1.4426950408889634f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      own[i] = make_float4(kNegLog2e * beta[4 * i], kNegLog2e * beta[4 * i + 1], kNegLog2e * beta[4 * i + 2],
+                           kNegLog2e * beta[4 * i + 3]);
+    __builtin_amdgcn_wave_barrier();
+    // ... and from there into the B fragments of the forward product: pieces h, m, l of features 32 kh + 8 g .. + 7 of
+    // chain j, and the split columns' [bh ; bm ; bh ; 0] for the extra K = 32 step
+    bf8 Bb[2][3], Bba;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const float4* src = reinterpret_cast<const float4*>(xch + j * kXchStride + 32 * kh + 8 * g);
+      const float4 f0 = src[0], f1 = src[1];
+      const float x8[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+      bf3_frags(x8, Bb[kh]);
+    }
+    {
+      float x8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x8[q] = sidx[q] >= 0 ? xch[j * kXchStride + sidx[q]] : 0.0f;
+      bf8 f3[3];
+      bf3_frags(x8, f3);
+      const u4v z4 = u4v{0u, 0u, 0u, 0u};
+      Bba = g == 1 ? f3[1] : (g == 3 ? __builtin_bit_cast(bf8, z4) : f3[0]);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    ARP_T(1, tt);
+    v4f acc[4], accA;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    accA = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    v2f lp2[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
+    // operand addresses relative to the buffer: row / feature / output row j, chunk g (XOR-permuted per row)
+    const uint32_t uj = (uint32_t)j, ug = (uint32_t)g;
+    const uint32_t a_h0 = kBf3XhF + uj * 128u + (((ug) ^ ((uj >> 1) & 7u)) << 4);          // kh = 0: chunk g
+    const uint32_t a_h1 = kBf3XhF + uj * 128u + (((4u + ug) ^ ((uj >> 1) & 7u)) << 4);     // kh = 1: chunk 4 + g
+    const uint32_t a_a = kBf3XaF + uj * 64u + ((ug ^ ((uj >> 2) & 3u)) << 4);
+    const uint32_t b_h = kBf3XhB + uj * 64u + ((ug ^ ((uj >> 2) & 3u)) << 4);              // + fb * 1024 + s * 4096
+    const uint32_t b_a = kBf3XaB + uj * 64u + ((ug ^ ((uj >> 2) & 3u)) << 4);              // + s * 1024
+    const uint32_t y_o = kBf3Y + ug * 16u;                                                 // + block * 64
+
+    // The pipeline over the 64-observation tiles.  Per tile: the 16 forward reads (three fragments and the outcomes of
+    // each of the four 16-observation blocks) were issued while the previous tile's last matrix-core instructions ran;
+    // the 10 backward reads go out first thing and land under the forward products.  Forward = 4 x 7 matrix-core
+    // instructions, each block's residuals (vector pipe: two transcendentals per observation) free to run beside the
+    // next block's products; backward = 2 x 14, the second k-step's after the hand-over so that they cover the latency of
+    // the next tile's forward reads.  ONE workgroup barrier per tile, at the hand-over: every LDS read of the tile has
+    // landed by then (the operands were waited for), so the barrier frees its buffer for tile n + 2 and publishes n + 1.
+    u4v F[4][3], Y[4], Bk[2][5];
+    // operand reads: one address register per operand kind (buffer base + the lane's part), the block / k-step / feature
+    // block as the instruction's immediate offset
+    auto rd = [](u4v& dst, uint32_t addr, auto off_tag) {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(off_tag)::value));
+    };
+#define ARP_OFF(x) std::integral_constant<int, (x)>{}
+    auto fwd_reads = [&](uint32_t base) {
+      const uint32_t p0 = base + a_h0, p1 = base + a_h1, pa = base + a_a, py = base + y_o;
+      rd(F[0][0], p0, ARP_OFF(0)); rd(F[0][1], p1, ARP_OFF(0)); rd(F[0][2], pa, ARP_OFF(0)); rd(Y[0], py, ARP_OFF(0));
+      rd(F[1][0], p0, ARP_OFF(2048)); rd(F[1][1], p1, ARP_OFF(2048)); rd(F[1][2], pa, ARP_OFF(1024)); rd(Y[1], py, ARP_OFF(64));
+      rd(F[2][0], p0, ARP_OFF(4096)); rd(F[2][1], p1, ARP_OFF(4096)); rd(F[2][2], pa, ARP_OFF(2048)); rd(Y[2], py, ARP_OFF(128));
+      rd(F[3][0], p0, ARP_OFF(6144)); rd(F[3][1], p1, ARP_OFF(6144)); rd(F[3][2], pa, ARP_OFF(3072)); rd(Y[3], py, ARP_OFF(192));
+    };
+    auto bwd_reads = [&](uint32_t base) {
+      const uint32_t ph = base + b_h, pa = base + b_a;
+      rd(Bk[0][0], ph, ARP_OFF(0)); rd(Bk[0][1], ph, ARP_OFF(1024)); rd(Bk[0][2], ph, ARP_OFF(2048)); rd(Bk[0][3], ph, ARP_OFF(3072));
+      rd(Bk[0][4], pa, ARP_OFF(0));
+      rd(Bk[1][0], ph, ARP_OFF(4096)); rd(Bk[1][1], ph, ARP_OFF(5120)); rd(Bk[1][2], ph, ARP_OFF(6144)); rd(Bk[1][3], ph, ARP_OFF(7168));
+      rd(Bk[1][4], pa, ARP_OFF(1024));
+    };
+#undef ARP_OFF
+    // product i (0 .. 6) of forward block b: X_h's two halves against beta's three pieces, then the split columns' step
+    auto fmm = [&](int b, int i, v4f e) {
+      return i < 6 ? mm(F[b][i & 1], Bb[i & 1][i >> 1], e) : mm(F[b][2], Bba, e);
+    };
+    // product i (0 .. 13) of backward k-step s_: four feature blocks against the residuals' three pieces, then the split
+    // columns' 16 extra rows against the two leading pieces
+    auto bmm = [&](int s_, int i, const bf8 (&Bw)[3]) {
+      if (i < 12) acc[i / 3] = mm(Bk[s_][i / 3], Bw[i % 3], acc[i / 3]);
+      else accA = mm(Bk[s_][4], Bw[i - 12], accA);
+    };
+    // residuals of a block WITHOUT the log density, in six stages of two vector instructions each (they ride in the
+    // shadows of the next block's products): y - 1 / (1 + 2^z) for the lane's four observations
+    struct Res { float ex[4], rc[4]; v2f d01, d23; };
+    auto res_stage = [&](int k, Res& R, const v4f& z, const v4f& yv, float (&wo)[4]) {
+      const v2f one = v2f{1.0f, 1.0f};
+      if (k == 0) { R.ex[0] = __builtin_amdgcn_exp2f(z[0]); R.ex[1] = __builtin_amdgcn_exp2f(z[1]); }
+      if (k == 1) { R.ex[2] = __builtin_amdgcn_exp2f(z[2]); R.ex[3] = __builtin_amdgcn_exp2f(z[3]); }
+      if (k == 2) { R.d01 = v2f{R.ex[0], R.ex[1]} + one; R.d23 = v2f{R.ex[2], R.ex[3]} + one; }
+      if (k == 3) { R.rc[0] = __builtin_amdgcn_rcpf(R.d01[0]); R.rc[1] = __builtin_amdgcn_rcpf(R.d01[1]); }
+      if (k == 4) { R.rc[2] = __builtin_amdgcn_rcpf(R.d23[0]); R.rc[3] = __builtin_amdgcn_rcpf(R.d23[1]); }
+      if (k == 5) {
+        const v2f w01 = v2f{yv[0], yv[1]} - v2f{R.rc[0], R.rc[1]}, w23 = v2f{yv[2], yv[3]} - v2f{R.rc[2], R.rc[3]};
+        wo[0] = w01[0]; wo[1] = w01[1]; wo[2] = w23[0]; wo[3] = w23[1];
+      }
+    };
+#define ARP_OFF(x) std::integral_constant<int, (x)>{}
+    // the backward operand reads of the current tile, one per slot (issued beside the forward products)
+    auto bwd_read_slot = [&](int k, uint32_t base) {
+      const uint32_t ph = base + b_h, pa = base + b_a;
+      if (k == 0) rd(Bk[0][0], ph, ARP_OFF(0));
+      if (k == 1) rd(Bk[0][1], ph, ARP_OFF(1024));
+      if (k == 2) rd(Bk[0][2], ph, ARP_OFF(2048));
+      if (k == 3) rd(Bk[0][3], ph, ARP_OFF(3072));
+      if (k == 4) rd(Bk[0][4], pa, ARP_OFF(0));
+      if (k == 5) rd(Bk[1][0], ph, ARP_OFF(4096));
+      if (k == 6) rd(Bk[1][1], ph, ARP_OFF(5120));
+      if (k == 7) rd(Bk[1][2], ph, ARP_OFF(6144));
+      if (k == 8) rd(Bk[1][3], ph, ARP_OFF(7168));
+      if (k == 9) rd(Bk[1][4], pa, ARP_OFF(1024));
+    };
+#undef ARP_OFF
+
+    // tile 0 has landed everywhere; tile 1 into the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nt > 1) issue_tile_bf3(1, buf ^ 1, tile_off, wv, lane);
+    fwd_reads(tile_off + (uint32_t)buf * kBufStep);
+    ARP_T(2, tt);
+
+    // The tile loop, written slot by slot: every matrix-core instruction is followed by the one or two other
+    // instructions that ride in its shadow (it holds vector issue for 8 of its 16 cycles; LDS reads and LDS-DMA issue
+    // beside it), and a scheduling barrier keeps the slot together -- left to itself the scheduler issues all 28
+    // products of a phase back to back and the vector work, the 26 operand reads and the six LDS-DMA pieces (60 - 100
+    // cycles of issue each) behind them: 2 800 cycles per tile against 900 of matrix-core time.
+    //   forward : 4 blocks x 7 products; slots carry the 10 backward reads of this tile and the previous block's residuals
+    //   hand-over: this tile's reads are complete, the next tile has landed: ONE barrier
+    //   backward: 2 k-steps x 14 products; slots carry the LDS-DMA of tile n + 2, the second k-step's split and the 16
+    //             forward reads of tile n + 1
+    for (int n = 0; n < nt; ++n) {
+      const int rows = min(kBf3Rows, N - n * kBf3Rows);
+      const uint32_t base = tile_off + (uint32_t)buf * kBufStep;
+      ARP_T(3, tt);
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[0][2]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[1][2]), "+v"(F[2][0]),
+                     "+v"(F[2][1]), "+v"(F[2][2]), "+v"(F[3][0]), "+v"(F[3][1]), "+v"(F[3][2]), "+v"(Y[0]), "+v"(Y[1]),
+                     "+v"(Y[2]), "+v"(Y[3]));
+      ARP_T(9, tt);
+      float w[4][4];
+      if constexpr (LOGP) {
+        // the closing pass of a trajectory (one gradient in L): the log density's extra vector work is left to the scheduler
+        bwd_reads(base);
+        auto forward = [&](auto mask_tag) {
+          constexpr bool MASK = decltype(mask_tag)::value;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            v4f e = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < 7; ++i) e = fmm(b, i, e);
+            residuals<LOGP, MASK, false>(e, __builtin_bit_cast(v4f, Y[b]), 16 * b + 4 * g, rows, w[b], lp2);
+          }
+        };
+        if (rows == kBf3Rows) forward(std::false_type{});
+        else forward(std::true_type{});
+      } else {
+        v4f e[4];
+        Res R;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          e[b] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int i = 0; i < 7; ++i) {
+            e[b] = fmm(b, i, e[b]);
+            if (b < 2 && i < 5) bwd_read_slot(5 * b + i, base);
+            if (b > 0 && i < 6) res_stage(i, R, e[b - 1], __builtin_bit_cast(v4f, Y[b - 1]), w[b - 1]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) res_stage(i, R, e[3], __builtin_bit_cast(v4f, Y[3]), w[3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(w[b][0]), "+v"(w[b][1]), "+v"(w[b][2]), "+v"(w[b][3]));
+      ARP_T(10, tt);
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(Bk[0][0]), "+v"(Bk[0][1]), "+v"(Bk[0][2]), "+v"(Bk[0][3]), "+v"(Bk[0][4]), "+v"(Bk[1][0]),
+                     "+v"(Bk[1][1]), "+v"(Bk[1][2]), "+v"(Bk[1][3]), "+v"(Bk[1][4]));
+      ARP_T(11, tt);
+      if (n + 1 < nt) {
+        // Hand-over, between the two products: every LDS read of tile n has landed (all its operands are in registers)
+        // and this wave's share of tile n + 1 too; after the barrier tile n + 1 is complete for every wave and tile n's
+        // buffer is free for tile n + 2.  The next tile's forward reads go out at once and land under the backward product.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (n + 2 < nt) issue_tile_bf3(n + 2, buf, tile_off, wv, lane);
+        buf ^= 1;
+        fwd_reads(tile_off + (uint32_t)buf * kBufStep);
+      }
+      // backward: a lane's eight residuals of blocks 2 s and 2 s + 1 are its B fragment of k-step s; the second k-step's
+      // split rides in the shadows of the first one's products (scheduling groups below)
+      bf8 Bw0[3], Bw1[3];
+      {
+        const float x0[8] = {w[0][0], w[0][1], w[0][2], w[0][3], w[1][0], w[1][1], w[1][2], w[1][3]};
+        bf3_frags(x0, Bw0);
+      }
+#pragma unroll
+      for (int i = 0; i < 14; ++i) bmm(0, i, Bw0);
+      {
+        const float x1[8] = {w[2][0], w[2][1], w[2][2], w[2][3], w[3][0], w[3][1], w[3][2], w[3][3]};
+        bf3_frags(x1, Bw1);
+      }
+#pragma unroll
+      for (int i = 0; i < 14; ++i) bmm(1, i, Bw1);
+      __builtin_amdgcn_sched_group_barrier(0x002, 46, 1);
+#pragma unroll
+      for (int i = 0; i < 14; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 1);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 14, 1);
+    }
+    ARP_T(3, tt);
+    // v back to the state layout: lane (g, j) holds v[16 fb + 4 g + r] of chain j in acc[fb][r]; the split columns'
+    // m and l parts (accA: output row 4 g + r = split column q (rows 0 - 7) / q + 8 (rows 8 - 15)) are added in LDS,
+    // the two halves of the wave one after the other (LDS operations of a wave execute in order)
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb)
+      *reinterpret_cast<float4*>(xch + j * kXchStride + 16 * fb + 4 * g) = make_float4(acc[fb][0], acc[fb][1], acc[fb][2], acc[fb][3]);
+    float lp = 0.0f;
+    if (LOGP) lpx[lane] = 0.6931471805599453f * ((lp2[0][0] + lp2[0][1]) + (lp2[1][0] + lp2[1][1]));
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if ((g >> 1) == half) {
+#pragma unroll
+        for (int r_ = 0; r_ < 4; ++r_) {
+          const int q = 4 * (g & 1) + r_;
+          if (sidx[q] >= 0) xch[j * kXchStride + sidx[q]] += accA[r_];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 f = own[i];
+      v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+    }
+    if (LOGP) lp = (lpx[c] + lpx[16 + c]) + (lpx[32 + c] + lpx[48 + c]);
+    __builtin_amdgcn_wave_barrier();
+    ARP_T(4, tt);
+    return lp;
+  }
+
   template <bool LOGP>
   ARP_DEV float grad(const float (&q)[ND], float (&g)[ND]) const {
     ARP_T0(tg);
@@ -700,6 +1060,7 @@ struct GermanLane {
     float lp;
     ARP_T(0, tg);
     if constexpr (K == 8) lp = likelihood_k8<LOGP>(beta, v);
+    else if constexpr (K == 4 && BF3_) lp = likelihood_bf3<LOGP>(beta, v);
     else if constexpr (K == 4) lp = likelihood_mfma<LOGP>(beta, v);
     else lp = likelihood_generic<LOGP>(beta, v);
     ARP_T(7, tg);

@@ -230,6 +230,10 @@ class Engine(object):
         return (elbo, prior) if return_prior else elbo
 
 
+    def set_option(self, key, value):
+        """Per-handle option (arp_model_set_option), e.g. ("german_math", "f32" | "bf16x3" | "auto")."""
+        _lib.check(self._L.arp_model_set_option(self._h, key.encode(), value.encode()))
+
     def vi_geometry(self):
         """Shape of this thread's last vi_run launch (arp_vi_geometry): threads per workgroup, sample groups G and row
         parts R per learning rate, learning rates per launch, workgroups resident together, workgroups one CU holds."""

@@ -127,6 +127,12 @@ const char* arp_last_error(void);
 int arp_model_create(const arp_dataset* data, arp_model** out);
 int arp_model_destroy(arp_model* m);
 int arp_model_dim(const arp_model* m);                 /* D */
+/* Per-handle options (no reference counterpart).  "german_math": how german credit's likelihood contraction runs at 4 lanes
+ * per chain -- "f32" = f32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32 products), "bf16x3" = bf16 matrix cores with every
+ * operand as three bf16 pieces (six leading cross products: f32-equivalent, error ~ 2^-23 per product; needs a design matrix
+ * with at most 8 columns that are not exact in one bf16 piece -- the reference's data have 7), "auto" (default) = bf16x3 where
+ * the data allow it.  Returns non-zero for an unknown key / value or a model the key does not apply to. */
+int arp_model_set_option(arp_model* m, const char* key, const char* value);
 /* Additive constant dropped from logp for parameterisation `which` (so callers can
  * report the reference-valued target_log_prob / ELBO): logp_ref = logp + const. */
 double arp_model_logp_const(const arp_model* m, int which);

@@ -97,11 +97,13 @@ def test_missing_param_and_bad_lanes_fail(engines):
         eng.logp_grad(x, lanes=1)  # no 1-lane instantiation for radon
 
 
-@pytest.mark.parametrize("n_obs", [1, 17, 128, 129, 300, 513, 1000])
+@pytest.mark.parametrize("n_obs", [1, 17, 64, 65, 128, 129, 300, 513, 1000])
 def test_german_observation_tiles(oracle_lib, gpu, n_obs):
-    """German credit's matrix-core likelihood (4 lanes per chain) streams the design matrix in 128-row tiles through two
-    LDS buffers: one tile, an odd and an even number of tiles, tiles that end inside a 16-row block -- log density and
-    gradient against the float64 oracle on the truncated data set, and the 8- and 16-lane paths beside it."""
+    """German credit's matrix-core likelihoods (4 lanes per chain) stream the design matrix in tiles through two LDS
+    buffers -- 64 observations per tile on bf16 matrix cores with three-piece operands (the default where the data allow
+    it: `german_math`), 128 on f32 matrix cores: one tile, an odd and an even number of tiles, tiles that end inside a
+    16-row block -- log density and gradient against the float64 oracle on the truncated data set, SAME tolerances for
+    both, and the 8- and 16-lane paths beside them."""
     import copy
     from autoreparam_amd import engine
     full = helpers.spec("german")
@@ -115,11 +117,54 @@ def test_german_observation_tiles(oracle_lib, gpu, n_obs):
         eng.set_param(0, (a, b))
         x = helpers.states(sp, 37, seed=n_obs)
         lp_o, g_o = orc.logp_grad(x, a, b, dtype=np.float64)
-        for lanes in (4, 8, 16):
+        for lanes, math in ((4, "bf16x3"), (4, "f32"), (8, "auto"), (16, "auto")):
+            eng.set_option("german_math", math)
             lp, g = eng.logp_grad(x, which=0, lanes=lanes)
             lp, g = lp.cpu().numpy(), g.cpu().numpy()
-            assert np.abs(lp - lp_o).max() <= 2e-6 * max(1.0, np.abs(lp_o).max()) + 1e-3, (lanes, kind)
-            assert np.abs(g - g_o).max() <= _tol(g_o), (lanes, kind)
+            assert np.abs(lp - lp_o).max() <= 2e-6 * max(1.0, np.abs(lp_o).max()) + 1e-3, (lanes, math, kind)
+            assert np.abs(g - g_o).max() <= _tol(g_o), (lanes, math, kind)
+
+
+def test_german_math_option(oracle_lib, gpu):
+    """arp_model_set_option("german_math", ...): auto picks the bf16 x 3 likelihood for the reference's data (7 columns
+    need three pieces), "f32" keeps the f32 matrix cores; a design matrix with more than 8 non-bf16 columns has no bf16
+    image (auto = f32, "bf16x3" refused); unknown keys / values / models fail loudly.  Both forms meet the oracle, and the
+    bf16 form is at least as close to it as the f32 one (its products are exact, only the accumulation rounds)."""
+    import copy
+    from autoreparam_amd import engine
+    sp = helpers.spec("german")
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "VIP")
+    x = helpers.states(sp, 256, seed=5, scale=0.3)
+    lp_o, g_o = orc.logp_grad(x, a, b, dtype=np.float64)
+    err = {}
+    eng = engine.Engine(sp, gpu)
+    eng.set_param(0, (a, b))
+    for math in ("f32", "bf16x3", "auto"):
+        eng.set_option("german_math", math)
+        lp, g = eng.logp_grad(x, lanes=4)
+        err[math] = np.abs(g.cpu().numpy() - g_o).max() / np.abs(g_o).max()
+        assert err[math] <= 2e-6
+    assert err["auto"] == err["bf16x3"] and err["bf16x3"] <= 1.5 * err["f32"]
+    with pytest.raises(RuntimeError):
+        eng.set_option("german_math", "fp8")
+    with pytest.raises(RuntimeError):
+        eng.set_option("no_such_key", "1")
+    with pytest.raises(RuntimeError):
+        engine.Engine(helpers.spec("radon_MN"), gpu).set_option("german_math", "f32")
+    # a dense design matrix: every column needs three pieces
+    dense = copy.copy(sp)
+    dense.raw = dict(sp.raw)
+    rs = np.random.RandomState(0)
+    dense.raw["X"] = (sp.raw["X"] + 0.01 * rs.randn(*sp.raw["X"].shape)).astype(np.float32)
+    e2 = engine.Engine(dense, gpu)
+    e2.set_param(0, (a, b))
+    with pytest.raises(RuntimeError):
+        e2.set_option("german_math", "bf16x3")
+    o2 = oracle_lib.OracleModel(dense)
+    lp2, g2 = e2.logp_grad(x, lanes=4)                         # auto: the f32 matrix cores
+    _, g2o = o2.logp_grad(x, a, b, dtype=np.float64)
+    assert np.abs(g2.cpu().numpy() - g2o).max() <= 2e-6 * np.abs(g2o).max()
 
 
 @pytest.mark.parametrize("ds", ["IN", "MO", "ND"])

@@ -30,7 +30,7 @@ def _eps0(oracle_lib, sp, a, b, x, frac):
     return (frac / np.sqrt(np.abs(diag) + 1.0)).astype(np.float32)
 
 
-def _compare(oracle_lib, gpu, mname, kind, lanes, adapt_kind, frac, L, n, n_adapt=0, sp=None, Cn=96, state_tol=1e-4):
+def _compare(oracle_lib, gpu, mname, kind, lanes, adapt_kind, frac, L, n, n_adapt=0, sp=None, Cn=96, state_tol=1e-4, options=()):
     """Run the HIP kernel and the float32 oracle on the same seeds, twice: once on the recording schedule under test
     (burn-in 2, every third transition: trace rows, accept flags) and once recording EVERY transition (state in sampler
     coordinates + accept flag + the oracle's Metropolis margins), which is what `helpers.explain_divergence` needs to
@@ -41,6 +41,8 @@ def _compare(oracle_lib, gpu, mname, kind, lanes, adapt_kind, frac, L, n, n_adap
         eng = _eng(mname, gpu)
     else:
         eng = engine.Engine(sp, gpu)
+    for key, value in options:
+        eng.set_option(key, value)
     orc = oracle_lib.OracleModel(sp)
     a, b = helpers.params(sp, kind)
     eng.set_param(0, (a, b))
@@ -92,17 +94,19 @@ def test_trajectories_match_oracle_fixed_step(oracle_lib, gpu, mname, kind):
         assert np.array_equal(st.rng.cpu().numpy().view(np.uint32)[:, :lanes], so["rng"][:, :lanes])
 
 
+@pytest.mark.parametrize("math", ["bf16x3", "f32"])
 @pytest.mark.parametrize("n_obs", [100, 300, 640])
-def test_german_trajectories_on_one_three_and_five_tiles(oracle_lib, gpu, n_obs):
-    """German credit on the matrix cores with the data set cut to 1, 3 and 5 tiles of 128 observations: an odd number of
-    tiles flips the buffer the first tile of a gradient lands in, and the trace rows are staged in the LDS area that the
-    next gradient's first tile overwrites -- trajectories, acceptance and trace rows against the float32 oracle."""
+def test_german_trajectories_on_one_three_and_five_tiles(oracle_lib, gpu, n_obs, math):
+    """German credit on the matrix cores -- bf16 with three-piece operands (64-observation tiles: 2, 5 and 10 of them) and
+    f32 (128-observation tiles: 1, 3 and 5) -- with the data set cut short: an odd number of tiles flips the buffer the
+    first tile of a gradient lands in, and the trace rows are staged in the LDS area that the next gradient's first tile
+    overwrites -- trajectories, acceptance and trace rows against the float32 oracle, same tolerances for both."""
     import copy
     full = helpers.spec("german")
     sp = copy.copy(full)
     sp.raw = dict(full.raw); sp.raw["X"] = full.raw["X"][:n_obs]; sp.raw["y"] = full.raw["y"][:n_obs]
     sp.observed = {"y": sp.raw["y"][None]}
-    r = _compare(oracle_lib, gpu, "german", "NCP", 4, 0, 0.05, 4, 12, sp=sp)
+    r = _compare(oracle_lib, gpu, "german", "NCP", 4, 0, 0.05, 4, 12, sp=sp, options=(("german_math", math),))
     ok = r["clean"]
     assert (r["err"][ok] <= 1e-4).all()
     assert (r["terr"][ok] <= 1e-4).mean() >= 0.98 and (r["terr"][ok] <= 1e-2).all()
