@@ -516,26 +516,49 @@ def main():
                                           "assumes N identical GPUs and no data-path collective (there is none)"}
 
     # secondary: the compute-bound model (BASELINE configs[2], german credit, 16 384 chains; SURVEY 8d prices it
-    # against the f32 peak: algorithmic flops = 2 products x 2 flop x N x F per gradient)
+    # against the f32 peak: algorithmic flops = 2 products x 2 flop x N x F per gradient).  Two forms of the SAME f32-exact
+    # contraction (arp_model_set_option "german_math"): f32 matrix cores, and -- the default since round 5 -- bf16 matrix
+    # cores with three-piece operands, which issue 3.7 x the flops on a pipe that is 16 x faster.
     if secondary:
         gspec = models._spec_german()
-        geng = engine.Engine(gspec, dev)
-        geng.set_param(0, "NCP")
         Cg, Lg, Tg = 16384, 4, 64   # 64 transitions per launch (the CLI runs up to 4 096): what a launch costs once -- state in and out, the spread between workgroups over few transitions -- is 0.09 ms, 14 % of a 4-transition launch
-        rsg = np.random.RandomState(1)
-        stg = engine.ChainState(torch.as_tensor((0.1 * rsg.randn(Cg, gspec.D)).astype(np.float32), device=dev))
-        epsg = np.full(gspec.D, 0.005, np.float32)
-        kwg = dict(seed=5, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9)
-        gms = _time_launches(lambda: geng.hmc_run(stg, epsg, Lg, Tg, **kwg), 3, 1)
         Ng, Fg = gspec.raw["X"].shape
         gflop = 4.0 * Ng * Fg
-        extras["german_credit"] = {
-            "kernel": "hmc_kernel<GermanLane<4,16>> (v_mfma_f32_16x16x4_f32)", "chains": Cg, "num_leapfrog_steps": Lg,
-            "kernel_ms": gms, "leapfrog_steps_per_s": Cg * Tg * Lg / (gms * 1e-3),
-            "roofline": {"bound": "mfma", "achieved": Cg * Tg * Lg * gflop / (gms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": Cg * Tg * Lg * gflop / (gms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                         "algorithmic_flop_per_gradient": gflop}}
-        del geng, stg
+        BF16_PEAK_TFLOPS = 16.0 * FP32_PEAK_TFLOPS          # dense v_mfma_f32_16x16x32_bf16: 1 024 flop per cycle and SIMD
+        # matrix-core flops the bf16 form issues per gradient and chain: per 32 observations 2 x 7 (forward) + 14 (backward)
+        # instructions of 16 x 16 x 32 x 2 flop, shared by the 16 chains of a wave; tiles of 64 observations
+        bf3_flop = ((Ng + 63) // 64) * 2 * 28 * (16 * 16 * 32 * 2) / 16.0
+        forms = {}
+        for gmath in ("bf16x3", "f32"):
+            geng = engine.Engine(gspec, dev)
+            geng.set_option("german_math", gmath)
+            geng.set_param(0, "NCP")
+            rsg = np.random.RandomState(1)
+            stg = engine.ChainState(torch.as_tensor((0.1 * rsg.randn(Cg, gspec.D)).astype(np.float32), device=dev))
+            epsg = np.full(gspec.D, 0.005, np.float32)
+            kwg = dict(seed=5, adapt_kind=_lib.ADAPT_DUAL, n_adapt=10 ** 9)
+            gms = _time_launches(lambda: geng.hmc_run(stg, epsg, Lg, Tg, **kwg), 3, 1)
+            alg_tf = Cg * Tg * Lg * gflop / (gms * 1e-3) / 1e12
+            entry = {"kernel_ms": gms, "leapfrog_steps_per_s": Cg * Tg * Lg / (gms * 1e-3),
+                     "f32_equivalent_TFLOPs": alg_tf, "f32_equivalent_over_f32_peak": alg_tf / FP32_PEAK_TFLOPS}
+            if gmath == "f32":
+                entry["kernel"] = "hmc_kernel<GermanLane<4,16>> (v_mfma_f32_16x16x4_f32)"
+                entry["roofline"] = {"bound": "mfma", "achieved": alg_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": alg_tf / FP32_PEAK_TFLOPS, "algorithmic_flop_per_gradient": gflop}
+            else:
+                ex_tf = Cg * Tg * Lg * bf3_flop / (gms * 1e-3) / 1e12
+                entry["kernel"] = "hmc_kernel<GermanLane<4,16,4,false,true>> (v_mfma_f32_16x16x32_bf16, three-piece operands)"
+                entry["roofline"] = {"bound": "mfma", "achieved": ex_tf, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": ex_tf / BF16_PEAK_TFLOPS, "issued_flop_per_gradient": bf3_flop,
+                                     "algorithmic_flop_per_gradient": gflop,
+                                     "note": "issued bf16 matrix-core flops against the dense bf16 peak; the wave is bound by "
+                                             "instruction issue (one wave per SIMD: every vector, LDS and LDS-DMA instruction "
+                                             "costs it 4 - 100 cycles), not by the matrix pipe -- DESIGN.md section 3"}
+            forms[gmath] = entry
+            del geng, stg
+        extras["german_credit"] = dict(forms["bf16x3"], chains=Cg, num_leapfrog_steps=Lg, transitions_per_launch=Tg,
+                                       default_math="bf16x3", forms=forms,
+                                       speedup_over_f32_matrix_cores=forms["f32"]["kernel_ms"] / forms["bf16x3"]["kernel_ms"])
         # election (BASELINE configs[4]: 131 072 chains): SURVEY 8d ~4.5 kflop per gradient (161 cells x ~25 incl. one exp
         # and one log1p each + 51 x 10) + 4 D for the leapfrog update
         espec = models._spec_election()
