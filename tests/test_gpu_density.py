@@ -206,3 +206,43 @@ def test_other_radon_datasets(oracle_lib, gpu, ds):
     err = np.abs(r["st"].q.cpu().numpy() - r["so"]["q"]).max(axis=1) / r["scale"]
     assert (err[ok] <= 2e-4).all(), np.sort(err[ok])[-5:]
     assert np.array_equal(r["st"].accept_count.cpu().numpy()[ok], r["so"]["accept_count"][ok])
+
+
+def test_german_bf16x3_on_adversarial_design_matrices(oracle_lib, gpu):
+    """The bf16 x 3 likelihood away from the reference's data: EIGHT split columns (the most its extra K = 32 step holds)
+    with scales from 1e-3 to 1e3, columns that are exact in one bf16 piece without being 0/1 (0.5, 1.5, -2, 96), an
+    all-zero column, 333 observations (five whole tiles and 13 rows) -- log density and gradient against the float64
+    oracle at the usual tolerances, beside the f32 matrix-core form; nine split columns: no bf16 image."""
+    import copy
+    from autoreparam_amd import engine
+    full = helpers.spec("german")
+    rs = np.random.RandomState(7)
+    N, F = 333, full.raw["X"].shape[1]
+    X = (rs.rand(N, F) < 0.3).astype(np.float32)                                  # zeros and ones
+    X[:, 0] = 1.0
+    scales = [1e-3, 0.05, 1.0, 3.7, 37.5, 250.0, 1e3, 0.3]
+    for q, s_ in enumerate(scales):
+        X[:, 1 + q] = (s_ * rs.randn(N)).astype(np.float32)                       # eight columns that need three pieces
+    X[:, 20] = rs.choice([0.5, 1.5, -2.0, 96.0], N)                              # exact in one piece, not 0/1
+    X[:, 21] = 0.0
+    y = (rs.rand(N) < 0.4).astype(np.float32)
+    sp = copy.copy(full)
+    sp.raw = dict(full.raw); sp.raw["X"] = X; sp.raw["y"] = y
+    sp.observed = {"y": y[None]}
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "VIP")
+    x = helpers.states(sp, 64, seed=11, scale=0.05)          # small coefficients: the logits stay out of saturation for most rows
+    lp_o, g_o = orc.logp_grad(x, a, b, dtype=np.float64)
+    eng = engine.Engine(sp, gpu)
+    eng.set_param(0, (a, b))
+    for math in ("bf16x3", "f32"):
+        eng.set_option("german_math", math)
+        lp, g = eng.logp_grad(x, lanes=4)
+        lp, g = lp.cpu().numpy(), g.cpu().numpy()
+        assert np.abs(lp - lp_o).max() <= 2e-6 * max(1.0, np.abs(lp_o).max()) + 1e-3, math
+        assert np.abs(g - g_o).max() <= _tol(g_o), math
+    X9 = X.copy(); X9[:, 30] = rs.randn(N).astype(np.float32)                     # a ninth split column
+    sp9 = copy.copy(sp); sp9.raw = dict(sp.raw); sp9.raw["X"] = X9
+    e9 = engine.Engine(sp9, gpu)
+    with pytest.raises(RuntimeError):
+        e9.set_option("german_math", "bf16x3")
