@@ -704,6 +704,10 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   const LaneOps* o = pick(*fam, m->n_groups, Kmax, 1 << 30, m->model != ARP_MODEL_GERMAN_CREDIT, 131072,
                           m->model == ARP_MODEL_TIME_SERIES ? 2 : 1);
   if (!o || !o->vi) { set_error("no VI kernel instantiation covers this group count"); return 1; }
+  // German credit: the row-part lane on bf16 matrix cores with three-piece operands where the data allow it (64-observation
+  // tiles), else on f32 matrix cores (128-observation tiles) -- the same choice as the chain kernels make (select_ops)
+  const bool german_bf3 = m->model == ARP_MODEL_GERMAN_CREDIT && m->german.Xb && m->german_math != 1;
+  if (german_bf3) o = &german_bf3_ops();
   if (m->D > o->vi_dmax) { set_error("arp_vi_run: model dimension exceeds this model's VI kernel instantiation"); return 1; }
   ViParams P;
   P.n_steps = cfg->n_steps; P.n_mc = cfg->n_mc; P.learn_a = cfg->learn_a; P.tied_b = cfg->tied_b; P.a_prior = cfg->a_prior; P.D = m->D;
@@ -743,7 +747,8 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   if (o->vi_parts) {
     // German credit: the observations' 128-row tiles are split too, so that a learning rate's group has about 32
     // workgroups (five learning rates: 160 CUs) and a gradient is two tiles of matrix-core work per wave
-    const int nt = (m->german.N + kGermanTileRows - 1) / kGermanTileRows;
+    const int tile_obs = german_bf3 ? kBf3Rows : kGermanTileRows;
+    const int nt = (m->german.N + tile_obs - 1) / tile_obs;
     R = std::min(nt, std::max(1, 32 / G));
   }
   int dbg = 0;

@@ -11,7 +11,7 @@ static LaneOps with_vi(LaneOps o, const LaneOps& vi) {
 }
 const LaneOps& german_bf3_ops() {
   static const LaneOps o = with_vi(Launch<GermanLane<4, 16, kBlock / 64, false, true>>::ops(),
-                                   Launch<GermanLane<4, 16, kGermanViBlock / 64, true>>::vi_only());
+                                   Launch<GermanLane<4, 16, kGermanViBlock / 64, true, true>>::vi_only());
   return o;
 }
 const std::vector<LaneOps>& german_ops() {

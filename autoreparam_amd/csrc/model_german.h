@@ -89,7 +89,8 @@ struct GermanArgs {
 // BF3_: the likelihood on bf16 matrix cores with three-piece operands (above) instead of f32 matrix cores; K = 4 only.
 template <int K_, int NLS_, int W_ = kBlock / 64, bool PART_ = false, bool BF3_ = false>
 struct GermanLane {
-  static_assert(!BF3_ || (K_ == 4 && !PART_), "the bf16 x 3 likelihood serves the 4-lane chain kernels");
+  static_assert(!BF3_ || K_ == 4, "the bf16 x 3 likelihood serves the 4-lane kernels");
+  static constexpr int kTileObs = BF3_ ? kBf3Rows : kGermanTileRows;   // observations per tile of this lane's image
   static constexpr int K = K_;
   static constexpr int NG = 1;          // overall_log_scale
   static constexpr int NLS = NLS_;      // features owned by this lane: d = slot*NLS + i
@@ -115,11 +116,11 @@ struct GermanLane {
   static constexpr int VI_BLOCK = W_ * 64;
   static constexpr int VI_DMAX = 128;   // LDS arrays of the VI kernel are sized for this (the real data: D = 125)
   ARP_DEV int tlo() const { if constexpr (PART_) return tlo_; else return 0; }
-  ARP_DEV int thi() const { if constexpr (PART_) return thi_; else return (N + kGermanTileRows - 1) / kGermanTileRows; }
+  ARP_DEV int thi() const { if constexpr (PART_) return thi_; else return (N + kTileObs - 1) / kTileObs; }
   ARP_DEV float pw() const { if constexpr (PART_) return pw_; else return 1.0f; }
   // row part `r` of `R`: whole tiles, as even as they go (a part past the data is empty and contributes nothing)
   ARP_DEV void set_part(int r, int R) {
-    const int nt = (N + kGermanTileRows - 1) / kGermanTileRows, per = (nt + R - 1) / R;
+    const int nt = (N + kTileObs - 1) / kTileObs, per = (nt + R - 1) / R;
     tlo_ = min(nt, r * per); thi_ = min(nt, tlo_ + per); pw_ = r == 0 ? 1.0f : 0.0f;
   }
   ARP_DEV bool resident() const { if constexpr (PART_) return res_; else return false; }
@@ -133,7 +134,10 @@ struct GermanLane {
     if (!res_) return;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t tile_off = lds_offset(tile_mem());
-    for (int n = 0; n < nt; ++n) issue_tile(tlo_ + n, (n + nt) & 1, tile_off, wv, threadIdx.x & 63);
+    for (int n = 0; n < nt; ++n) {
+      if constexpr (BF3_) issue_tile_bf3(tlo_ + n, (n + nt) & 1, tile_off, wv, threadIdx.x & 63);
+      else issue_tile(tlo_ + n, (n + nt) & 1, tile_off, wv, threadIdx.x & 63);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -153,7 +157,7 @@ struct GermanLane {
     }
     nown = F - slot * NLS;
     nown = nown < 0 ? 0 : (nown > NLS ? NLS : nown);
-    tlo_ = 0; thi_ = (N + kGermanTileRows - 1) / kGermanTileRows; pw_ = 1.0f; res_ = false;
+    tlo_ = 0; thi_ = (N + kTileObs - 1) / kTileObs; pw_ = 1.0f; res_ = false;
     set_param(av, bv);
   }
   ARP_DEV void set_param(const float* av, const float* bv) {
@@ -602,9 +606,10 @@ struct GermanLane {
   ARP_DEV void first_tile() const {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if constexpr (BF3_) {
-      const int ntb = (N + kBf3Rows - 1) / kBf3Rows;
+      const int ntb = thi() - tlo();
+      if (resident()) return;
       __syncthreads();
-      issue_tile_bf3(0, ntb & 1, lds_offset(tile_mem()), wv, threadIdx.x & 63);
+      if (!PART_ || ntb > 0) issue_tile_bf3(tlo(), ntb & 1, lds_offset(tile_mem()), wv, threadIdx.x & 63);
       return;
     }
     const int nt = thi() - tlo();
@@ -793,7 +798,8 @@ struct GermanLane {
     const int c = lane >> 2, t = lane & 3;    // state layout (t == slot)
     const int g = lane >> 4, j = lane & 15;   // matrix-core layout: lane group g, row / chain j
     const uint32_t tile_off = lds_offset(tile);
-    const int nt = (N + kBf3Rows - 1) / kBf3Rows;
+    const int t0 = tlo(), nt = thi() - t0;   // this workgroup's tiles (all of them outside the VI kernel)
+    const bool res = resident();              // (VI kernel) the part's one or two tiles are in the buffers for good
     int buf = nt & 1;
     ARP_T0(tt);
 
@@ -913,10 +919,12 @@ struct GermanLane {
 #undef ARP_OFF
 
     // tile 0 has landed everywhere; tile 1 into the other buffer
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (nt > 1) issue_tile_bf3(1, buf ^ 1, tile_off, wv, lane);
-    fwd_reads(tile_off + (uint32_t)buf * kBufStep);
+    if (!res) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (nt > 1) issue_tile_bf3(t0 + 1, buf ^ 1, tile_off, wv, lane);
+    }
+    if (!PART_ || nt > 0) fwd_reads(tile_off + (uint32_t)buf * kBufStep);
     ARP_T(2, tt);
 
     // The tile loop, written slot by slot: every matrix-core instruction is followed by the one or two other
@@ -929,7 +937,7 @@ struct GermanLane {
     //   backward: 2 k-steps x 14 products; slots carry the LDS-DMA of tile n + 2, the second k-step's split and the 16
     //             forward reads of tile n + 1
     for (int n = 0; n < nt; ++n) {
-      const int rows = min(kBf3Rows, N - n * kBf3Rows);
+      const int rows = min(kBf3Rows, N - (t0 + n) * kBf3Rows);
       const uint32_t base = tile_off + (uint32_t)buf * kBufStep;
       ARP_T(3, tt);
       asm volatile("s_waitcnt lgkmcnt(0)"
@@ -983,9 +991,11 @@ struct GermanLane {
         // Hand-over, between the two products: every LDS read of tile n has landed (all its operands are in registers)
         // and this wave's share of tile n + 1 too; after the barrier tile n + 1 is complete for every wave and tile n's
         // buffer is free for tile n + 2.  The next tile's forward reads go out at once and land under the backward product.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (n + 2 < nt) issue_tile_bf3(n + 2, buf, tile_off, wv, lane);
+        if (!res) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (n + 2 < nt) issue_tile_bf3(t0 + n + 2, buf, tile_off, wv, lane);
+        }
         buf ^= 1;
         fwd_reads(tile_off + (uint32_t)buf * kBufStep);
       }
