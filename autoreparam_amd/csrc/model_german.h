@@ -1037,8 +1037,10 @@ struct GermanLane {
       if ((g >> 1) == half) {
 #pragma unroll
         for (int r_ = 0; r_ < 4; ++r_) {
-          const int q = 4 * (g & 1) + r_;
-          if (sidx[q] >= 0) xch[j * kXchStride + sidx[q]] += accA[r_];
+          // split column 4 (g & 1) + r_: both candidates by CONSTANT index (a run-time index into the lane object would
+          // pin the whole object -- a[], b[], the pointers -- in scratch or LDS instead of registers)
+          const int sq = (g & 1) ? sidx[4 + r_] : sidx[r_];
+          if (sq >= 0) xch[j * kXchStride + sq] += accA[r_];
         }
       }
       __builtin_amdgcn_wave_barrier();
