@@ -747,16 +747,25 @@ struct GermanLane {
   // ---- the bf16 x 3 likelihood (see the tile image at the top of the file) ----
   typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
   typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-  // this wave's share of tile n of the bf16 image into buffer `buf`: pieces wv, wv + W, ...
+  // this wave's share of tile n of the bf16 image into buffer `buf`: a contiguous run of ceil(23 / W) pieces, four per
+  // M0 set-up (the instruction offset moves the global and the LDS address alike), the rest one by one
   ARP_DEV void issue_tile_bf3(int n, int buf, uint32_t tile_off, int wv, int lane) const {
-    const float* src = Xb + (size_t)n * kBf3ImgTile;
-    const uint32_t dst = tile_off + (uint32_t)buf * kBufStep;
+    constexpr int PW = (kBf3Pieces + W_ - 1) / W_;
+    const int p0 = wv * PW;
+    const float* src = Xb + (size_t)n * kBf3ImgTile + p0 * 256;
+    const uint32_t dst = tile_off + (uint32_t)buf * kBufStep + (uint32_t)p0 * 1024u;
     const uint32_t voff = (uint32_t)lane * 16u;
 #pragma unroll
-    for (int p = 0; p < (kBf3Pieces + W_ - 1) / W_; ++p) {
-      const int piece = wv + p * W_;
-      if (piece < kBf3Pieces) glds16(src + piece * 256, voff, dst + (uint32_t)piece * 1024u);
-    }
+    for (int p = 0; p + 4 <= PW; p += 4)
+      if (p0 + p + 4 <= kBf3Pieces) glds16x4(src + p * 256, voff, dst + (uint32_t)p * 1024u);
+      else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (p0 + p + k < kBf3Pieces) glds16(src + (p + k) * 256, voff, dst + (uint32_t)(p + k) * 1024u);
+      }
+#pragma unroll
+    for (int p = PW / 4 * 4; p < PW; ++p)
+      if (p0 + p < kBf3Pieces) glds16(src + p * 256, voff, dst + (uint32_t)p * 1024u);
   }
   // two bf16 (the high halves of two f32 bit patterns) in one register: element 2k low, 2k + 1 high
   static ARP_DEV uint32_t bf_pack(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
