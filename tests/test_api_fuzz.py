@@ -61,6 +61,16 @@ def test_host_only_handles_build_and_validate(host_lib, name):
     assert L.arp_model_set_param(h, 0, a.ctypes.data_as(f32p), a.ctypes.data_as(f32p)) == 0
     assert L.arp_model_set_param(h, 2, a.ctypes.data_as(f32p), a.ctypes.data_as(f32p)) != 0
     assert L.arp_model_set_param(h, 0, None, a.ctypes.data_as(f32p)) != 0
+    # options: german_math on german credit only (the reference's data have 7 columns that need three bf16 pieces: every
+    # value is accepted); unknown keys, values, NULLs and other models fail with a message
+    if name == "german":
+        for v in (b"f32", b"bf16x3", b"auto"):
+            assert L.arp_model_set_option(h, b"german_math", v) == 0
+        assert L.arp_model_set_option(h, b"german_math", b"fp8") != 0 and b"german_math" in L.arp_last_error()
+    else:
+        assert L.arp_model_set_option(h, b"german_math", b"f32") != 0
+    assert L.arp_model_set_option(h, b"no_such_key", b"1") != 0 and len(L.arp_last_error()) > 0
+    assert L.arp_model_set_option(h, None, b"1") != 0 and L.arp_model_set_option(None, b"german_math", b"f32") != 0
     assert L.arp_model_destroy(h) == 0
 
 
