@@ -1,0 +1,45 @@
+"""Stability soak of the many-workgroup VI launch: random model, number of learning rates (1 .. 9: German credit's groups stop
+fitting together at 6), draw counts that leave lanes / waves / turns ragged, step counts, tied / untied / fixed parameterisation;
+every fit runs TWICE and must repeat itself bit for bit (the in-launch hand-offs add in workgroup order), stay finite and
+return no error (a hand-off that waits 2 s sets the launch's error flag).  usage: vi_soak.py [seed] [seconds]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import helpers
+from autoreparam_amd import engine
+MODELS = ["8schools", "radon_MN", "radon_PA", "election", "german", "radon_sd_MN", "funnel", "electric", "time_series"]
+rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+engines = {m: engine.Engine(helpers.spec(m), "cuda:0") for m in MODELS}
+t0 = time.time(); n = 0; steps_total = 0; shapes = set()
+while time.time() - t0 < budget:
+    m = MODELS[rs.randint(len(MODELS))]
+    sp, eng = helpers.spec(m), engines[m]
+    n_lr = int(rs.randint(1, 10))
+    n_mc = int(rs.choice([1, 2, 7, 31, 64, 100, 255, 256, 257, 600, 1024, 4096]))
+    n_steps = int(rs.randint(1, 90))
+    learn = rs.rand() < 0.5
+    tied = learn and rs.rand() < 0.5
+    kind = ["CP", "NCP", "VIP"][rs.randint(3)]
+    eng.set_param(0, helpers.params(sp, kind, seed=rs.randint(100)))
+    lrs = (10.0 ** rs.uniform(-3, -0.7, n_lr)).astype(np.float32)
+    loc0 = (1e-2 * rs.randn(n_lr, sp.D)).astype(np.float32)
+    seed = int(rs.randint(1 << 30))
+    out = []
+    for _ in range(2):
+        loc = torch.as_tensor(loc0.copy(), device="cuda:0"); rho = torch.full((n_lr, sp.D), -2.0, device="cuda:0")
+        w = torch.zeros(n_lr, sp.D, device="cuda:0") if learn else None
+        wb = torch.zeros(n_lr, sp.D, device="cuda:0") if (learn and not tied) else None
+        e = eng.vi_run(lrs, loc, rho, n_steps, n_mc, w=w, wb=wb, tied_b=tied, seed=seed)
+        out.append([t.cpu().numpy() for t in (e, loc, rho) + ((w,) if learn else ())])
+    g = eng.vi_geometry()
+    shapes.add((m, g["sample_groups"], g["row_parts"], g["learning_rates_per_launch"]))
+    tag = (m, n_lr, n_mc, n_steps, learn, tied, kind, seed)
+    for x, y in zip(*out):
+        assert np.array_equal(x, y, equal_nan=True), ("not reproducible", tag)
+    # a learning rate of 0.2 may diverge to inf/nan on its own (the reference's search discards those); the first ELBO never does
+    assert np.isfinite(out[0][0][:, 0]).all(), ("first ELBO not finite", tag)
+    n += 1; steps_total += 2 * n_lr * n_steps
+print("vi soak ok: %d fits (each twice, bitwise equal), %d optimisation steps, %d distinct (model, G, R, learning rates per launch) shapes in %.0f s"
+      % (n, steps_total, len(shapes), time.time() - t0))
