@@ -290,3 +290,34 @@ def test_vi_hand_offs_under_uneven_load(gpu):
             assert np.array_equal(a, b)
         assert np.isfinite(busy[0]).all()
         del still_busy
+
+
+@pytest.mark.parametrize("mname,kind,idx", [("8schools", "CP", 1), ("german", "NCP", 0)])
+def test_vi_nan_gradients_are_zeroed(oracle_lib, gpu, mname, kind, idx):
+    """inference.py:62-65: a NaN gradient becomes 0 before Adam sees it.  A scale parameter that starts at e^100
+    overflows float32: the ELBO estimates are NaN from the first step on and the gradients of (nearly) every variational
+    parameter with them -- those parameters stay where they started, bit for bit, the ones whose gradient is still a
+    number move as the oracle's do, and nothing becomes NaN.  (Only cases where HIP path and oracle put NaN -- not +-inf,
+    which Adam turns into a NaN parameter on both sides, as TF's would -- in the same entries: past float32 overflow that
+    class depends on the order of the algebra, DESIGN.md section 9, tools/experiments/nonfinite_probe.py.)"""
+    from autoreparam_amd import engine
+    sp = helpers.spec(mname)
+    eng = engine.Engine(sp, gpu)
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, kind)
+    eng.set_param(0, (a, b))
+    rs = np.random.RandomState(0)
+    loc0 = (1e-2 * rs.randn(1, sp.D)).astype(np.float32); rho0 = np.full((1, sp.D), -2.0, np.float32)
+    loc0[0, idx] = 100.0 if mname != "german" else 95.0
+    loc = torch.as_tensor(loc0.copy(), device=gpu); rho = torch.as_tensor(rho0.copy(), device=gpu)
+    elbo = eng.vi_run([0.05], loc, rho, 20, 64, seed=3).cpu().numpy()
+    lo, ro = loc0.copy(), rho0.copy()
+    elbo_o = orc.vi_run(a, b, [0.05], lo, ro, None, 20, 64, seed=3, lanes=VI_LANES[mname])
+    assert np.isnan(elbo_o).all() and np.isnan(elbo).all()
+    lg, rg = loc.cpu().numpy(), rho.cpu().numpy()
+    assert np.isfinite(lg).all() and np.isfinite(rg).all() and np.isfinite(lo).all()
+    still = (lo == loc0) & (ro == rho0)
+    assert still.sum() >= sp.D - 2 and still[0, idx]
+    assert np.array_equal(lg[still], loc0[still]) and np.array_equal(rg[still], rho0[still])
+    np.testing.assert_allclose(lg[~still], lo[~still], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(rg[~still], ro[~still], rtol=1e-3, atol=1e-4)
