@@ -184,6 +184,54 @@ def test_config3_full_size_german_dvip(gpu, tmp_path):
     assert tr["beta"].shape == (S, 4, 62)
 
 
+def test_config5_full_size_election_cvip(gpu, tmp_path):
+    """BASELINE configs[4] at its real size through the CLI flow: election, cVIP fit (the learned continuous parameterisation) ->
+    HMCtuning sweep over the leapfrog count -> HMC with dual averaging on 131 072 chains with the tuned count, statistics
+    accumulated inside the kernels.  Short schedule; the pooled posterior means of the centred coordinates against the long
+    float64 oracle run (tests/golden/posterior_golden.npz), and the 1-based one-hot quirk's prior-only slot: `a[0]` has
+    no observation (models.py:978, 985-988), so its posterior is its prior given (mua, sigma_a)."""
+    import torch
+    from autoreparam_amd import inference
+    d = str(tmp_path)
+    base = ["--model=election", "--method=cVIP", "--results_dir=" + d, "--num_chains=131072", "--seed=4"]
+    _run(base + ["--inference=VI", "--num_optimization_steps=1500"])
+    r = json.load(open(os.path.join(d, "cVIP_eig_tied.json")))
+    a_learned = np.concatenate([np.ravel(v) for k, v in r["learned_reparam"].items() if k.endswith("_a")])
+    assert ((a_learned > 0) & (a_learned < 1)).all() and np.ptp(a_learned) > 0.05        # continuous, and it moved
+    small = ["--num_samples=100", "--num_burnin_steps=600", "--num_adaptation_steps=500"]
+    for L in (2, 4, 8):                          # the reference's sweep: one tuning run per count (main.py:315-323)
+        _run(base[:3] + ["--num_chains=4096", "--seed=4", "--inference=HMCtuning", "--num_leapfrog_steps=%d" % L] + small)
+    r = json.load(open(os.path.join(d, "cVIP_eig_tied.json")))
+    tried = sorted(t["num_leapfrog_steps"] for t in r["tuning_runs"])
+    assert tried == [2, 4, 8]
+    S, burn = 300, 1500
+    res = _run(base + ["--inference=HMC", "--num_samples=%d" % S, "--num_burnin_steps=%d" % burn, "--num_adaptation_steps=1200",
+                       "--trace_chunk_rows=64", "--num_chains_to_save=2"])
+    ess_min, sem_min, acc, mcmc_time = res
+    assert 55 < acc < 95 and ess_min > 0
+    info = inference.hmc.last_ess_info
+    assert info.estimator == "autocorrelation" and info.chains == 1024 and info.batch_means.shape == (131072, 55)
+    mean_c, var_c = inference.hmc.last_moments
+    assert mean_c.shape == (131072, 55) and torch.isfinite(mean_c).all()
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "posterior_golden.npz"))
+    mean_g, sd_g, mcse_g = gold["election/mean"], gold["election/sd"], gold["election/mcse"]
+    cm = mean_c.cpu().numpy()
+    mean = cm.mean(axis=0)
+    mcse = cm.std(axis=0, ddof=1) / np.sqrt(cm.shape[0])
+    z = np.abs(mean - mean_g) / (np.sqrt(mcse ** 2 + mcse_g ** 2) + 0.02 * sd_g)
+    assert z.max() < 5.0, (int(z.argmax()), float(z.max()))
+    sd = np.sqrt(var_c.cpu().numpy().mean(axis=0) + cm.var(axis=0))
+    assert np.abs(sd / sd_g - 1).max() < 0.12
+    # "posterior means within 1 %" where the two runs' Monte-Carlo errors allow the statement
+    err = np.sqrt(mcse ** 2 + mcse_g ** 2)
+    big = (np.abs(mean_g) > 5 * sd_g) & (4 * err < 0.01 * np.abs(mean_g))
+    assert big.sum() >= 1 and (np.abs(mean[big] / mean_g[big] - 1) < 0.01).all()
+    r = json.load(open(os.path.join(d, "cVIP_eig_tied.json")))
+    assert len(r["ess_min"]) == 1 and r["ess_chains"] == [1024]
+    assert np.load(os.path.join(d, "cVIP_eig_tied_ess.npz"))["a"].shape == (1024, 51)
+    assert np.load(os.path.join(d, "cVIP_eig_tied_traces.npz"))["a"].shape == (S, 2, 51)
+
+
 def test_every_model_and_method_runs_through_the_cli():
     """The reference's README model list x its five methods (CP, NCP, cVIP, dVIP, i), each VI -> HMCtuning -> HMC through
     main.py at 256 chains (tools/cli_matrix.py): 45 runs, finite ESS and acceptance rates, the file sequencing the
