@@ -4,6 +4,7 @@
 #include <string.h>
 #include <algorithm>
 #include <memory>
+#include <mutex>
 #include "host_common.h"
 
 namespace arp {
@@ -16,6 +17,10 @@ static const double kHalfLog2Pi = 0.9189385332046727;
 // geometry of the last arp_vi_run of this thread (arp_vi_geometry: a measurement hook)
 struct ViGeometry { int v[6]; };
 static thread_local ViGeometry g_vi_geometry = {{0, 0, 0, 0, 0, 0}};
+// arp_vi_run launches whose workgroups wait for each other hold this from the launch to the end of the launch: two such
+// launches from two threads of a process would share the device's workgroup slots, and a group that is only partly
+// resident waits for slots the other launch's waiting groups hold
+static std::mutex g_vi_launch_mutex;
 
 // Test hook (ARP_DEBUG=1 ARP_HOST_ONLY=1, announced on stderr): model handles WITHOUT a device.  Host memory stands in
 // for the device tables, so that every entry point's argument validation and host-side sizing can be driven -- and run
@@ -784,6 +789,8 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   P.err = (int*)m->vi_ws;
   P.xch = GR > 1 ? (unsigned long long*)((char*)m->vi_ws + 256) : nullptr;
   g_vi_geometry = {B, G, R, groups_per_launch, (int)std::min<long long>((long long)cfg->n_lr * GR, capacity), occ};
+  std::unique_lock<std::mutex> one_at_a_time(g_vi_launch_mutex, std::defer_lock);
+  if (GR > 1) one_at_a_time.lock();
   for (int lr0 = 0; lr0 < cfg->n_lr; lr0 += groups_per_launch) {
     const int ng = std::min(groups_per_launch, cfg->n_lr - lr0);
     // every polled word starts at zero (epochs start at 1): the flag and this launch's granules

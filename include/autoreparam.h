@@ -12,13 +12,18 @@
  *     unless the parameter name ends in `_host`;
  *   - the caller owns every buffer; the library never frees caller memory;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
- *     calls only enqueue work, they never synchronise;
+ *     calls only enqueue work, they never synchronise (one exception: arp_vi_run, see there);
  *   - every function returns 0 on success, non-zero on failure, and
  *     arp_last_error() then returns a human readable message (thread local);
  *   - chain states use the reference layout: the model's latent parts,
  *     flattened and concatenated in trace order, one row per chain,
  *     row-major float32 `[C][D]`  (reference: list of `[C,*event]` tensors,
  *     inference.py:207-216).
+ *   - threads: a handle is used by one thread at a time; different handles (same device or not) may be
+ *     driven from different threads concurrently, each on a stream of its own -- results do not depend on
+ *     it.  arp_vi_run's multi-workgroup launches need their groups resident together: the library runs
+ *     them one at a time per process; across processes sharing a device, or beside another kernel that
+ *     holds the device for seconds, a hand-off that waits 2 s makes the call fail instead of hanging.
  */
 #ifndef AUTOREPARAM_H_
 #define AUTOREPARAM_H_

@@ -1,0 +1,71 @@
+"""GPU: the boundary's threading contract (include/autoreparam.h, SURVEY.md 8b "Threading"): one handle per thread, several
+threads of a process driving the same device concurrently, each on a stream of its own -- every result is bit for bit the
+one the thread gets alone.  ctypes releases the GIL for the duration of a call, so the calls really overlap."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _vi(eng, gpu, sp, seed, learn):
+    rs = np.random.RandomState(0)
+    lrs = [0.02, 0.05, 0.1]
+    loc = torch.as_tensor((1e-2 * rs.randn(3, sp.D)).astype(np.float32), device=gpu); rho = torch.full((3, sp.D), -2.0, device=gpu)
+    w = torch.zeros(3, sp.D, device=gpu) if learn else None
+    e = eng.vi_run(lrs, loc, rho, 120, 256, w=w, seed=seed)
+    return [t.cpu().numpy() for t in (e, loc, rho)]
+
+
+def _hmc(eng, gpu, sp, seed):
+    from autoreparam_amd import engine, _lib
+    st = engine.ChainState(torch.as_tensor(helpers.states(sp, 3001, seed=seed, scale=0.05), device=gpu))
+    tr = torch.zeros(24, 3001, sp.D, device=gpu)      # 3 launches x 16 transitions, every second one recorded
+    eps = np.full(sp.D, 2e-3, np.float32)
+    for _ in range(3):
+        eng.hmc_run(st, eps, 4, 16, seed=seed, adapt_kind=_lib.ADAPT_DUAL, n_adapt=40, thin=2, trace=tr)
+    return [st.q.cpu().numpy(), st.accept_count.cpu().numpy(), tr.cpu().numpy()]
+
+
+def _job(kind, mname, gpu, seed):
+    from autoreparam_amd import engine
+    sp = helpers.spec(mname)
+    eng = engine.Engine(sp, gpu)                  # a handle of this thread's own
+    eng.set_param(0, (np.full(sp.D, 0.5, np.float32), np.ones(sp.D, np.float32)) if kind == "cvip" else "NCP")
+    out = []
+    for rep in range(3):
+        out.append(_hmc(eng, gpu, sp, seed + rep) if kind == "hmc" else _vi(eng, gpu, sp, seed + rep, kind == "cvip"))
+    return out
+
+
+JOBS = [("vi", "german", 11), ("cvip", "election", 12), ("hmc", "radon_PA", 13), ("vi", "radon_MN", 14), ("hmc", "german", 15),
+        ("cvip", "german", 16)]
+
+
+def test_handles_driven_from_concurrent_threads(gpu):
+    alone = [_job(k, m, gpu, s) for k, m, s in JOBS]
+    torch.cuda.synchronize()
+    got, errs = [None] * len(JOBS), []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=gpu)):
+                got[i] = _job(*JOBS[i][:2], gpu, JOBS[i][2])
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:                    # noqa: BLE001 -- reported below, in the main thread
+            errs.append((JOBS[i], repr(e)))
+
+    for _round in range(2):
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(len(JOBS))]
+        for t in ts: t.start()
+        for t in ts: t.join(timeout=300)
+        assert not any(t.is_alive() for t in ts), "a thread hangs"
+        assert not errs, errs
+        for job, a, b in zip(JOBS, alone, got):
+            for ra, rb in zip(a, b):
+                for x, y in zip(ra, rb):
+                    assert np.array_equal(x, y, equal_nan=True), job
