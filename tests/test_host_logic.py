@@ -219,3 +219,30 @@ def test_result_files_are_replaced_atomically(tmp_path):
     cli.save_hmc_results(file_path=p, ess_min=2.0, ess_estimator="autocorrelation")
     assert json.load(open(p)) == {"ess_min": [1.0, 2.0], "ess_estimator": ["autocorrelation", "autocorrelation"]}
     assert os.listdir(str(tmp_path)) == ["r.json"]
+
+
+def test_leapfrog_count_is_settled_as_the_reference_does(capsys):
+    """main.py:315-336: a tuning run insists on --num_leapfrog_steps and is skipped when that count is already recorded; a
+    sampling run without it takes the best tuning run's; --count_in_leapfrog_steps divides the three schedule lengths
+    by it (truncating)."""
+    from autoreparam_amd import main as cli
+    runs = [{"num_leapfrog_steps": 2, "ess_min": 1.0}, {"num_leapfrog_steps": 8, "ess_min": 3.5},
+            {"num_leapfrog_steps": 4, "ess_min": 2.0}]
+    assert cli.get_best_num_leapfrog_steps_from_tuning_runs(runs) == 8
+    f = flags_mod.FlagValues(); f.parse(["--inference=HMCtuning"])
+    with pytest.raises(ValueError, match="number of leapfrog steps"):
+        cli._settle_leapfrog_count({"tuning_runs": runs}, True, f)
+    f = flags_mod.FlagValues(); f.parse(["--inference=HMCtuning", "--num_leapfrog_steps=4"])
+    assert cli._settle_leapfrog_count({"tuning_runs": runs}, True, f) is False          # already there: nothing to do
+    f = flags_mod.FlagValues(); f.parse(["--inference=HMCtuning", "--num_leapfrog_steps=16"])
+    assert cli._settle_leapfrog_count({"tuning_runs": runs}, True, f) is True and f.num_leapfrog_steps == 16
+    f = flags_mod.FlagValues(); f.parse(["--inference=HMC"])
+    assert cli._settle_leapfrog_count({"tuning_runs": runs}, False, f) is True and f.num_leapfrog_steps == 8
+    assert (f.num_samples, f.num_burnin_steps, f.num_adaptation_steps) == (50000, 10000, 6000)
+    f = flags_mod.FlagValues(); f.parse(["--inference=HMC", "--count_in_leapfrog_steps", "--num_leapfrog_steps=3",
+                                         "--num_samples=1000", "--num_burnin_steps=500", "--num_adaptation_steps=100"])
+    assert cli._settle_leapfrog_count({"tuning_runs": runs}, False, f) is True
+    assert (f.num_samples, f.num_burnin_steps, f.num_adaptation_steps) == (333, 166, 33)
+    f = flags_mod.FlagValues(); f.parse(["--inference=HMC"])
+    with pytest.raises(KeyError):                                                     # no tuning run, no count: the reference's KeyError
+        cli._settle_leapfrog_count({}, False, f)
