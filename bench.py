@@ -348,6 +348,8 @@ def main():
         # anything in this process has touched the GPU (never an exec), relay the child's output (rank 0's one JSON
         # line goes to the inherited stdout) and leave with its return code
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    # stdout carries the ONE JSON line and nothing else: what the CLI flows print on the way (fits, tuning runs) goes to stderr
+    json_out, sys.stdout = sys.stdout, sys.stderr
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -868,7 +870,7 @@ def main():
                 out["cpu_baseline_reference_shaped"] = cpu_baseline_reference_shaped(spec, L)
             except Exception as e:
                 out["cpu_baseline_reference_shaped"] = {"value": None, "error": repr(e)}
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -207,3 +207,20 @@ def test_one_rank_bench_under_the_launcher_reports_rccl():
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["dist_backend"] == "nccl" and j["rccl_ranks"] == 1 and j["n_gpus"] == 1 and j["ranks"] == 1
     assert j["stats_allgather_s"] > 0 and 0.3 < j["accept_rate"] < 1.0
+
+
+def test_bench_stdout_is_one_json_line():
+    """`python bench.py` the way the driver runs the N = 1 bench: the CLI flows it drives (VI fits, tuning runs, the ESS run)
+    print their progress to stderr; stdout holds the one JSON line and nothing else."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--chains", "4096", "--transitions", "32",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout[:2000]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["ess_per_sec"] > 0 and "roofline" in j
+    assert "finished optimization" in r.stderr          # the flow's chatter went there
