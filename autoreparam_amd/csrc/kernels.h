@@ -876,6 +876,19 @@ ARP_DEV float chain_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// The same sum over the chains of ONE 16-lane row only (K = 16: a row is a chain, nothing to add): every lane of the row
+// ends with its slot's total.  The VI kernel leaves the rows' partial sums in LDS and the parameter's owner adds them in
+// row order -- per value one or two DPP adds and a store, where the butterfly over the whole wave cost ten instructions.
+template <int K>
+ARP_DEV float row_sum(float v) {
+  static_assert(K == 1 || K == 2 || K == 4 || K == 8 || K == 16, "lanes per chain");
+  if (K <= 1) v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+  if (K <= 2) v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  if (K <= 4) v += dpp_mov<0x124>(v);    // row_ror:4
+  if (K <= 8) v += dpp_mov<0x128>(v);    // row_ror:8
+  return v;
+}
+
 // d/dx log of the reference's --discrete_prior density on a learnable parameter x in (0,1) (main.py:244-253):
 // Mixture(logits (0,5,0); Laplace(0, 0.1), Uniform(0,1), Laplace(1, 0.1))
 ARP_DEV float discrete_prior_dlogp(float x) {
@@ -952,9 +965,17 @@ __global__ __launch_bounds__(B) void vi_kernel(
   constexpr int NDW = (ND + 1) / 2 * 2;        // 32-bit words a lane consumes per draw
   static_assert(B % 64 == 0 && B % K == 0 && kViBlock % B == 0, "workgroup shape");
   constexpr int DM = lane_vi_dmax<Lane>::value;
-  __shared__ float s_loc[DM], s_sig[DM], s_lsig[DM], s_a[DM], s_b[DM];
-  // every wave's partial sums (sum g, sum g*eps, sum dlogp/da, sum dlogp/db), added up in wave order
-  __shared__ float s_part[W][4][DM];
+  __shared__ float s_sig[DM], s_a[DM], s_b[DM];
+  // Lane layout of a parameter row: element i of the lane with slot s sits at position i K + s (a replicated global K
+  // times; positions of padding slices hold zeros for ever).  A lane reads {loc, sigma, log sigma, 1} of its element with
+  // one ds_read_b128 at an immediate offset and writes its sums the same way: no per-element index arithmetic, and no
+  // per-element validity masks (German credit has 32 of them: held in scalar registers they spilled).
+  constexpr int PM = ND * K;
+  constexpr int NR = W * 4;                  // 16-lane rows of the workgroup
+  __shared__ float4 s_row[PM];
+  __shared__ int s_pos[DM];                  // position of parameter d in that layout
+  // every row's partial sums (sum g, sum g*eps, sum dlogp/da, sum dlogp/db), added up in row order
+  __shared__ float s_part[NR][4][PM];
   __shared__ float s_elbo_w[W], s_pri[DM];
   __shared__ float s_elbo, s_prior;
   __shared__ float s_red[2][DM];   // shared (a, b) groups: per-element gradient contributions, then the leaders' values
@@ -1009,6 +1030,25 @@ __global__ __launch_bounds__(B) void vi_kernel(
   lane_tables(M, A, s_lane_tab);
   M.init(A, s_a, s_b, slot);
   if constexpr (lane_has_part<Lane>::value) { M.set_part(rp, P.R); M.make_resident(); }
+  for (int e = tid; e < PM; e += B) s_row[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < K) {                                       // the first chain's lanes write the map (every chain has the same)
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      if (i < NG) { if (slot == 0) s_pos[M.gg(i)] = -(i * K) - 1; }        // negative: replicated over the K slots
+      else if (M.lvalid(i - NG)) s_pos[M.lidx(i - NG)] = i * K + slot;
+    }
+  }
+  __syncthreads();
+  int lpos[PPT], lrep[PPT];
+#pragma unroll
+  for (int u = 0; u < PPT; ++u) {
+    const int d = tid + u * B;
+    const int e = d < D ? s_pos[d] : 0;
+    lpos[u] = e < 0 ? -(e + 1) : e;
+    lrep[u] = e < 0 ? K : 1;
+  }
+  float* const my_part = &s_part[tid >> 4][0][tid & 15];      // lanes of a row's first chain: (tid & 15) < K
+  const bool row_writer = (tid & 15) < K;
   // one stream per (learning rate, stream of the layout, slot)
   Rng rng = rng_seed(P.seed ^ 0x5649564956495649ull, ((unsigned long long)lr_i << 32) | (unsigned)(s0 % cpp),
                      (uint32_t)slot, (uint32_t)K);
@@ -1031,7 +1071,9 @@ __global__ __launch_bounds__(B) void vi_kernel(
       const int d = tid + u * B;
       if (d < D) {
         float sp = rho[u] > 20.0f ? rho[u] : fast_log(1.0f + fast_exp(rho[u]));   // softplus
-        s_loc[d] = loc[u]; s_sig[d] = sp; s_lsig[d] = fast_log(sp);
+        s_sig[d] = sp;
+        const float4 r4 = make_float4(loc[u], sp, fast_log(sp), 1.0f);
+        for (int j = 0; j < lrep[u]; ++j) s_row[lpos[u] + j] = r4;
         if (P.learn_a) {
           float a = sigmoidf_(w[u]);
           s_a[d] = a;
@@ -1088,19 +1130,18 @@ __global__ __launch_bounds__(B) void vi_kernel(
       VI_T(1);
       float ent = 0.f, entg = 0.f;
       {
-        float lc[ND], sg_[ND], ls[ND];
-        load_row(M, s_loc, lc); load_row(M, s_sig, sg_); load_row(M, s_lsig, ls);
+        const float4* const rowp = s_row + slot;
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
+          const float4 r4 = rowp[i * K];          // {loc, sigma, log sigma, 1}, all zero in a padding slice
           if (i < NG) {
             eps[i] = group_bcast0<K>(eps[i], slot);
-            entg += fmaf(0.5f * eps[i], eps[i], ls[i]);
+            entg += fmaf(0.5f * eps[i], eps[i], r4.z);
           } else {
-            bool ok = M.lvalid(i - NG);
-            eps[i] = ok ? eps[i] : 0.f;
-            ent += ok ? fmaf(0.5f * eps[i], eps[i], ls[i]) : 0.f;
+            eps[i] *= r4.w;
+            ent += fmaf(0.5f * eps[i], eps[i], r4.z);
           }
-          z[i] = fmaf(sg_[i], eps[i], lc[i]);
+          z[i] = fmaf(r4.y, eps[i], r4.x);
         }
       }
       VI_T(2);
@@ -1141,17 +1182,14 @@ __global__ __launch_bounds__(B) void vi_kernel(
     if (single) { if (SP > 1) rng_jump(rng, jump_step); }
     else for (int n = (SP - pos) * NDW; n > 0; --n) rng_next(rng);
     VI_T(1);
-    // reduce over the chains of the wave, then over waves through LDS
+    // sums over the chains of each 16-lane row in registers; the rows' partial sums go to LDS in the lane layout
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (k >= nq) break;
 #pragma unroll
       for (int i = 0; i < ND; ++i) {
-        float v = chain_sum<K>(acc[k][i]);
-        if ((tid & 63) < K) {    // every element d < D is written by exactly one lane of every wave
-          if (i < NG) { if (slot == 0) s_part[tid >> 6][k][M.gg(i)] = v; }
-          else if (M.lvalid(i - NG)) s_part[tid >> 6][k][M.lidx(i - NG)] = v;
-        }
+        const float v = row_sum<K>(acc[k][i]);
+        if (row_writer) my_part[k * PM + i * K] = v;
       }
     }
     elbo = chain_sum<K>(elbo);
@@ -1167,9 +1205,9 @@ __global__ __launch_bounds__(B) void vi_kernel(
       for (int k = 0; k < 4; ++k) {
         float t = 0.f;
         if (d < D && k < nq) {
-          t = s_part[0][k][d];
+          t = s_part[0][k][lpos[u]];
 #pragma unroll
-          for (int wv = 1; wv < W; ++wv) t += s_part[wv][k][d];
+          for (int r = 1; r < NR; ++r) t += s_part[r][k][lpos[u]];
         }
         tot[u][k] = t;
       }
