@@ -1182,14 +1182,28 @@ __global__ __launch_bounds__(B) void vi_kernel(
     if (single) { if (SP > 1) rng_jump(rng, jump_step); }
     else for (int n = (SP - pos) * NDW; n > 0; --n) rng_next(rng);
     VI_T(1);
-    // sums over the chains of each 16-lane row in registers; the rows' partial sums go to LDS in the lane layout
+    // sums over the chains of each 16-lane row in registers (all lanes), then -- under ONE branch, not one execution mask
+    // per element -- the rows' partial sums go to LDS in the lane layout
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k >= nq) break;
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-      for (int i = 0; i < ND; ++i) {
-        const float v = row_sum<K>(acc[k][i]);
-        if (row_writer) my_part[k * PM + i * K] = v;
+      for (int i = 0; i < ND; ++i) acc[k][i] = row_sum<K>(acc[k][i]);
+    if (P.learn_a) {
+#pragma unroll
+      for (int k = 2; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) acc[k][i] = row_sum<K>(acc[k][i]);
+    }
+    if (row_writer) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) my_part[k * PM + i * K] = acc[k][i];
+      if (P.learn_a) {
+#pragma unroll
+        for (int k = 2; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < ND; ++i) my_part[k * PM + i * K] = acc[k][i];
       }
     }
     elbo = chain_sum<K>(elbo);
