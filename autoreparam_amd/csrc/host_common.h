@@ -163,7 +163,9 @@ inline bool stats_lds_enabled() {
 template <int K, int NL>
 LaneOps radon_lane_ops() {
   LaneOps o = Launch<RadonLane<K, NL>>::ops();
-  if constexpr (K >= 4) {
+  // (the packed layer wants at least two county pairs per lane: the 13- and 15-county states at 8 / 16 lanes per chain run
+  // on the generic kernels)
+  if constexpr (K >= 4 && NL >= 4) {
     using T = RadonPk<K, NL>;
     // a run that accumulates statistics takes the instantiation with the accumulators in LDS when they fit
     constexpr bool SL = PkBlock<T>::kStatsFit;

@@ -69,6 +69,7 @@ mcmc = tfp.mcmc
 # this repository's test names -> the reference's (model, dataset)
 REF_NAME = {"8schools": ("8schools", None), "radon_MN": ("radon", "MN"), "radon_PA": ("radon", "PA"),
             "radon_IN": ("radon", "IN"), "radon_MO": ("radon", "MO"), "radon_ND": ("radon", "ND"),
+            "radon_MA": ("radon", "MA"), "radon_AZ": ("radon", "AZ"), "radon_sd_AZ": ("radon_stddvs", "AZ"),
             "german": ("german_credit_lognormalcentered", None), "radon_sd_MN": ("radon_stddvs", "MN"),
             "funnel": ("neals_funnel", None), "election": ("election", None), "electric": ("electric", None),
             "time_series": ("time_series", None)}

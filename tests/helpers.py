@@ -10,6 +10,9 @@ MODEL_SPECS = {
     "radon_IN": lambda: models._spec_radon("IN"),
     "radon_MO": lambda: models._spec_radon("MO"),
     "radon_ND": lambda: models._spec_radon("ND"),
+    "radon_MA": lambda: models._spec_radon("MA"),          # 13 counties
+    "radon_AZ": lambda: models._spec_radon("AZ"),          # 15 counties
+    "radon_sd_AZ": lambda: models._spec_radon_stddvs("AZ"),
     "german": lambda: models._spec_german(),
     "radon_sd_MN": lambda: models._spec_radon_stddvs("MN"),
     "funnel": lambda: models._spec_funnel(),

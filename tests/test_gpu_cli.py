@@ -184,6 +184,37 @@ def test_config3_full_size_german_dvip(gpu, tmp_path):
     assert tr["beta"].shape == (S, 4, 62)
 
 
+@pytest.mark.parametrize("ds", ["MA", "AZ"])
+def test_small_radon_states_through_the_cli(gpu, oracle_lib, tmp_path, ds):
+    """`--model=radon --dataset=MA | AZ` (README.md:22; 13 and 15 counties): VI, one tuning run and a sampling run per method,
+    the interleaved sampler included; its pooled posterior means against the closed form (radon is Gaussian)."""
+    import helpers
+    d = str(tmp_path)
+    base = ["--model=radon", "--dataset=" + ds, "--results_dir=" + d, "--num_chains=2048", "--seed=3"]
+    short = ["--num_samples=400", "--num_burnin_steps=600", "--num_adaptation_steps=400", "--num_chains_to_save=2048"]
+    for m in ("CP", "NCP"):
+        _run(base + ["--inference=VI", "--method=" + m, "--num_optimization_steps=900"])
+        _run(base + ["--inference=HMCtuning", "--method=" + m, "--num_leapfrog_steps=4"] + short)
+    res = _run(base + ["--inference=HMC", "--method=CP"] + short)
+    assert res[0] > 0 and 50 < res[2] < 99
+    res = _run(base + ["--inference=HMC", "--method=i"] + short)
+    assert np.isfinite(res[0]) and res[0] > 0
+    r = json.load(open(os.path.join(d, "i_tied.json")))
+    assert len(r["ess_min"]) == 1 and r["acceptance_rate_cp"][0] > 40 and r["acceptance_rate_ncp"][0] > 40
+    sp = helpers.spec("radon_" + ds)
+    orc = oracle_lib.OracleModel(sp)
+    a, b = helpers.params(sp, "CP")
+    _, g0 = orc.logp_grad(np.zeros((1, sp.D)), a, b)
+    _, gI = orc.logp_grad(np.eye(sp.D), a, b)
+    P = -(gI - g0)
+    mean = np.linalg.solve(P, g0[0]); sd = np.sqrt(np.diag(np.linalg.inv(P)))
+    tr = np.load(os.path.join(d, "i_tied_traces.npz"))
+    got = np.concatenate([tr[k].reshape(tr[k].shape[0], tr[k].shape[1], -1) for k in ("mua", "b1", "b2", "m")], axis=2)
+    assert got.shape == (400, 2048, sp.D)
+    m = got.mean(axis=(0, 1))
+    assert np.abs((m - mean) / sd).max() < 0.04, np.abs((m - mean) / sd).max()      # ~ 2 048 x 400 correlated samples
+
+
 def test_config5_full_size_election_cvip(gpu, tmp_path):
     """BASELINE configs[4] at its real size through the CLI flow: election, cVIP fit (the learned continuous parameterisation) ->
     HMCtuning sweep over the leapfrog count -> HMC with dual averaging on 131 072 chains with the tuned count, statistics

@@ -167,9 +167,10 @@ def test_german_math_option(oracle_lib, gpu):
     assert np.abs(g2.cpu().numpy() - g2o).max() <= 2e-6 * np.abs(g2o).max()
 
 
-@pytest.mark.parametrize("ds", ["IN", "MO", "ND"])
+@pytest.mark.parametrize("ds", ["IN", "MO", "ND", "MA", "AZ"])
 def test_other_radon_datasets(oracle_lib, gpu, ds):
-    """The reference's remaining radon data sets (91, 115 and 53 counties; main.py --dataset): every lanes-per-chain split
+    """The reference's remaining radon data sets (91, 115, 53, 13 and 15 counties: every state of srrs2.dat that README.md:22
+    lists; main.py --dataset; the two small ones run the generic lane kernels at 8 / 16 lanes per chain): every lanes-per-chain split
     the library instantiates for them against the float64 oracle, the library's own choice included, and a short
     interleaved run against the float32 oracle."""
     import torch
@@ -206,6 +207,35 @@ def test_other_radon_datasets(oracle_lib, gpu, ds):
     err = np.abs(r["st"].q.cpu().numpy() - r["so"]["q"]).max(axis=1) / r["scale"]
     assert (err[ok] <= 2e-4).all(), np.sort(err[ok])[-5:]
     assert np.array_equal(r["st"].accept_count.cpu().numpy()[ok], r["so"]["accept_count"][ok])
+
+
+def test_radon_stddvs_on_a_small_state(oracle_lib, gpu):
+    """radon_stddvs --dataset=AZ (15 counties: one or two per lane): density and gradient at both lane splits against the
+    float64 oracle, and a VI fit against the oracle's timeline (the widest split, one county per lane)."""
+    import torch
+    from autoreparam_amd import engine
+    sp = helpers.spec("radon_sd_AZ")
+    eng = engine.Engine(sp, gpu)
+    orc = oracle_lib.OracleModel(sp)
+    x = helpers.states(sp, 70, seed=3)
+    for kind in ("CP", "NCP", "VIP"):
+        a, b = helpers.params(sp, kind)
+        eng.set_param(0, (a, b))
+        lp_o, g_o = orc.logp_grad(x, a, b, dtype=np.float64)
+        for lanes in (0, 8, 16):
+            lp, g = eng.logp_grad(x, which=0, lanes=lanes)
+            assert np.abs(lp.cpu().numpy() - lp_o).max() <= 2e-6 * max(1.0, np.abs(lp_o).max()) + 1e-3, (lanes, kind)
+            assert np.abs(g.cpu().numpy() - g_o).max() <= _tol(g_o), (lanes, kind)
+    a, b = helpers.params(sp, "NCP")
+    eng.set_param(0, (a, b))
+    rs = np.random.RandomState(0)
+    loc0 = (1e-2 * rs.randn(1, sp.D)).astype(np.float32); rho0 = np.full((1, sp.D), -2.0, np.float32)
+    loc = torch.as_tensor(loc0.copy(), device=gpu); rho = torch.as_tensor(rho0.copy(), device=gpu)
+    elbo = eng.vi_run([0.05], loc, rho, 80, 256, seed=4).cpu().numpy()
+    lo, ro = loc0.copy(), rho0.copy()
+    elbo_o = orc.vi_run(a, b, [0.05], lo, ro, None, 80, 256, seed=4, lanes=16)
+    np.testing.assert_allclose(elbo[:, :5], elbo_o[:, :5], rtol=2e-5, atol=2e-2)
+    np.testing.assert_allclose(elbo[:, -16:].mean(1), elbo_o[:, -16:].mean(1), rtol=2e-3, atol=0.5)
 
 
 def test_german_bf16x3_on_adversarial_design_matrices(oracle_lib, gpu):

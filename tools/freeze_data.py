@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--out", default=OUT)
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
-    for code in ("MN", "PA", "IN", "MO", "ND"):
+    for code in ("MN", "PA", "IN", "MO", "ND", "MA", "AZ"):      # the states of srrs2.dat (README.md:22: MA, IN, PA, MO, ND, AZ; MN the default)
         try:
             d = radon(code)
         except Exception as e:  # states whose county tables do not join
