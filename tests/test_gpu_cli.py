@@ -215,6 +215,20 @@ def test_small_radon_states_through_the_cli(gpu, oracle_lib, tmp_path, ds):
     assert np.abs((m - mean) / sd).max() < 0.04, np.abs((m - mean) / sd).max()      # ~ 2 048 x 400 correlated samples
 
 
+def test_radon_stddvs_small_state_through_the_cli(gpu, tmp_path):
+    """`--model=radon_stddvs --dataset=AZ`: the cVIP fit, the thresholded dVIP run and the interleaved sampler."""
+    d = str(tmp_path)
+    base = ["--model=radon_stddvs", "--dataset=AZ", "--results_dir=" + d, "--num_chains=512", "--seed=5"]
+    short = ["--num_samples=200", "--num_burnin_steps=400", "--num_adaptation_steps=300", "--num_leapfrog_steps=4"]
+    for m in ("CP", "NCP", "cVIP", "dVIP"):
+        _run(base + ["--inference=VI", "--method=" + m, "--num_optimization_steps=600"])
+    for m in ("CP", "NCP"):
+        _run(base + ["--inference=HMCtuning", "--method=" + m] + short)
+    for m in ("dVIP", "i"):
+        res = _run(base + ["--inference=HMC", "--method=" + m] + short)
+        assert np.isfinite(res[0]) and res[0] > 0
+
+
 def test_config5_full_size_election_cvip(gpu, tmp_path):
     """BASELINE configs[4] at its real size through the CLI flow: election, cVIP fit (the learned continuous parameterisation) ->
     HMCtuning sweep over the leapfrog count -> HMC with dual averaging on 131 072 chains with the tuned count, statistics
