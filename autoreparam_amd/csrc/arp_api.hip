@@ -491,6 +491,7 @@ int arp_model_destroy(arp_model* m) {
   if (m->dev_tables) (void)hipFree(m->dev_tables);
   for (int w = 0; w < 2; ++w) if (m->dev_ab[w]) (void)hipFree(m->dev_ab[w]);
   if (m->vi_ws) (void)hipFree(m->vi_ws);
+  if (m->seg_flags) (void)hipFree(m->seg_flags);
   delete m;
   return 0;
 }
@@ -641,6 +642,7 @@ static int fill_params(arp_model* m, const arp_hmc_config* cfg, const arp_hmc_io
   P.trace_chains = (cfg->trace_chains > 0 && cfg->trace_chains < cfg->n_chains) ? cfg->trace_chains : cfg->n_chains;
   P.L1 = 0; P.adapt1 = nullptr; P.accept_count1 = nullptr; P.eps0_1 = nullptr; P.trace_accept1 = nullptr;
   P.rec_accept1 = nullptr;
+  P.segs = 1; P.seg_len = cfg->n_steps; P.seg_blocks = 0; P.seg_epoch = 0; P.seg_flags = nullptr;
   return 0;
 }
 
@@ -682,7 +684,45 @@ int arp_interleaved_run(arp_model* m, const arp_hmc_config* cfg, int n_leapfrog_
   const LaneOps* o = select_ops(m, cfg->lanes_per_chain, cfg->n_chains);
   if (!o) return 1;
   auto fn = o->interleaved;
-  if (m->param_kind[0] == kModeCP && m->param_kind[1] == kModeNCP && o->interleaved_cp_ncp) fn = o->interleaved_cp_ncp;
+  if (m->param_kind[0] == kModeCP && m->param_kind[1] == kModeNCP && o->interleaved_cp_ncp) {
+    fn = o->interleaved_cp_ncp;
+    // Relay (radon_fast.h: radon_interleaved_kernel): a launch whose workgroups are only a few rounds on the device (two
+    // workgroups per CU at a time) is cut into segments of steps, so that a CU that is free takes the next segment in
+    // line instead of idling behind a slower one (profiles/r05_relay_segments.txt).  The gradient has to travel with the
+    // state (k0.grad), as it does between launches.
+    const long long blocks = ((long long)cfg->n_chains * o->K + kBlock - 1) / kBlock;
+    static thread_local int cus_of[64] = {0};               // CUs per device, asked once per thread and device
+    int& cus = cus_of[m->device & 63];
+    if (cus <= 0) {
+      hipDeviceProp_t prop;
+      ARP_HIP_OK(hipGetDeviceProperties(&prop, m->device));
+      cus = prop.multiProcessorCount;
+    }
+    const long long slots = 2LL * cus;                      // two 256-register workgroups per CU
+    // (less than one round: every workgroup is resident from the start and a block's segments run one after the other anyway --
+    // measured neutral; at one round and more: 32 768 chains - 6.4 %, 49 152 - 6.5 %, 65 536 - 5.3 % with eight segments (- 4.5 %
+    // with four), 131 072 - 2.4 %, 262 144 - 0.7 % of the launch's time)
+    int segs = (io->k0.grad && blocks >= slots) ? (cfg->n_steps >= 512 ? 8 : (cfg->n_steps >= 256 ? 4 : 1)) : 1;
+    int dbg = 0;
+    if (debug_int("ARP_SEGMENTS", &dbg) && dbg >= 1 && dbg <= 8 && io->k0.grad) segs = dbg;      // experiments (ARP_DEBUG=1 only)
+    if (segs > 1) {
+      if (m->seg_flags_n < blocks) {
+        if (m->seg_flags) { ARP_HIP_OK(hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(m->seg_flags); m->seg_flags = nullptr; m->seg_flags_n = 0; }
+        ARP_HIP_OK(hipMalloc(&m->seg_flags, (size_t)blocks * sizeof(unsigned)));
+        ARP_HIP_OK(hipMemset(m->seg_flags, 0, (size_t)blocks * sizeof(unsigned)));
+        m->seg_flags_n = (int)blocks;
+        m->seg_launch = 0;
+      }
+      m->seg_launch += 1;
+      if (m->seg_launch >= (1u << 27)) {            // the epochs would wrap: start over from clean flags
+        ARP_HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+        ARP_HIP_OK(hipMemset(m->seg_flags, 0, (size_t)m->seg_flags_n * sizeof(unsigned)));
+        m->seg_launch = 1;
+      }
+      P.segs = segs; P.seg_len = (cfg->n_steps + segs - 1) / segs; P.seg_blocks = (int)blocks;
+      P.seg_epoch = m->seg_launch * 16u; P.seg_flags = m->seg_flags;
+    }
+  }
   fn(family_args(m), m->dev_ab[0], m->dev_ab[0] + m->D, m->dev_ab[1], m->dev_ab[1] + m->D, P, (hipStream_t)stream);
   ARP_HIP_OK(hipGetLastError());
   return 0;

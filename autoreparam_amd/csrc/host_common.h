@@ -189,7 +189,7 @@ LaneOps radon_lane_ops() {
     o.hmc_b1 = o.hmc_vip_pk;
     o.interleaved_cp_ncp = [](const void* args, const float*, const float*, const float*, const float*,
                               const HmcParams& P, hipStream_t s) {
-      const dim3 g(Launch<RadonLane<K, NL>>::blocks(P.C));
+      const dim3 g(Launch<RadonLane<K, NL>>::blocks(P.C) * (P.segs > 1 ? P.segs : 1));
       if (SL && P.stats && stats_lds_enabled()) hipLaunchKernelGGL((radon_interleaved_kernel<T, SL>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, P);
       else hipLaunchKernelGGL((radon_interleaved_kernel<T>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, P);
     };
@@ -268,6 +268,10 @@ struct arp_model {
   // hand-off workspace of the VI kernel (granules + the error flag in its first 256 bytes), grown on demand
   void* vi_ws = nullptr;
   size_t vi_ws_bytes = 0;
+  // relay flags of the segmented interleaved launch (one word per chain block; arp_api.hip: arp_interleaved_run)
+  unsigned* seg_flags = nullptr;
+  int seg_flags_n = 0;
+  unsigned seg_launch = 0;
   double const_base = 0.0;                       // parameterisation independent part of the dropped constant
   std::vector<std::pair<int, double>> top_scale; // (flattened index, log prior scale) of top-level latents
 };

@@ -35,6 +35,12 @@ struct HmcParams {
   // interleaved kernel only: second transition kernel (parameterisation 1)
   int L1;
   float* adapt1; uint32_t* accept_count1; const float* eps0_1; uint8_t* trace_accept1; uint32_t* rec_accept1;
+  // Relay (radon_fast.h: radon_interleaved_kernel): the launch's n_steps cut into `segs` segments of seg_len steps, a workgroup
+  // per (segment, chain block); segment s of a block starts when seg_flags[block] == seg_epoch + s.  segs <= 1: one workgroup
+  // per block takes all the steps.
+  int segs, seg_len, seg_blocks;
+  unsigned seg_epoch;
+  unsigned* seg_flags;
 };
 
 

@@ -568,3 +568,53 @@ def test_in_kernel_statistics_interleaved(oracle_lib, gpu):
         x = tr.double(); scale = x.abs().amax(dim=0) + 1
         assert ((mean - x.mean(dim=0)).abs() / scale).max() < 2e-6
         assert ((var - x.var(dim=0, unbiased=True)).abs() / (scale * scale)).max() < 2e-6
+
+
+@pytest.mark.parametrize("chains,lanes", [(65536, 0), (8192, 0), (1000, 4), (4097, 8)])
+def test_relay_segments_equal_the_unsegmented_launch(gpu, monkeypatch, chains, lanes):
+    """radon's interleaved launch cut into segments of steps (a workgroup per segment and chain block, the state relayed through
+    HBM inside the launch; arp_api.hip: arp_interleaved_run, radon_fast.h): states, gradients, adaptation, counters, trace
+    rows, acceptance flags and in-kernel statistics bit for bit those of the launch with one workgroup per block -- for the
+    library's own choice (4 or 8 segments where the blocks are a round or more, none below), for 2, 3 and 8 segments, with steps that do not divide evenly and a
+    burn-in that ends inside a segment, twice in a row (the flags' epochs)."""
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec("radon_PA")
+    eng = _eng("radon_PA", gpu)
+    eng.set_param(0, "CP"); eng.set_param(1, "NCP")
+    q0 = helpers.states(sp, chains, seed=2, scale=0.1)
+    e = np.full(sp.D, 0.06, np.float32); e[2] = 0.015
+    monkeypatch.setenv("ARP_DEBUG", "1")
+
+    def run(segs, T, with_stats):
+        if segs is None:
+            monkeypatch.delenv("ARP_SEGMENTS", raising=False)
+        else:
+            monkeypatch.setenv("ARP_SEGMENTS", str(segs))
+        st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+        n_burn = 101
+        S = 2 * ((2 * T - n_burn) // 2 // 2 + 1)
+        tr = torch.zeros(S, chains, sp.D, device=gpu)
+        a0 = torch.zeros(S, chains, dtype=torch.uint8, device=gpu); a1 = torch.zeros_like(a0)
+        extra = dict(stats=torch.zeros(6, chains, sp.D, device=gpu), stats_batch=3, n_samples=S) if with_stats else {}
+        for _ in range(2):          # two launches: the second starts from the first one's state (step_base > 0)
+            eng.interleaved_run(st, e, e, 4, 4, T, seed=9, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=150, n_burnin=n_burn, thin=2,
+                                trace=tr, trace_accept0=a0, trace_accept1=a1, trace_centered=False, lanes=lanes, **extra)
+        torch.cuda.synchronize()
+        out = [st.q, st.grad, st.logp, st.adapt, st.adapt1, st.accept_count, st.accept_count1, st.rng, tr, a0, a1]
+        if with_stats:
+            out.append(extra["stats"])
+        return [t.cpu().numpy() for t in out]
+
+    for T, with_stats in ((333, False), (256, True), (520, False)):     # library's choice: 4, 4 and 8 segments
+        ref = run(1, T, with_stats)
+        for segs in (None, 2, 3, 8):
+            got = run(segs, T, with_stats)
+            for k, (x, y) in enumerate(zip(ref[:11], got[:11])):
+                assert np.array_equal(x, y, equal_nan=True), (segs, T, with_stats, k)
+            if with_stats:
+                # the accumulators fold their partial batch where a segment ends, as they do where a launch ends: the sums
+                # are the same numbers added in another grouping (float32 rounding of the sums)
+                n = ref[8].shape[0]
+                for a_, b_ in zip(engine.stats_summary(torch.as_tensor(ref[11]), n, 3)[:2], engine.stats_summary(torch.as_tensor(got[11]), n, 3)[:2]):
+                    scale = a_.abs().max(dim=0).values + 1e-3
+                    assert ((a_ - b_).abs() / scale).max() < 1e-5, (segs, T)
