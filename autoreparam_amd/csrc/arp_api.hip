@@ -596,6 +596,36 @@ static int check_adapt(const arp_hmc_config* cfg) {
   return 0;
 }
 
+// Relay segments (kernels.h: relay_begin; host_common.h: relay_plan): a launch's steps cut into segments that are handed
+// from workgroup to workgroup inside the launch, so that a CU that is free takes the next (segment, chain block) in line
+// instead of idling behind a slower one (profiles/r05_relay_segments.txt).  This gives the launcher what it needs: one
+// flag word per chain block on the handle, an epoch that makes this launch's flag values its own (no clearing between
+// launches), and `segs` = -1 (the launcher decides with its kernel's occupancy), a forced count (ARP_DEBUG=1
+// ARP_SEGMENTS=n) or 1 (`allowed` false).
+static int relay_prepare(arp_model* m, const arp_hmc_config* cfg, int K, bool allowed, hipStream_t stream, HmcParams* P) {
+  P->segs = 1; P->seg_len = cfg->n_steps; P->seg_blocks = 0; P->seg_epoch = 0; P->seg_flags = nullptr;
+  if (!allowed || cfg->n_steps < 256) return 0;
+  int segs = -1, dbg = 0;
+  if (debug_int("ARP_SEGMENTS", &dbg) && dbg >= 1 && dbg <= 8) segs = dbg;
+  if (segs == 1) return 0;
+  const long long blocks = ((long long)cfg->n_chains * K + kBlock - 1) / kBlock;
+  if (m->seg_flags_n < blocks) {
+    if (m->seg_flags) { ARP_HIP_OK(hipStreamSynchronize(stream)); (void)hipFree(m->seg_flags); m->seg_flags = nullptr; m->seg_flags_n = 0; }
+    ARP_HIP_OK(hipMalloc(&m->seg_flags, (size_t)blocks * sizeof(unsigned)));
+    ARP_HIP_OK(hipMemset(m->seg_flags, 0, (size_t)blocks * sizeof(unsigned)));
+    m->seg_flags_n = (int)blocks;
+    m->seg_launch = 0;
+  }
+  m->seg_launch += 1;
+  if (m->seg_launch >= (1u << 27)) {            // the epochs would wrap: start over from clean flags
+    ARP_HIP_OK(hipStreamSynchronize(stream));
+    ARP_HIP_OK(hipMemset(m->seg_flags, 0, (size_t)m->seg_flags_n * sizeof(unsigned)));
+    m->seg_launch = 1;
+  }
+  P->segs = segs; P->seg_blocks = m->seg_flags_n; P->seg_epoch = m->seg_launch * 16u; P->seg_flags = m->seg_flags;
+  return 0;
+}
+
 static int fill_params(arp_model* m, const arp_hmc_config* cfg, const arp_hmc_io* io, bool need_cache, HmcParams* Pp) {
   if (cfg->n_chains <= 0 || cfg->n_leapfrog <= 0 || cfg->n_steps < 0 || cfg->thin <= 0 || cfg->step_base < 0) {
     set_error("n_chains, n_leapfrog, thin must be positive and n_steps, step_base non-negative");
@@ -658,6 +688,7 @@ int arp_hmc_run(arp_model* m, int which, const arp_hmc_config* cfg, const arp_hm
   if (m->param_kind[which] == kModeNCP && o->hmc_ncp) fn = o->hmc_ncp;
   if (m->param_kind[which] == kModeB1 && o->hmc_b1) fn = o->hmc_b1;
   if (m->param_kind[which] == kModeVIP && o->hmc_vip_pk) fn = o->hmc_vip_pk;
+  if (relay_prepare(m, cfg, o->K, true, (hipStream_t)stream, &P)) return 1;
   fn(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, (hipStream_t)stream);
   ARP_HIP_OK(hipGetLastError());
   return 0;
@@ -684,45 +715,9 @@ int arp_interleaved_run(arp_model* m, const arp_hmc_config* cfg, int n_leapfrog_
   const LaneOps* o = select_ops(m, cfg->lanes_per_chain, cfg->n_chains);
   if (!o) return 1;
   auto fn = o->interleaved;
-  if (m->param_kind[0] == kModeCP && m->param_kind[1] == kModeNCP && o->interleaved_cp_ncp) {
-    fn = o->interleaved_cp_ncp;
-    // Relay (radon_fast.h: radon_interleaved_kernel): a launch whose workgroups are only a few rounds on the device (two
-    // workgroups per CU at a time) is cut into segments of steps, so that a CU that is free takes the next segment in
-    // line instead of idling behind a slower one (profiles/r05_relay_segments.txt).  The gradient has to travel with the
-    // state (k0.grad), as it does between launches.
-    const long long blocks = ((long long)cfg->n_chains * o->K + kBlock - 1) / kBlock;
-    static thread_local int cus_of[64] = {0};               // CUs per device, asked once per thread and device
-    int& cus = cus_of[m->device & 63];
-    if (cus <= 0) {
-      hipDeviceProp_t prop;
-      ARP_HIP_OK(hipGetDeviceProperties(&prop, m->device));
-      cus = prop.multiProcessorCount;
-    }
-    const long long slots = 2LL * cus;                      // two 256-register workgroups per CU
-    // (less than one round: every workgroup is resident from the start and a block's segments run one after the other anyway --
-    // measured neutral; at one round and more: 32 768 chains - 6.4 %, 49 152 - 6.5 %, 65 536 - 5.3 % with eight segments (- 4.5 %
-    // with four), 131 072 - 2.4 %, 262 144 - 0.7 % of the launch's time)
-    int segs = (io->k0.grad && blocks >= slots) ? (cfg->n_steps >= 512 ? 8 : (cfg->n_steps >= 256 ? 4 : 1)) : 1;
-    int dbg = 0;
-    if (debug_int("ARP_SEGMENTS", &dbg) && dbg >= 1 && dbg <= 8 && io->k0.grad) segs = dbg;      // experiments (ARP_DEBUG=1 only)
-    if (segs > 1) {
-      if (m->seg_flags_n < blocks) {
-        if (m->seg_flags) { ARP_HIP_OK(hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(m->seg_flags); m->seg_flags = nullptr; m->seg_flags_n = 0; }
-        ARP_HIP_OK(hipMalloc(&m->seg_flags, (size_t)blocks * sizeof(unsigned)));
-        ARP_HIP_OK(hipMemset(m->seg_flags, 0, (size_t)blocks * sizeof(unsigned)));
-        m->seg_flags_n = (int)blocks;
-        m->seg_launch = 0;
-      }
-      m->seg_launch += 1;
-      if (m->seg_launch >= (1u << 27)) {            // the epochs would wrap: start over from clean flags
-        ARP_HIP_OK(hipStreamSynchronize((hipStream_t)stream));
-        ARP_HIP_OK(hipMemset(m->seg_flags, 0, (size_t)m->seg_flags_n * sizeof(unsigned)));
-        m->seg_launch = 1;
-      }
-      P.segs = segs; P.seg_len = (cfg->n_steps + segs - 1) / segs; P.seg_blocks = (int)blocks;
-      P.seg_epoch = m->seg_launch * 16u; P.seg_flags = m->seg_flags;
-    }
-  }
+  if (m->param_kind[0] == kModeCP && m->param_kind[1] == kModeNCP && o->interleaved_cp_ncp) fn = o->interleaved_cp_ncp;
+  // (kernels that carry the gradient from step to step need it to travel with the state, as it does between launches)
+  if (relay_prepare(m, cfg, o->K, io->k0.grad != nullptr, (hipStream_t)stream, &P)) return 1;
   fn(family_args(m), m->dev_ab[0], m->dev_ab[0] + m->D, m->dev_ab[1], m->dev_ab[1] + m->D, P, (hipStream_t)stream);
   ARP_HIP_OK(hipGetLastError());
   return 0;

@@ -8,6 +8,8 @@
 #include <string>
 #include <type_traits>
 #include <utility>
+#include <map>
+#include <mutex>
 #include <vector>
 #include "../../include/autoreparam.h"
 #include "kernels.h"
@@ -70,6 +72,61 @@ struct LaneOps {
 template <class L, class = void> struct lane_vi_block { static constexpr int value = 128; };
 template <class L> struct lane_vi_block<L, std::void_t<decltype(L::VI_BLOCK)>> { static constexpr int value = L::VI_BLOCK; };
 
+// Relay segments (kernels.h: relay_begin): the API hands a launcher the flags, the epoch and `segs` = -1 (allowed, not yet
+// decided), a forced count (experiments) or 1 (not allowed); the launcher knows its kernel and decides with its occupancy:
+// segments pay where the chain blocks are at least one round of resident workgroups (profiles/r05_relay_segments.txt) --
+// 8 from 512 steps per launch on, 4 from 256.
+inline int relay_device_cus() {
+  static thread_local int cus_of[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  int& cus = cus_of[dev & 63];
+  if (cus <= 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+template <class F>
+inline HmcParams relay_plan(const HmcParams& P, int blocks, F kernel) {
+  HmcParams Q = P;
+  int segs = P.segs;
+  if (segs == -1) {
+    static std::mutex mu;
+    static std::map<const void*, int> occ_of;
+    int occ = 0;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      auto it = occ_of.find((const void*)kernel);
+      if (it == occ_of.end()) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, kBlock, 0) != hipSuccess) occ = 0;
+        occ_of[(const void*)kernel] = occ;
+      } else {
+        occ = it->second;
+      }
+    }
+    const long long slots = (long long)occ * relay_device_cus();
+    segs = (slots > 0 && blocks >= slots) ? (P.n_steps >= 512 ? 8 : (P.n_steps >= 256 ? 4 : 1)) : 1;
+    // one workgroup per CU (German credit and time_series at 4 lanes per chain: 100 - 155 KB of LDS): a workgroup that waits for
+    // its block holds the whole CU, and every hand-over invalidates the XCD's L2 under the tile stream -- measured + 0.1 % and
+    // + 4.2 % (tools/experiments/relay_ab.py), so these launches stay whole
+    if (occ < 2) segs = 1;
+  }
+  if (segs < 1 || !P.seg_flags || blocks > P.seg_blocks) segs = 1;      // (seg_blocks arrives as the flags' capacity)
+  Q.segs = segs;
+  Q.seg_len = (P.n_steps + segs - 1) / segs;
+  Q.seg_blocks = blocks;
+  return Q;
+}
+
+// launch KERNEL over NBLOCKS chain blocks (x the segments relay_plan decides), the kernel's own arguments first, P last
+#define ARP_RELAY_LAUNCH(KERNEL, NBLOCKS, STREAM, P, ...)                                                   \
+  do {                                                                                                      \
+    const HmcParams Q_ = relay_plan(P, NBLOCKS, KERNEL);                                                     \
+    hipLaunchKernelGGL(KERNEL, dim3((NBLOCKS) * Q_.segs), dim3(kBlock), 0, STREAM, __VA_ARGS__, Q_);         \
+  } while (0)
+
 template <class Lane>
 struct Launch {
   static int blocks(int C) { return (int)(((long long)C * Lane::K + kBlock - 1) / kBlock); }
@@ -84,13 +141,15 @@ struct Launch {
                        *(const typename Lane::Args*)args, a, b, dir, in, C, D, out);
   }
   static void hmc(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s) {
-    hipLaunchKernelGGL(hmc_kernel<Lane>, dim3(blocks(P.C)), dim3(kBlock), 0, s,
-                       *(const typename Lane::Args*)args, a, b, P);
+    const HmcParams Q = relay_plan(P, blocks(P.C), hmc_kernel<Lane>);
+    hipLaunchKernelGGL(hmc_kernel<Lane>, dim3(blocks(P.C) * Q.segs), dim3(kBlock), 0, s,
+                       *(const typename Lane::Args*)args, a, b, Q);
   }
   static void interleaved(const void* args, const float* a0, const float* b0, const float* a1, const float* b1,
                           const HmcParams& P, hipStream_t s) {
-    hipLaunchKernelGGL(interleaved_kernel<Lane>, dim3(blocks(P.C)), dim3(kBlock), 0, s,
-                       *(const typename Lane::Args*)args, a0, b0, a1, b1, P);
+    const HmcParams Q = relay_plan(P, blocks(P.C), interleaved_kernel<Lane>);
+    hipLaunchKernelGGL(interleaved_kernel<Lane>, dim3(blocks(P.C) * Q.segs), dim3(kBlock), 0, s,
+                       *(const typename Lane::Args*)args, a0, b0, a1, b1, Q);
   }
   static constexpr int kViB = lane_vi_block<Lane>::value;
   static void vi(const void* args, const float* a, const float* b, const ViParams& P, int n_groups, hipStream_t s) {
@@ -112,13 +171,15 @@ struct Launch {
   }
   template <int MODE>
   static void hmc_m(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s) {
-    hipLaunchKernelGGL((hmc_kernel<Lane, MODE>), dim3(blocks(P.C)), dim3(kBlock), 0, s,
-                       *(const typename Lane::Args*)args, a, b, P);
+    const HmcParams Q = relay_plan(P, blocks(P.C), hmc_kernel<Lane, MODE>);
+    hipLaunchKernelGGL((hmc_kernel<Lane, MODE>), dim3(blocks(P.C) * Q.segs), dim3(kBlock), 0, s,
+                       *(const typename Lane::Args*)args, a, b, Q);
   }
   static void interleaved_m(const void* args, const float* a0, const float* b0, const float* a1, const float* b1,
                             const HmcParams& P, hipStream_t s) {
-    hipLaunchKernelGGL((interleaved_kernel<Lane, kModeCP, kModeNCP>), dim3(blocks(P.C)), dim3(kBlock), 0, s,
-                       *(const typename Lane::Args*)args, a0, b0, a1, b1, P);
+    const HmcParams Q = relay_plan(P, blocks(P.C), interleaved_kernel<Lane, kModeCP, kModeNCP>);
+    hipLaunchKernelGGL((interleaved_kernel<Lane, kModeCP, kModeNCP>), dim3(blocks(P.C) * Q.segs), dim3(kBlock), 0, s,
+                       *(const typename Lane::Args*)args, a0, b0, a1, b1, Q);
   }
   // only the VI launcher (a lane sized for the VI kernel's workgroup; nothing else is instantiated)
   static LaneOps vi_only() {
@@ -170,28 +231,28 @@ LaneOps radon_lane_ops() {
     // a run that accumulates statistics takes the instantiation with the accumulators in LDS when they fit
     constexpr bool SL = PkBlock<T>::kStatsFit;
     o.hmc_cp = [](const void* args, const float*, const float*, const HmcParams& P, hipStream_t s) {
-      const dim3 g(Launch<RadonLane<K, NL>>::blocks(P.C));
-      if (SL && P.stats && stats_lds_enabled()) hipLaunchKernelGGL((pk_hmc_kernel<T, kModeCP, SL>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, nullptr, nullptr, P);
-      else hipLaunchKernelGGL((pk_hmc_kernel<T, kModeCP>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, nullptr, nullptr, P);
+      const int nb = Launch<RadonLane<K, NL>>::blocks(P.C);
+      if (SL && P.stats && stats_lds_enabled()) ARP_RELAY_LAUNCH((pk_hmc_kernel<T, kModeCP, SL>), nb, s, P, *(const RadonArgs*)args, nullptr, nullptr);
+      else ARP_RELAY_LAUNCH((pk_hmc_kernel<T, kModeCP>), nb, s, P, *(const RadonArgs*)args, nullptr, nullptr);
     };
     o.hmc_ncp = [](const void* args, const float*, const float*, const HmcParams& P, hipStream_t s) {
-      const dim3 g(Launch<RadonLane<K, NL>>::blocks(P.C));
-      if (SL && P.stats && stats_lds_enabled()) hipLaunchKernelGGL((pk_hmc_kernel<T, kModeNCP, SL>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, nullptr, nullptr, P);
-      else hipLaunchKernelGGL((pk_hmc_kernel<T, kModeNCP>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, nullptr, nullptr, P);
+      const int nb = Launch<RadonLane<K, NL>>::blocks(P.C);
+      if (SL && P.stats && stats_lds_enabled()) ARP_RELAY_LAUNCH((pk_hmc_kernel<T, kModeNCP, SL>), nb, s, P, *(const RadonArgs*)args, nullptr, nullptr);
+      else ARP_RELAY_LAUNCH((pk_hmc_kernel<T, kModeNCP>), nb, s, P, *(const RadonArgs*)args, nullptr, nullptr);
     };
     // cVIP / dVIP runs: a free per county (m has unit scale, so b is inert: "a free, b = 1" and the untied form are the
     // same kernel)
     o.hmc_vip_pk = [](const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s) {
-      const dim3 g(Launch<RadonLane<K, NL>>::blocks(P.C));
-      if (SL && P.stats && stats_lds_enabled()) hipLaunchKernelGGL((pk_hmc_kernel<T, kModeVIP, SL>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, a, b, P);
-      else hipLaunchKernelGGL((pk_hmc_kernel<T, kModeVIP>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, a, b, P);
+      const int nb = Launch<RadonLane<K, NL>>::blocks(P.C);
+      if (SL && P.stats && stats_lds_enabled()) ARP_RELAY_LAUNCH((pk_hmc_kernel<T, kModeVIP, SL>), nb, s, P, *(const RadonArgs*)args, a, b);
+      else ARP_RELAY_LAUNCH((pk_hmc_kernel<T, kModeVIP>), nb, s, P, *(const RadonArgs*)args, a, b);
     };
     o.hmc_b1 = o.hmc_vip_pk;
     o.interleaved_cp_ncp = [](const void* args, const float*, const float*, const float*, const float*,
                               const HmcParams& P, hipStream_t s) {
-      const dim3 g(Launch<RadonLane<K, NL>>::blocks(P.C) * (P.segs > 1 ? P.segs : 1));
-      if (SL && P.stats && stats_lds_enabled()) hipLaunchKernelGGL((radon_interleaved_kernel<T, SL>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, P);
-      else hipLaunchKernelGGL((radon_interleaved_kernel<T>), g, dim3(kBlock), 0, s, *(const RadonArgs*)args, P);
+      const int nb = Launch<RadonLane<K, NL>>::blocks(P.C);
+      if (SL && P.stats && stats_lds_enabled()) ARP_RELAY_LAUNCH((radon_interleaved_kernel<T, SL>), nb, s, P, *(const RadonArgs*)args);
+      else ARP_RELAY_LAUNCH((radon_interleaved_kernel<T>), nb, s, P, *(const RadonArgs*)args);
     };
   }
   return o;
@@ -207,11 +268,11 @@ LaneOps election_lane_ops() {
     constexpr bool SL = PkBlock<T>::kStatsFit;   // statistics accumulators in LDS (two workgroups per CU instead of three)
 #define ARP_EL(MODE)                                                                                              \
     [](const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s) {                     \
-      const dim3 g(Launch<ElectionLane<K, NL>>::blocks(P.C));                                                      \
+      const int nb = Launch<ElectionLane<K, NL>>::blocks(P.C);                                                      \
       if (SL && P.stats && stats_lds_enabled())                                                                    \
-        hipLaunchKernelGGL((pk_hmc_kernel<T, MODE, SL>), g, dim3(kBlock), 0, s, *(const ElectionArgs*)args, a, b, P); \
+        ARP_RELAY_LAUNCH((pk_hmc_kernel<T, MODE, SL>), nb, s, P, *(const ElectionArgs*)args, a, b); \
       else                                                                                                         \
-        hipLaunchKernelGGL((pk_hmc_kernel<T, MODE>), g, dim3(kBlock), 0, s, *(const ElectionArgs*)args, a, b, P);  \
+        ARP_RELAY_LAUNCH((pk_hmc_kernel<T, MODE>), nb, s, P, *(const ElectionArgs*)args, a, b);  \
     }
     o.hmc_cp = ARP_EL(kModeCP);
     o.hmc_ncp = ARP_EL(kModeNCP);
@@ -221,11 +282,11 @@ LaneOps election_lane_ops() {
     // --method=i: centred / non-centred interleaving on the packed layer (pk_chain.h: pk_interleaved_kernel)
     o.interleaved_cp_ncp = [](const void* args, const float* a0, const float* b0, const float*, const float*,
                               const HmcParams& P, hipStream_t s) {
-      const dim3 g(Launch<ElectionLane<K, NL>>::blocks(P.C));
+      const int nb = Launch<ElectionLane<K, NL>>::blocks(P.C);
       if (SL && P.stats && stats_lds_enabled())
-        hipLaunchKernelGGL((pk_interleaved_kernel<T, kModeCP, kModeNCP, SL>), g, dim3(kBlock), 0, s, *(const ElectionArgs*)args, a0, b0, P);
+        ARP_RELAY_LAUNCH((pk_interleaved_kernel<T, kModeCP, kModeNCP, SL>), nb, s, P, *(const ElectionArgs*)args, a0, b0);
       else
-        hipLaunchKernelGGL((pk_interleaved_kernel<T, kModeCP, kModeNCP>), g, dim3(kBlock), 0, s, *(const ElectionArgs*)args, a0, b0, P);
+        ARP_RELAY_LAUNCH((pk_interleaved_kernel<T, kModeCP, kModeNCP>), nb, s, P, *(const ElectionArgs*)args, a0, b0);
     };
   }
   return o;

@@ -44,6 +44,61 @@ struct HmcParams {
 };
 
 
+// ---------------------------------------------------------------------------
+// Relay.  The workgroups of a launch that are resident together (one or two per CU) are often exactly one or two rounds,
+// and then every CU does the same work however fast it runs: the launch ends with the slowest.  With P.segs > 1 the grid is
+// segs x seg_blocks workgroups, segment-major, each taking seg_len of the launch's steps for one block of chains; the
+// state travels from a block's segment to the next through the HBM rows a chunked run uses between launches (q, grad,
+// logp, adapt, rng, counters, statistics), so the result is bit for bit the unsegmented launch's, and a CU that is free
+// takes the next (segment, block) in line whoever ran the block before (profiles/r05_relay_segments.txt).
+// relay_begin rewrites the kernel's OWN copy of the parameters to the segment's view (steps, first transition, recording
+// schedule -- the arithmetic of arp_api.hip: fill_params) and, behind a segment, waits for the flag the segment before
+// raised after its stores (workgroups are handed out in index order, so that one is running or done); relay_end raises it.
+// ---------------------------------------------------------------------------
+struct RelayId { unsigned bid; int seg; };
+ARP_DEV RelayId relay_begin(HmcParams& P) {
+  RelayId r{blockIdx.x, 0};
+  if (P.segs > 1) {
+    r.seg = (int)(r.bid / (unsigned)P.seg_blocks);
+    r.bid -= (unsigned)r.seg * (unsigned)P.seg_blocks;
+    const int start = r.seg * P.seg_len;
+    int n = min(P.seg_len, P.n_steps - start);
+    P.n_steps = n < 0 ? 0 : n;
+    P.step_base += start;
+    if (r.seg > 0) {
+      long long first_n = 1 + (long long)P.n_burnin, r0 = 0;
+      if (P.step_base + 1 > first_n) { r0 = (P.step_base + 1 - first_n + P.thin - 1) / P.thin; first_n += r0 * P.thin; }
+      const long long s0 = first_n - P.step_base - 1;
+      P.rec_step = s0 < P.n_steps ? (int)s0 : -1;
+      P.rec_row = (int)(r0 < 0x7fffffff ? r0 : 0x7fffffff);
+      P.stats_bpos = (int)(r0 % P.stats_batch);
+      if (threadIdx.x == 0) {
+        unsigned* const f = P.seg_flags + r.bid;
+        const unsigned want = P.seg_epoch + (unsigned)r.seg;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+          __builtin_amdgcn_s_sleep(8);
+          // 10 s of the 100 MHz clock: if the hand-out order ever failed, stop loudly instead of hanging
+          if (__builtin_amdgcn_s_memrealtime() - t0 > 1000000000ull) __builtin_trap();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // this CU's L1 (and stale L2 lines of other XCDs' data)
+      }
+      __syncthreads();
+    }
+  }
+  return r;
+}
+ARP_DEV void relay_end(const HmcParams& P, RelayId r) {
+  if (P.segs > 1) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every storing wave drains its stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // the XCD's L2 written back
+      __hip_atomic_store(P.seg_flags + r.bid, P.seg_epoch + (unsigned)r.seg + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // Lane models that keep chain-independent tables in LDS declare SMEM_FLOATS, stage_tables(Args, smem) (all threads of the
 // workgroup) and bind_tables(smem); every kernel gives them the block before Lane::init.
 template <class L, class = void> struct lane_smem { static constexpr int value = 0; };
@@ -534,7 +589,8 @@ template <class Lane, int MODE = kModeVIP>
 __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
     typename Lane::Args A, const float* __restrict__ av, const float* __restrict__ bv, HmcParams P) {
   constexpr int K = Lane::K, ND = Lane::ND;
-  long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const RelayId rid = relay_begin(P);
+  long long t = (long long)rid.bid * kBlock + threadIdx.x;
   const int slot = (int)(t % K);
   long long c = t / K;
   const bool live = c < P.C;
@@ -553,7 +609,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
   float* save = s_save + threadIdx.x;
   float* stage = s_stage + (threadIdx.x >> 6) * stage_floats<Lane>();
   // first chain of this wave, this lane's chain within the wave, floats of the wave's live chains
-  const long long cw0 = ((long long)blockIdx.x * kBlock + (threadIdx.x & ~63)) / K;
+  const long long cw0 = ((long long)rid.bid * kBlock + (threadIdx.x & ~63)) / K;
   const int cl = (threadIdx.x & 63) / K;
   const int nvalid = (int)(P.C - cw0 < 64 / K ? (P.C - cw0 > 0 ? P.C - cw0 : 0) : 64 / K) * D;
   for (int d = threadIdx.x; d < D; d += kBlock) s_eps[d] = P.eps0[d];
@@ -656,6 +712,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
       P.accept_count[c2] = nacc;
     }
   }
+  relay_end(P, rid);
 }
 
 // ---------------------------------------------------------------------------
@@ -673,7 +730,8 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
     typename Lane::Args A, const float* __restrict__ av0, const float* __restrict__ bv0,
     const float* __restrict__ av1, const float* __restrict__ bv1, HmcParams P) {
   constexpr int K = Lane::K, ND = Lane::ND;
-  long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const RelayId rid = relay_begin(P);
+  long long t = (long long)rid.bid * kBlock + threadIdx.x;
   const int slot = (int)(t % K);
   long long c = t / K;
   const bool live = c < P.C;
@@ -689,7 +747,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
   ARP_STAGE_SMEM(Lane);
   float* save = s_save + threadIdx.x;
   float* stage = s_stage + (threadIdx.x >> 6) * stage_floats<Lane>();
-  const long long cw0 = ((long long)blockIdx.x * kBlock + (threadIdx.x & ~63)) / K;
+  const long long cw0 = ((long long)rid.bid * kBlock + (threadIdx.x & ~63)) / K;
   const int cl = (threadIdx.x & 63) / K;
   const int nvalid = (int)(P.C - cw0 < 64 / K ? (P.C - cw0 > 0 ? P.C - cw0 : 0) : 64 / K) * D;
   for (int d = threadIdx.x; d < D; d += kBlock) { s_eps[0][d] = P.eps0[d]; s_eps[1][d] = P.eps0_1[d]; }
@@ -808,6 +866,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
       P.accept_count[c2] = nacc0; P.accept_count1[c2] = nacc1;
     }
   }
+  relay_end(P, rid);
 }
 
 // ---------------------------------------------------------------------------

@@ -444,7 +444,8 @@ __global__ __launch_bounds__(kBlock, (STATS || MODE == ARP_PK_VIP_MINW2) && T::M
     typename T::Args A, const float* __restrict__ av, const float* __restrict__ bv, HmcParams P) {
   constexpr int K = T::K, NP = T::NP, ND = T::ND, NG = T::NG;
   // chain of this lane (a launch holds fewer than 2^31 / K chains: 32-bit lane arithmetic)
-  const unsigned t = blockIdx.x * (unsigned)kBlock + threadIdx.x;
+  const RelayId rid = relay_begin(P);
+  const unsigned t = rid.bid * (unsigned)kBlock + threadIdx.x;
   const int slot = (int)(t % K);
   int c = (int)(t / K);
   const bool live = c < P.C;
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(kBlock, (STATS || MODE == ARP_PK_VIP_MINW2) && T::M
   float* save = wsave + 2 * (threadIdx.x & 63);
   float* stage = wsave;   // the wave's staging block aliases its own parked state (dead between transitions)
   // first chain of this wave: wave-uniform, kept in SGPRs so that row addresses are scalar arithmetic
-  const long long cw0 = (long long)((blockIdx.x * (unsigned)kBlock + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x & ~63)) / K);
+  const long long cw0 = (long long)((rid.bid * (unsigned)kBlock + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x & ~63)) / K);
   const int cl = (threadIdx.x & 63) / K;
   const int nvalid = (int)(P.C - cw0 < 64 / K ? (P.C - cw0 > 0 ? P.C - cw0 : 0) : 64 / K) * D;
   for (int d = threadIdx.x; d < PkBlock<T>::kEps; d += kBlock) s_eps[d] = d < D ? P.eps0[d] : 0.0f;
@@ -565,6 +566,7 @@ __global__ __launch_bounds__(kBlock, (STATS || MODE == ARP_PK_VIP_MINW2) && T::M
       P.accept_count[c2] = nacc;
     }
   }
+  relay_end(P, rid);
 }
 
 // Interleaved sampling on the packed chain layer for lane models whose change of coordinates is NOT a unit-Jacobian
@@ -577,7 +579,8 @@ template <class T, int M0, int M1, bool STATS = false>
 __global__ __launch_bounds__(kBlock, STATS && T::MINW > 2 ? 2 : T::MINW) void pk_interleaved_kernel(
     typename T::Args A, const float* __restrict__ av0, const float* __restrict__ bv0, HmcParams P) {
   constexpr int K = T::K, NP = T::NP, ND = T::ND, NG = T::NG;
-  const unsigned t = blockIdx.x * (unsigned)kBlock + threadIdx.x;
+  const RelayId rid = relay_begin(P);
+  const unsigned t = rid.bid * (unsigned)kBlock + threadIdx.x;
   const int slot = (int)(t % K);
   int c = (int)(t / K);
   const bool live = c < P.C;
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(kBlock, STATS && T::MINW > 2 ? 2 : T::MINW) void pk
   float* wsave = s_save + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * pk_save_wave_floats<T>();
   float* save = wsave + 2 * (threadIdx.x & 63);
   float* stage = wsave;
-  const long long cw0 = (long long)((blockIdx.x * (unsigned)kBlock + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x & ~63)) / K);
+  const long long cw0 = (long long)((rid.bid * (unsigned)kBlock + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x & ~63)) / K);
   const int cl = (threadIdx.x & 63) / K;
   const int nvalid = (int)(P.C - cw0 < 64 / K ? (P.C - cw0 > 0 ? P.C - cw0 : 0) : 64 / K) * D;
   for (int d = threadIdx.x; d < PkBlock<T>::kEps; d += kBlock) {
@@ -701,6 +704,7 @@ __global__ __launch_bounds__(kBlock, STATS && T::MINW > 2 ? 2 : T::MINW) void pk
       P.accept_count[c2] = nacc0; P.accept_count1[c2] = nacc1;
     }
   }
+  relay_end(P, rid);
 }
 
 }  // namespace arp

@@ -242,46 +242,8 @@ struct RadonPk {
 template <class T, bool STATS = false>
 __global__ __launch_bounds__(kBlock, T::MINW) void radon_interleaved_kernel(RadonArgs A, HmcParams P) {
   constexpr int K = T::K, NP = T::NP, ND = T::ND;
-  // Relay: with P.segs > 1 the grid is segs x seg_blocks workgroups, segment-major.  The workgroups of ONE launch that fit on
-  // the device together (two per CU) are exactly two rounds at the headline size, so a CU that runs a few per cent slower makes
-  // the others wait at the end; with the steps cut into segments, a free CU takes the next (segment, block) in line whoever ran
-  // the segment before it -- the state travels through the same HBM rows a chunked run uses between launches (q, grad, logp,
-  // adapt, rng, counters, statistics), which makes the result bit for bit the unsegmented one.
-  unsigned bid = blockIdx.x;
-  int seg = 0, n_steps = P.n_steps;
-  long long step_base = P.step_base;
-  int rec_step0 = P.rec_step, rec_row0 = P.rec_row, bpos0 = P.stats_bpos;
-  if (P.segs > 1) {
-    seg = (int)(bid / (unsigned)P.seg_blocks);
-    bid -= (unsigned)seg * (unsigned)P.seg_blocks;
-    const int start = seg * P.seg_len;
-    n_steps = min(P.seg_len, P.n_steps - start);
-    if (n_steps < 0) n_steps = 0;
-    step_base += start;
-    if (seg > 0) {
-      // the recording schedule of this segment (arp_api.hip: fill_params): result r is taken after transition 1 + burnin + r thin
-      long long first_n = 1 + (long long)P.n_burnin, r0 = 0;
-      if (step_base + 1 > first_n) { r0 = (step_base + 1 - first_n + P.thin - 1) / P.thin; first_n += r0 * P.thin; }
-      const long long s0 = first_n - step_base - 1;
-      rec_step0 = s0 < n_steps ? (int)s0 : -1;
-      rec_row0 = (int)(r0 < 0x7fffffff ? r0 : 0x7fffffff);
-      bpos0 = (int)(r0 % P.stats_batch);
-      // wait for the segment before this one (another workgroup, possibly on another XCD), then make its stores visible here
-      if (threadIdx.x == 0) {
-        unsigned* const f = P.seg_flags + bid;
-        const unsigned want = P.seg_epoch + (unsigned)seg;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-          __builtin_amdgcn_s_sleep(8);
-          // 10 s of the 100 MHz clock: workgroups are handed out in order, so the segment before is running or done; if that
-          // ever failed, stop loudly instead of hanging
-          if (__builtin_amdgcn_s_memrealtime() - t0 > 1000000000ull) __builtin_trap();
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      __syncthreads();
-    }
-  }
+  const RelayId rid = relay_begin(P);      // kernels.h: the launch's steps in segments, a workgroup per (segment, chain block)
+  const unsigned bid = rid.bid;
   const unsigned t = bid * (unsigned)kBlock + threadIdx.x;
   const int slot = (int)(t % K);
   int c = (int)(t / K);
@@ -314,7 +276,7 @@ __global__ __launch_bounds__(kBlock, T::MINW) void radon_interleaved_kernel(Rado
     float v[ND];
     load_row(M, P.q + (size_t)c * D, v);
     T::unpack(v, qg, qc);
-    if (step_base == 0 || !P.grad) {
+    if (P.step_base == 0 || !P.grad) {
       float pg[3] = {0.f, 0.f, 0.f}, eg[3] = {0.f, 0.f, 0.f}; v2f pc[NP], ec[NP]; float ke;
       M.template pass<kModeCP, 2>(qg, qc, pg, pc, eg, ec, gg_, gc, lp, ke);
     } else {
@@ -327,7 +289,7 @@ __global__ __launch_bounds__(kBlock, T::MINW) void radon_interleaved_kernel(Rado
   Rng rng;
   uint32_t* rs = P.rng + ((size_t)c * kRngSlots + slot) * 4;
   uint32_t nacc0, nacc1;
-  if (step_base == 0) {
+  if (P.step_base == 0) {
     kap[0] = kap[1] = 1.0f; es[0] = es[1] = 0.0f; la_[0] = la_[1] = 0.0f;
     nacc0 = nacc1 = 0u;
     rng = rng_seed(P.seed, (unsigned long long)(P.chain_offset + c), (uint32_t)slot, (uint32_t)K);
@@ -337,10 +299,10 @@ __global__ __launch_bounds__(kBlock, T::MINW) void radon_interleaved_kernel(Rado
     nacc0 = P.accept_count[c]; nacc1 = P.accept_count1[c];
     rng = Rng{rs[0], rs[1]};
   }
-  int next_rec = rec_step0, rec_row = rec_row0, bpos = bpos0;
+  int next_rec = P.rec_step, rec_row = P.rec_row, bpos = P.stats_bpos;
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  for (int s = 0; s < n_steps; ++s) {
-    const long long n = step_base + s + 1;
+  for (int s = 0; s < P.n_steps; ++s) {
+    const long long n = P.step_base + s + 1;
     bool acc0, acc1;
     float la = pk_transition<kModeCP>(M, rng, P.L, kap[0], s_eps[0], qg, qc, gg_, gc, lp, acc0, save);
     nacc0 += acc0 ? 1u : 0u;
@@ -402,16 +364,7 @@ __global__ __launch_bounds__(kBlock, T::MINW) void radon_interleaved_kernel(Rado
       P.accept_count[c2] = nacc0; P.accept_count1[c2] = nacc1;
     }
   }
-  if (P.segs > 1) {
-    // hand the block on: every storing wave drains its stores, the workgroup meets, ONE lane writes the XCD's L2 back and
-    // raises the flag the next segment's workgroup polls
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __hip_atomic_store(P.seg_flags + bid, P.seg_epoch + (unsigned)seg + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  relay_end(P, rid);
 }
 
 }  // namespace arp

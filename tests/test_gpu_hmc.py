@@ -618,3 +618,60 @@ def test_relay_segments_equal_the_unsegmented_launch(gpu, monkeypatch, chains, l
                 for a_, b_ in zip(engine.stats_summary(torch.as_tensor(ref[11]), n, 3)[:2], engine.stats_summary(torch.as_tensor(got[11]), n, 3)[:2]):
                     scale = a_.abs().max(dim=0).values + 1e-3
                     assert ((a_ - b_).abs() / scale).max() < 1e-5, (segs, T)
+
+
+@pytest.mark.parametrize("mname,kind,chains,sampler", [
+    ("german", "NCP", 16384, "hmc"),          # hmc_kernel<GermanLane<4,16,4,false,true>>: 256 workgroups = one round at one per CU
+    ("german", "VIP", 4099, "hmc"),
+    ("election", "NCP", 131072, "hmc"),       # pk_hmc_kernel<ElectionPk<4,13>, NCP>
+    ("election", "B1", 70001, "hmc"),
+    ("radon_MN", "CP", 65536, "hmc"),         # pk_hmc_kernel<RadonPk<4,22>, CP>
+    ("election", None, 65536, "interleaved"),   # pk_interleaved_kernel (re-bootstraps)
+    ("electric", None, 65536, "interleaved"),   # the generic interleaved_kernel
+    ("radon_sd_MN", "NCP", 65536, "hmc"),     # the generic hmc_kernel at two waves per SIMD
+])
+def test_relay_segments_in_every_chain_kernel(gpu, monkeypatch, mname, kind, chains, sampler):
+    """The relay (kernels.h: relay_begin / relay_end) in the generic and the packed chain kernels: the library's own choice of
+    segments and a forced three against the launch with one workgroup per chain block -- states, gradients, log densities,
+    adaptation, counters, generator states, trace rows and acceptance flags bit for bit, over two launches."""
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec(mname)
+    eng = _eng(mname, gpu)
+    if sampler == "hmc":
+        eng.set_param(0, helpers.params(sp, kind, seed=3))
+    else:
+        eng.set_param(0, "CP"); eng.set_param(1, "NCP")
+    q0 = helpers.states(sp, chains, seed=4, scale=0.05)
+    e = np.full(sp.D, 2e-3 if mname != "time_series" else 1e-4, np.float32)
+    T = 300 if mname != "german" else 260
+    keep = min(chains, 4096)
+    monkeypatch.setenv("ARP_DEBUG", "1")
+
+    def run(segs):
+        if segs is None:
+            monkeypatch.delenv("ARP_SEGMENTS", raising=False)
+        else:
+            monkeypatch.setenv("ARP_SEGMENTS", str(segs))
+        st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+        S = T      # rows: two launches of T steps, every second one recorded
+        tr = torch.zeros(S, keep, sp.D, device=gpu)
+        a0 = torch.zeros(S, chains, dtype=torch.uint8, device=gpu); a1 = torch.zeros_like(a0)
+        for _ in range(2):
+            if sampler == "hmc":
+                eng.hmc_run(st, e, 3, T, seed=21, adapt_kind=_lib.ADAPT_DUAL, n_adapt=350, n_burnin=57, thin=2, trace=tr,
+                            trace_accept=a0, trace_chains=keep)
+            else:
+                eng.interleaved_run(st, e, e, 2, 2, T, seed=21, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=350, n_burnin=57, thin=2,
+                                    trace=tr, trace_accept0=a0, trace_accept1=a1, trace_chains=keep)
+        torch.cuda.synchronize()
+        out = [st.q, st.grad, st.logp, st.adapt, st.accept_count, st.rng, tr, a0, a1]
+        if sampler != "hmc":
+            out += [st.adapt1, st.accept_count1]
+        return [t.cpu().numpy() for t in out]
+
+    ref = run(1)
+    assert np.isfinite(ref[0]).all() and ref[4].sum() > 0
+    for segs in (None, 3):
+        got = run(segs)
+        for k, (x, y) in enumerate(zip(ref, got)):
+            assert np.array_equal(x, y, equal_nan=True), (segs, k)
