@@ -93,7 +93,14 @@ if "GRBM_GUI_ACTIVE" in sq:
         derived["valu_active_frac_of_wave_lifetime"] = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]
     if "SQ_INSTS_VALU" in sq:
         derived["simd_cycles_per_valu_inst"] = n_simd * cyc / sq["SQ_INSTS_VALU"]
-        derived["valu_insts_per_wave_per_sampler_step"] = sq["SQ_INSTS_VALU"] / sq.get("SQ_WAVES", 1) / cfg["transitions_per_step"]
+        # relay segments: the launch's steps are cut into segments, a wave per (segment, 64 lanes), so a
+        # wave runs transitions_per_step / segments of them -- the number of segments is the power of two by which the
+        # launch's waves exceed one wave per 64 lanes at 4 lanes per chain (the headline's split)
+        waves_whole = cfg["chains_per_gpu"] * 4 / 64.0
+        segs = max(1, int(round(sq.get("SQ_WAVES", waves_whole) / waves_whole)))
+        derived["relay_segments"] = segs
+        steps_per_wave = cfg["transitions_per_step"] / float(segs)
+        derived["valu_insts_per_wave_per_sampler_step"] = sq["SQ_INSTS_VALU"] / sq.get("SQ_WAVES", 1) / steps_per_wave
     derived["clock_ghz_estimate"] = cyc / avg_ns
     try:
         sys.path.insert(0, ROOT)
@@ -106,8 +113,9 @@ if "GRBM_GUI_ACTIVE" in sq:
         waves_per_simd_total = sq.get("SQ_WAVES", 0) / n_simd
         derived["issue_bound_cycles_at_2.4GHz_per_wave_step"] = priced
         # time based (the costs are times quoted at 2.4 GHz): priced time / this profiled pass's measured time
-        derived["issue_bound_frac"] = (priced / 2.4e9) * cfg["transitions_per_step"] * waves_per_simd_total / (avg_ns * 1e-9)
-        derived["issue_bound_frac_if_costs_were_true_cycles"] = priced * cfg["transitions_per_step"] * waves_per_simd_total / cyc
+        spw = cfg["transitions_per_step"] / float(derived.get("relay_segments", 1))     # steps a wave runs
+        derived["issue_bound_frac"] = (priced / 2.4e9) * spw * waves_per_simd_total / (avg_ns * 1e-9)
+        derived["issue_bound_frac_if_costs_were_true_cycles"] = priced * spw * waves_per_simd_total / cyc
     except Exception as e:
         derived["issue_bound_error"] = repr(e)
 head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, stdout=subprocess.PIPE, text=True).stdout.strip()
