@@ -157,7 +157,9 @@ int arp_logp_grad(arp_model* m, int which, const float* x, int n_chains,
 int arp_transform(arp_model* m, int which, int dir, const float* in, int n_chains,
                   float* out, void* stream);
 
-/* HMC segment (mcmc.HamiltonianMonteCarlo + step-size adaptation + sample_chain). */
+/* HMC segment (mcmc.HamiltonianMonteCarlo + step-size adaptation + sample_chain): `cfg->n_steps` transitions in ONE
+ * launch.  (Internally a launch of 256 steps or more may hand its chains from workgroup to workgroup a few times -- DESIGN.md
+ * section 3, relay segments --; the result is bit for bit that of one workgroup per chain block, the call stays asynchronous.) */
 int arp_hmc_run(arp_model* m, int which, const arp_hmc_config* cfg,
                 const arp_hmc_io* io, void* stream);
 
