@@ -78,8 +78,9 @@ ARP_DEV RelayId relay_begin(HmcParams& P) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
           __builtin_amdgcn_s_sleep(8);
-          // 10 s of the 100 MHz clock: if the hand-out order ever failed, stop loudly instead of hanging
-          if (__builtin_amdgcn_s_memrealtime() - t0 > 1000000000ull) __builtin_trap();
+          // a minute of the 100 MHz clock (a segment is milliseconds; another process may hold the device for a while): if the
+          // hand-out order ever failed, stop loudly instead of hanging
+          if (__builtin_amdgcn_s_memrealtime() - t0 > 6000000000ull) __builtin_trap();
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // this CU's L1 (and stale L2 lines of other XCDs' data)
       }
