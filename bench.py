@@ -802,7 +802,8 @@ def main():
                         "measured_bytes_per_launch": traffic,
                         "measured_frac_of_8TBps": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                         "note": "the byte model charges every transition a state load/store the fused kernel performs "
-                                "once per launch; the measured figure is what crosses HBM"}}
+                                "once per launch segment (the launch hands its chains from workgroup to workgroup up to eight "
+                                "times: DESIGN.md section 3, relay segments); the measured figure is what crosses HBM"}}
         if dist is not None and dist.get_backend() == "nccl":
             out_rccl = world
         else:
