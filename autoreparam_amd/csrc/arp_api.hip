@@ -491,7 +491,6 @@ int arp_model_destroy(arp_model* m) {
   if (m->dev_tables) (void)hipFree(m->dev_tables);
   for (int w = 0; w < 2; ++w) if (m->dev_ab[w]) (void)hipFree(m->dev_ab[w]);
   if (m->vi_ws) (void)hipFree(m->vi_ws);
-  if (m->seg_flags) (void)hipFree(m->seg_flags);
   delete m;
   return 0;
 }
@@ -599,9 +598,9 @@ static int check_adapt(const arp_hmc_config* cfg) {
 // Relay segments (kernels.h: relay_begin; host_common.h: relay_plan): a launch's steps cut into segments that are handed
 // from workgroup to workgroup inside the launch, so that a CU that is free takes the next (segment, chain block) in line
 // instead of idling behind a slower one (profiles/r05_relay_segments.txt).  This gives the launcher what it needs: one
-// flag word per chain block on the handle, an epoch that makes this launch's flag values its own (no clearing between
-// launches), and `segs` = -1 (the launcher decides with its kernel's occupancy), a forced count (ARP_DEBUG=1
-// ARP_SEGMENTS=n) or 1 (`allowed` false).
+// zeroed flag word per chain block that belongs to THIS launch alone -- a stream-ordered allocation, given back behind the
+// launch (relay_release), so launches of one handle that overlap on different streams never share a word -- and `segs` =
+// -1 (the launcher decides with its kernel's occupancy), a forced count (ARP_DEBUG=1 ARP_SEGMENTS=n) or 1 (`allowed` false).
 static int relay_prepare(arp_model* m, const arp_hmc_config* cfg, int K, bool allowed, hipStream_t stream, HmcParams* P) {
   P->segs = 1; P->seg_len = cfg->n_steps; P->seg_blocks = 0; P->seg_epoch = 0; P->seg_flags = nullptr;
   if (!allowed || cfg->n_steps < 256) return 0;
@@ -609,20 +608,25 @@ static int relay_prepare(arp_model* m, const arp_hmc_config* cfg, int K, bool al
   if (debug_int("ARP_SEGMENTS", &dbg) && dbg >= 1 && dbg <= 8) segs = dbg;
   if (segs == 1) return 0;
   const long long blocks = ((long long)cfg->n_chains * K + kBlock - 1) / kBlock;
-  if (m->seg_flags_n < blocks) {
-    if (m->seg_flags) { ARP_HIP_OK(hipStreamSynchronize(stream)); (void)hipFree(m->seg_flags); m->seg_flags = nullptr; m->seg_flags_n = 0; }
-    ARP_HIP_OK(hipMalloc(&m->seg_flags, (size_t)blocks * sizeof(unsigned)));
-    ARP_HIP_OK(hipMemset(m->seg_flags, 0, (size_t)blocks * sizeof(unsigned)));
-    m->seg_flags_n = (int)blocks;
-    m->seg_launch = 0;
+  if (segs == -1) {
+    // no kernel gets segments below one round of two workgroups per CU (relay_plan): spare those launches the allocation
+    static thread_local int cus_of[64] = {0};
+    int& cus = cus_of[m->device & 63];
+    if (cus <= 0) {
+      hipDeviceProp_t prop;
+      ARP_HIP_OK(hipGetDeviceProperties(&prop, m->device));
+      cus = prop.multiProcessorCount;
+    }
+    if (blocks < 2LL * cus) return 0;
   }
-  m->seg_launch += 1;
-  if (m->seg_launch >= (1u << 27)) {            // the epochs would wrap: start over from clean flags
-    ARP_HIP_OK(hipStreamSynchronize(stream));
-    ARP_HIP_OK(hipMemset(m->seg_flags, 0, (size_t)m->seg_flags_n * sizeof(unsigned)));
-    m->seg_launch = 1;
-  }
-  P->segs = segs; P->seg_blocks = m->seg_flags_n; P->seg_epoch = m->seg_launch * 16u; P->seg_flags = m->seg_flags;
+  void* flags = nullptr;
+  ARP_HIP_OK(hipMallocAsync(&flags, (size_t)blocks * sizeof(unsigned), stream));
+  ARP_HIP_OK(hipMemsetAsync(flags, 0, (size_t)blocks * sizeof(unsigned), stream));
+  P->segs = segs; P->seg_blocks = (int)blocks; P->seg_epoch = 0u; P->seg_flags = (unsigned*)flags;
+  return 0;
+}
+static int relay_release(const HmcParams& P, hipStream_t stream) {
+  if (P.seg_flags) ARP_HIP_OK(hipFreeAsync(P.seg_flags, stream));
   return 0;
 }
 
@@ -690,7 +694,9 @@ int arp_hmc_run(arp_model* m, int which, const arp_hmc_config* cfg, const arp_hm
   if (m->param_kind[which] == kModeVIP && o->hmc_vip_pk) fn = o->hmc_vip_pk;
   if (relay_prepare(m, cfg, o->K, true, (hipStream_t)stream, &P)) return 1;
   fn(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, (hipStream_t)stream);
-  ARP_HIP_OK(hipGetLastError());
+  const hipError_t launched = hipGetLastError();
+  if (relay_release(P, (hipStream_t)stream)) return 1;
+  ARP_HIP_OK(launched);
   return 0;
 }
 
@@ -719,7 +725,9 @@ int arp_interleaved_run(arp_model* m, const arp_hmc_config* cfg, int n_leapfrog_
   // (kernels that carry the gradient from step to step need it to travel with the state, as it does between launches)
   if (relay_prepare(m, cfg, o->K, io->k0.grad != nullptr, (hipStream_t)stream, &P)) return 1;
   fn(family_args(m), m->dev_ab[0], m->dev_ab[0] + m->D, m->dev_ab[1], m->dev_ab[1] + m->D, P, (hipStream_t)stream);
-  ARP_HIP_OK(hipGetLastError());
+  const hipError_t launched = hipGetLastError();
+  if (relay_release(P, (hipStream_t)stream)) return 1;
+  ARP_HIP_OK(launched);
   return 0;
 }
 

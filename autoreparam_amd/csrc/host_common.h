@@ -329,10 +329,6 @@ struct arp_model {
   // hand-off workspace of the VI kernel (granules + the error flag in its first 256 bytes), grown on demand
   void* vi_ws = nullptr;
   size_t vi_ws_bytes = 0;
-  // relay flags of the segmented interleaved launch (one word per chain block; arp_api.hip: arp_interleaved_run)
-  unsigned* seg_flags = nullptr;
-  int seg_flags_n = 0;
-  unsigned seg_launch = 0;
   double const_base = 0.0;                       // parameterisation independent part of the dropped constant
   std::vector<std::pair<int, double>> top_scale; // (flattened index, log prior scale) of top-level latents
 };

@@ -69,3 +69,38 @@ def test_handles_driven_from_concurrent_threads(gpu):
             for ra, rb in zip(a, b):
                 for x, y in zip(ra, rb):
                     assert np.array_equal(x, y, equal_nan=True), job
+
+
+def test_one_handle_two_streams_overlapping_launches(gpu):
+    """One handle, launches enqueued back to back on TWO streams for two different chain populations (calls serialised by the
+    caller, the work overlaps on the device): the relay segments of a launch use flag words of their own (a stream-ordered
+    allocation per launch), so each population's run is bit for bit the one it gets alone."""
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec("radon_PA")
+    eng = engine.Engine(sp, gpu)
+    eng.set_param(0, "CP"); eng.set_param(1, "NCP")
+    e = np.full(sp.D, 0.05, np.float32); e[2] = 0.012
+    C, T = 65536, 384
+    q0 = [helpers.states(sp, C, seed=s, scale=0.1) for s in (1, 2)]
+
+    def go(st, seed):
+        eng.interleaved_run(st, e, e, 3, 3, T, seed=seed, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=500)
+
+    alone = []
+    for k in range(2):
+        st = engine.ChainState(torch.as_tensor(q0[k], device=gpu))
+        for _ in range(3): go(st, 40 + k)
+        torch.cuda.synchronize()
+        alone.append([t.cpu().numpy() for t in (st.q, st.grad, st.rng, st.accept_count, st.accept_count1)])
+    streams = [torch.cuda.Stream(device=gpu) for _ in range(2)]
+    sts = [engine.ChainState(torch.as_tensor(q0[k], device=gpu)) for k in range(2)]
+    torch.cuda.synchronize()
+    for _ in range(3):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                go(sts[k], 40 + k)
+    torch.cuda.synchronize()
+    for k in range(2):
+        got = [t.cpu().numpy() for t in (sts[k].q, sts[k].grad, sts[k].rng, sts[k].accept_count, sts[k].accept_count1)]
+        for x, y in zip(alone[k], got):
+            assert np.array_equal(x, y)
