@@ -260,3 +260,43 @@ def test_clock_probe_reports_a_plausible_shader_clock(gpu):
     ghz = engine.clock_probe(gpu, 5.0)
     assert ghz is not None and 1.2 < ghz < 2.6, ghz
     assert _lib.lib().arp_clock_probe(0, C.c_void_p(0), C.c_void_p(0)) != 0
+
+
+@pytest.mark.parametrize("sampler", ["interleaved", "hmc"])
+def test_trace_past_two_to_the_32_elements(gpu, sampler):
+    """A trace of 4.65e9 floats (18.6 GB: 1 000 rows x 65 536 chains x 71) and acceptance flags: rows written beyond element
+    2^32 (byte 2^34) are where they belong -- the last rows equal those of a second run of the same chains that records only the
+    tail (same seeds, same transitions, burn-in moved), and the rows in front of them are not touched by it."""
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec("radon_PA")
+    eng = _eng("radon_PA", gpu)
+    eng.set_param(0, "CP"); eng.set_param(1, "NCP")
+    C, S, T = 65536, 1000, 2000                         # a row every second transition
+    assert S * C * sp.D > 2 ** 32
+    q0 = helpers.states(sp, C, seed=6, scale=0.1)
+    e = np.full(sp.D, 0.05, np.float32); e[2] = 0.012
+
+    def run(n_burn, rows):
+        st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+        tr = torch.full((rows, C, sp.D), -7.0, device=gpu)
+        acc = torch.full((rows, C), 9, dtype=torch.uint8, device=gpu)
+        for _ in range(2):                              # two launches of 1 000 transitions
+            if sampler == "interleaved":
+                eng.interleaved_run(st, e, e, 1, 1, T // 2, seed=3, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=100, n_burnin=n_burn,
+                                    thin=2, trace=tr, trace_accept0=acc, trace_centered=False)
+            else:
+                eng.hmc_run(st, e, 1, T // 2, seed=3, adapt_kind=_lib.ADAPT_DUAL, n_adapt=100, n_burnin=n_burn, thin=2, trace=tr,
+                            trace_accept=acc, trace_centered=False)
+        torch.cuda.synchronize()
+        return tr, acc
+
+    tr, acc = run(0, S)
+    assert not (tr[-1] == -7.0).any() and not (acc[-1] == 9).any() and torch.isfinite(tr[-3:]).all()
+    tail_rows = 5
+    tr_t, acc_t = run(2 * (S - tail_rows), tail_rows)       # the same transitions; result r is taken after transition 1 + burn-in + 2 r
+    assert torch.equal(tr[S - tail_rows:], tr_t) and torch.equal(acc[S - tail_rows:], acc_t)
+    # rows on both sides of element 2^32 hold chain states (not the fill value), row by row different
+    k = 2 ** 32 // (C * sp.D)
+    assert not (tr[k - 1:k + 2] == -7.0).any() and not torch.equal(tr[k], tr[k + 1])
+    del tr, acc, tr_t, acc_t
+    torch.cuda.empty_cache()
