@@ -3,7 +3,7 @@
 timed repeatedly, with the distribution of the lag at which series are cut (float64 oracle on a sample of chains)."""
 import json, os, sys, tempfile, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from autoreparam_amd import main as cli, inference, util, models, graphs
 from autoreparam_amd.flags import FLAGS

@@ -3,7 +3,7 @@
 "german_math") -- accuracy of log density and gradient against the float64 oracle on the same states, and the fused HMC
 kernel's time at 16 384 chains, L = 4, 256 transitions per launch.
 
-    python tools/german_math_ab.py [chains=16384] [transitions=256]
+    python tests/diagnostics/german_math_ab.py [chains=16384] [transitions=256]
 """
 import os
 import sys
@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers  # noqa: E402

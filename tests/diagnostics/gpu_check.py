@@ -1,7 +1,7 @@
 """First-contact GPU script: parity of logp/grad + HMC vs the C oracle, then a
 throughput sweep over lanes-per-chain and chain counts for radon."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

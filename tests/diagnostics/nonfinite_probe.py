@@ -1,7 +1,8 @@
 """Past float32 overflow: which gradient entries are finite / +-inf / NaN in the HIP path (arp_logp_grad) and in the float32
 oracle -- one scale parameter at e^100 (profiles/r05_nonfinite_classes.txt)."""
 import sys, os
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, helpers
 import oracle; oracle.build()
 from autoreparam_amd import engine

@@ -53,7 +53,7 @@ def states(sp, n, seed=0, scale=0.3):
 # have sat within `margin_tol` of its threshold in the oracle's run; a chain that differs anywhere else fails.
 # ---------------------------------------------------------------------------
 EPS32 = float(np.finfo(np.float32).eps)
-# measured (tools/margin_probe.py, profiles/r03_margin_probe.txt: every model x parameterisation x lanes, fixed step and
+# measured (tests/diagnostics/margin_probe.py, profiles/r03_margin_probe.txt: every model x parameterisation x lanes, fixed step and
 # simple adaptation): every decision that differed had |log u - log alpha| <= 1.7e-3 or <= 1.0 ulp of its energies
 MARGIN_ABS, MARGIN_ULPS = 2e-3, 4.0
 

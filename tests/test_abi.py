@@ -66,6 +66,24 @@ def test_product_path_does_not_import_oracle():
                 assert "liboracle" not in txt, (dirpath, f)
 
 
+def test_only_the_checkers_import_the_oracle():
+    """Outside tests/ the oracle is imported in exactly two places, both as the checker: bench.py's CPU-baseline leg and
+    __graft_entry__ (build() compiles it, smoke() checks one small run against it).  The measurement scripts under tools/
+    do not; the ones that compare against the oracle live under tests/diagnostics/."""
+    hits = []
+    for dirpath, dirs, files in os.walk(ROOT):
+        dirs[:] = [d for d in dirs if d not in (".git", "gpurun_out", "tests", "oracle", "__pycache__", "build")]
+        for f in files:
+            if f.endswith(".py") or f.endswith(".sh"):
+                txt = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M):
+                    hits.append(os.path.relpath(os.path.join(dirpath, f), ROOT))
+    assert sorted(hits) == ["__graft_entry__.py", "bench.py"], hits
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for m in re.finditer(r"^(\s*)(import|from)\s+oracle\b", src, flags=re.M):
+        assert len(m.group(1)) >= 4, "bench.py imports the oracle at module level"     # inside cpu_baseline() only
+
+
 def test_enum_values_match_header(built):
     src = open(os.path.join(ROOT, "include", "autoreparam.h")).read()
     enums = {k: int(v) for k, v in re.findall(r"\b(ARP_[A-Z_0-9]+)\s*=\s*(\d+)", src)}

@@ -299,7 +299,7 @@ def test_vi_nan_gradients_are_zeroed(oracle_lib, gpu, mname, kind, idx):
     parameter with them -- those parameters stay where they started, bit for bit, the ones whose gradient is still a
     number move as the oracle's do, and nothing becomes NaN.  (Only cases where HIP path and oracle put NaN -- not +-inf,
     which Adam turns into a NaN parameter on both sides, as TF's would -- in the same entries: past float32 overflow that
-    class depends on the order of the algebra, DESIGN.md section 9, tools/experiments/nonfinite_probe.py.)"""
+    class depends on the order of the algebra, DESIGN.md section 9, tests/diagnostics/nonfinite_probe.py.)"""
     from autoreparam_amd import engine
     sp = helpers.spec(mname)
     eng = engine.Engine(sp, gpu)
