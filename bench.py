@@ -794,8 +794,9 @@ def main():
                 "kernel_ms": kern_ms, "kernel_ms_min": float(np.min(per_launch_ms)),
                 "kernel_ms_median": float(np.median(per_launch_ms)), "kernel_ms_max": float(np.max(per_launch_ms)),
                 "algorithmic_flop_per_leapfrog": flop_lf,
-                "note": "FP32 vector issue binds this kernel (state in registers for the whole launch); frac = SURVEY 8(d) "
-                        "algorithmic flops / HIP-event kernel time / 157.3 TFLOP/s",
+                "note": "FP32 vector issue binds this kernel (state in registers; the ONE launch of a step hands its chains from "
+                        "workgroup to workgroup up to eight times -- relay segments, DESIGN.md section 3 -- bit for bit the "
+                        "unsegmented run); frac = SURVEY 8(d) algorithmic flops / HIP-event kernel time / 157.3 TFLOP/s",
                 "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
                         "algorithmic_GBps": alg_bytes / (kern_ms * 1e-3) / 1e9,
                         "algorithmic_frac_of_8TBps": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
