@@ -856,6 +856,12 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   return 0;
 }
 
+int arp_relay_geometry(int32_t* out3) {
+  if (!out3) { set_error("arp_relay_geometry: null argument"); return 1; }
+  for (int i = 0; i < 3; ++i) out3[i] = relay_last().v[i];
+  return 0;
+}
+
 int arp_vi_geometry(int32_t* out6) {
   if (!out6) { set_error("arp_vi_geometry: null argument"); return 1; }
   for (int i = 0; i < 6; ++i) out6[i] = g_vi_geometry.v[i];

@@ -88,10 +88,18 @@ inline int relay_device_cus() {
   }
   return cus;
 }
+// what the calling thread's last chain launch did (arp_relay_geometry, a measurement hook): segments, chain blocks, workgroups of
+// the kernel one CU holds (0 where the launcher did not have to ask)
+struct RelayGeometry { int v[3]; };
+inline RelayGeometry& relay_last() {
+  static thread_local RelayGeometry g = {{1, 0, 0}};
+  return g;
+}
 template <class F>
 inline HmcParams relay_plan(const HmcParams& P, int blocks, F kernel) {
   HmcParams Q = P;
   int segs = P.segs;
+  int occ_seen = 0;
   if (segs == -1) {
     static std::mutex mu;
     static std::map<const void*, int> occ_of;
@@ -106,6 +114,7 @@ inline HmcParams relay_plan(const HmcParams& P, int blocks, F kernel) {
         occ = it->second;
       }
     }
+    occ_seen = occ;
     const long long slots = (long long)occ * relay_device_cus();
     segs = (slots > 0 && blocks >= slots) ? (P.n_steps >= 512 ? 8 : (P.n_steps >= 256 ? 4 : 1)) : 1;
     // one workgroup per CU (German credit and time_series at 4 lanes per chain: 100 - 155 KB of LDS): a workgroup that waits for
@@ -117,6 +126,7 @@ inline HmcParams relay_plan(const HmcParams& P, int blocks, F kernel) {
   Q.segs = segs;
   Q.seg_len = (P.n_steps + segs - 1) / segs;
   Q.seg_blocks = blocks;
+  relay_last() = {{segs, blocks, occ_seen}};
   return Q;
 }
 

@@ -234,6 +234,13 @@ class Engine(object):
         """Per-handle option (arp_model_set_option), e.g. ("german_math", "f32" | "bf16x3" | "auto")."""
         _lib.check(self._L.arp_model_set_option(self._h, key.encode(), value.encode()))
 
+    def relay_geometry(self):
+        """What this thread's last hmc_run / interleaved_run launch did (arp_relay_geometry): relay segments, chain blocks,
+        workgroups of the kernel per CU."""
+        out = (C.c_int32 * 3)()
+        _lib.check(self._L.arp_relay_geometry(out))
+        return dict(zip(("segments", "chain_blocks", "workgroups_per_cu"), [int(v) for v in out]))
+
     def vi_geometry(self):
         """Shape of this thread's last vi_run launch (arp_vi_geometry): threads per workgroup, sample groups G and row
         parts R per learning rate, learning rates per launch, workgroups resident together, workgroups one CU holds."""

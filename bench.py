@@ -446,6 +446,10 @@ def main():
     elapsed = time.perf_counter() - t0
     per_launch_ms = [float(a.elapsed_time(b)) for a, b in ev]
     kern_ms = float(np.mean(per_launch_ms))
+    try:
+        relay_segments = eng.relay_geometry()["segments"]     # of the last timed launch (arp_relay_geometry)
+    except Exception:
+        relay_segments = None
     # the shader clock this box holds under a vector-bound load, measured now, while the chip is at the temperature and power
     # state of the timed region (arp_clock_probe: s_memtime / s_memrealtime around 10 ms of packed FMAs on every SIMD)
     try:
@@ -809,6 +813,7 @@ def main():
             out_rccl = world
         else:
             out_rccl = None
+        roof["relay_segments"] = relay_segments
         roof["clock_ghz_live"] = clock_live
         roof["clock_live_note"] = ("shader clock held under 10 ms of packed FMAs on every SIMD right after the timed region "
                                    "(arp_clock_probe); the 157.3 TFLOP/s peak assumes 2.4 GHz: frac x 2.4 / clock_ghz_live is the "

@@ -220,6 +220,11 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
  * together (= CUs in use when one fits per CU), workgroups of the kernel one CU holds}.  (bench.py: vi_kernel.) */
 int arp_vi_geometry(int32_t* out6);
 
+/* Measurement hook: what the calling thread's last arp_hmc_run / arp_interleaved_run launch did -- out3 = {relay segments
+ * the launch's steps were cut into (1 = one workgroup per chain block), chain blocks, workgroups of
+ * the kernel one CU holds (0 where the question did not arise)}. */
+int arp_relay_geometry(int32_t* out3);
+
 /* Effective sample size of every series of a recorded trace (replaces tfp.mcmc.effective_sample_size with its
  * defaults, inference.py:240, 327): `trace` holds n_samples rows of `row_stride` floats, series i is column i
  * (i < n_series, e.g. n_series = C*D of a [S][C][D] trace); ess[i] = S / (-1 + 2 sum_k (S-k)/S rho_k) with the

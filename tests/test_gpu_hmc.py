@@ -675,3 +675,37 @@ def test_relay_segments_in_every_chain_kernel(gpu, monkeypatch, mname, kind, cha
         got = run(segs)
         for k, (x, y) in enumerate(zip(ref, got)):
             assert np.array_equal(x, y, equal_nan=True), (segs, k)
+
+
+def test_relay_rule(gpu, monkeypatch):
+    """Which launches the library cuts into relay segments (host_common.h: relay_plan), read back through arp_relay_geometry: 8
+    from 512 steps per launch on and 4 from 256 where the chain blocks are at least one round of the kernel's resident
+    workgroups; none for shorter launches, for fewer blocks, or for kernels that hold a whole CU per workgroup."""
+    from autoreparam_amd import engine, _lib
+    monkeypatch.delenv("ARP_SEGMENTS", raising=False)
+
+    def segs(mname, chains, T, sampler="i", lanes=0):
+        sp = helpers.spec(mname)
+        eng = _eng(mname, gpu)
+        eng.set_param(0, "CP"); eng.set_param(1, "NCP")
+        st = engine.ChainState(torch.as_tensor(helpers.states(sp, chains, seed=1, scale=0.05), device=gpu))
+        e = np.full(sp.D, 1e-3, np.float32)
+        if sampler == "i":
+            eng.interleaved_run(st, e, e, 1, 1, T, seed=1, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=0, lanes=lanes)
+        else:
+            eng.hmc_run(st, e, 1, T, seed=1, adapt_kind=_lib.ADAPT_NONE, lanes=lanes)
+        torch.cuda.synchronize()
+        return eng.relay_geometry()
+
+    g = segs("radon_PA", 65536, 1024)
+    assert g["segments"] == 8 and g["chain_blocks"] == 1024 and g["workgroups_per_cu"] == 2        # the headline launch
+    assert segs("radon_PA", 65536, 300)["segments"] == 4
+    assert segs("radon_PA", 65536, 255)["segments"] == 1
+    assert segs("radon_PA", 32768, 512)["segments"] == 8          # exactly one round
+    assert segs("radon_PA", 16384, 512)["segments"] == 1          # half a round (4 lanes per chain: 256 blocks)
+    assert segs("radon_PA", 8192, 512)["segments"] == 1           # the 8-GPU shard (8 lanes per chain: 256 blocks)
+    assert segs("election", 131072, 512, "hmc")["segments"] == 8
+    g = segs("german", 16384, 512, "hmc")                          # 256 blocks: under the two-per-CU round, not even asked
+    assert g["segments"] == 1 and g["chain_blocks"] == 256
+    g = segs("time_series", 65536, 512, "hmc")                     # 1 024 blocks, but one workgroup holds a CU: stays whole
+    assert g["segments"] == 1 and g["workgroups_per_cu"] == 1 and g["chain_blocks"] == 1024
