@@ -605,7 +605,7 @@ static int relay_prepare(arp_model* m, const arp_hmc_config* cfg, int K, bool al
   P->segs = 1; P->seg_len = cfg->n_steps; P->seg_blocks = 0; P->seg_epoch = 0; P->seg_flags = nullptr;
   if (!allowed || cfg->n_steps < 256) return 0;
   int segs = -1, dbg = 0;
-  if (debug_int("ARP_SEGMENTS", &dbg) && dbg >= 1 && dbg <= 8) segs = dbg;
+  if (debug_int("ARP_SEGMENTS", &dbg) && dbg >= 1 && dbg <= 64) segs = dbg;
   if (segs == 1) return 0;
   const long long blocks = ((long long)cfg->n_chains * K + kBlock - 1) / kBlock;
   if (segs == -1) {
