@@ -167,7 +167,11 @@ def _ess_report(info, model_config, flags, dev, ess_parts=None):
         # arithmetic) -- the summary says so instead of hiding them in the mean.
         parts = [np.asarray(e) for e in ess_parts]
         n = parts[0].shape[0] if parts else 0
-        local = sum(bool(any(np.isnan(p[c]).any() for p in parts)) for c in range(n))
+        stuck = np.zeros(n, bool)
+        for p in parts:                                        # [C, *event] each: one vector pass per part, not one per chain
+            if n:                                              # (a rank can hold no ESS chains in a streaming run)
+                stuck |= np.isnan(p.reshape(n, int(np.prod(p.shape[1:], dtype=np.int64)))).any(axis=1)
+        local = int(stuck.sum())
         n_const = int(parallel.all_reduce_sum(float(local), dev).item())
         if n_const:
             util.print_("    {} chain(s) never moved after burn-in (constant series: ESS nan, counted as 0 by get_min_ess)".format(n_const))

@@ -125,7 +125,10 @@ def get_min_ess(ess):
     then mean and standard error over chains.  `ess` is a list of [C, *event] arrays."""
     ess = [np.nan_to_num(np.asarray(e)) for e in ess]
     num_chains = ess[0].shape[0]
-    min_ess = [min(np.array(e[c]).min() for e in ess) for c in range(num_chains)]
+    # (the reference loops over chains in Python; the same minima, one vector pass per part -- 0.5 s at 65 536 chains otherwise)
+    if num_chains == 0:
+        return np.float32("nan"), np.float32("nan")
+    min_ess = np.minimum.reduce([e.reshape(num_chains, int(np.prod(e.shape[1:], dtype=np.int64))).min(axis=1) for e in ess])
     mean_ess = np.mean(min_ess)
     sem_ess = np.std(min_ess) / np.sqrt(len(min_ess))
     return mean_ess, sem_ess
