@@ -132,3 +132,58 @@ def get_min_ess(ess):
     mean_ess = np.mean(min_ess)
     sem_ess = np.std(min_ess) / np.sqrt(len(min_ess))
     return mean_ess, sem_ess
+
+
+def stddvs_to_mcmc_step_sizes(results, num_leapfrog_steps):
+    """reference util.py:308-313: sqrt(2 mean(scale)) / L per `*_scale` entry of a stored fit."""
+    L = float(num_leapfrog_steps)
+    return [np.sqrt(2 * np.mean(results[k])) / L for k in results.keys() if k.endswith("_scale")]
+
+
+def reject_outliers(data, m=1.5):
+    """reference util.py:418-423: the entries within m standard deviations of the mean (all of them if none is)."""
+    data = np.asarray(data)
+    kept = data[np.abs(data - np.mean(data)) < m * np.std(data)]
+    return kept if kept.size else data
+
+
+def get_min_ess_other(ess, num_chains=None):
+    """reference util.py:426-442: `ess` indexed [chain][part]; per chain the minimum over parts and elements, outliers
+    dropped (reject_outliers), then mean and standard error."""
+    num_chains = len(ess) if num_chains is None else num_chains
+    mins = np.array([min(np.nan_to_num(np.asarray(e)).min() for e in ess[c]) for c in range(num_chains)])
+    mins = reject_outliers(mins)
+    return np.mean(mins), np.std(mins) / np.sqrt(len(mins))
+
+
+def estimate_true_mean(sample_groups, esss):
+    """reference util.py:316-331: per group, each variable's sample mean weighted by the group's share of the total ESS."""
+    total = float(sum(esss))
+    return [[0 + w * np.mean(v) / total for v in group] for group, w in zip(sample_groups, esss)]
+
+
+def compute_V_cp(q, v):
+    """reference util.py:65-67: posterior covariance of the two-variable Gaussian hierarchy, centred coordinates."""
+    return np.array([[1.0 + v, 1.0], [1.0, q * v + 1.0]]) / (v * q + q + 1.0)
+
+
+def compute_V_ncp(q, v):
+    """reference util.py:70-72: the same covariance in non-centred coordinates."""
+    off = -np.sqrt(v) * q
+    return np.array([[q + 1, off], [off, v * q + 1]]) * (1 / (v * q + q + 1))
+
+
+def _condition_number(q, v, shared):
+    t = v * q + 1
+    root = 2 * np.sqrt(t * t - shared * (v * q + q + 1) * t)
+    return (2 * t + root) / (2 * t - root)
+
+
+def condition_number_cp(q, v):
+    """reference util.py:75-80: ratio of the eigenvalues of the centred posterior precision."""
+    return _condition_number(q, v, v / (v + 1))
+
+
+def condition_number_ncp(q, v):
+    """reference util.py:83-88: the same for the non-centred form."""
+    return _condition_number(q, v, 1 / (q + 1))

@@ -86,9 +86,35 @@ HEADLINE_COST = ISSUE_COST_2W
 HEADLINE_MIX = {"pk": 840.0, "trans": 76.0, "dpp": 76.0, "mad_u64": 37.0, "half_rate": 60.5, "fma3": 65.0, "mov": 77.5, "other": 336.5}
 
 
-def headline_issue_bound(clock_ghz, leapfrogs_per_step=8, chains_per_wave=16):
+_LEDGER_CLASS = {"pk_f32": "pk", "trans": "trans", "dpp": "dpp", "mad_u64": "mad_u64", "half_rate": "half_rate", "fma3": "fma3",
+                 "mov": "mov", "valu_other": "other"}
+
+
+def headline_mix():
+    """The headline kernel's VALU mix per wave and step: the `weighted` row of the newest profiles/rNN_headline_ledger.txt
+    (tools/asm_ledger.py over the ISA of the build that is benched); the round-4 constants above only if no ledger parses."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_headline_ledger.txt")), reverse=True):
+        try:
+            cols, row = None, None
+            for ln in open(path):
+                w = ln.split()
+                if w[:2] == ["block", "instr"]:
+                    cols = w[2:]
+                elif w and w[0] == "weighted" and cols:
+                    row = [float(v) for v in w[2:2 + len(cols)]]
+            if cols and row:
+                mix = {_LEDGER_CLASS[c]: v for c, v in zip(cols, row) if c in _LEDGER_CLASS}
+                if set(mix) == set(HEADLINE_MIX):
+                    return mix, "profiles/" + os.path.basename(path)
+        except (OSError, ValueError):
+            continue
+    return dict(HEADLINE_MIX), "bench.py constants (profiles/r04_headline_ledger.txt)"
+
+
+def headline_issue_bound(clock_ghz, leapfrogs_per_step=8, chains_per_wave=16, mix=None):
     """leapfrog-steps/s if all 1 024 SIMDs issued the headline step's instruction mix back to back"""
-    cyc = sum(HEADLINE_COST[k] * v for k, v in HEADLINE_MIX.items())
+    cyc = sum(HEADLINE_COST[k] * v for k, v in (mix or HEADLINE_MIX).items())
     return 256 * 4 * clock_ghz * 1e9 / cyc * chains_per_wave * leapfrogs_per_step, cyc
 
 
@@ -338,6 +364,9 @@ def main():
                     help="skip the secondary figures: profiler runs, so that every launch of the headline kernel in "
                          "the trace is a timed or warm-up step")
     ap.add_argument("--no-ess", action="store_true", help="skip the reference-flow ESS/sec run")
+    ap.add_argument("--verbose", action="store_true", help="let the CLI flows' progress through (to stderr)")
+    ap.add_argument("--extras", default=os.path.join(ROOT, "bench_extras.json"),
+                    help="where the secondary figures go (the stdout line stays short and names this path)")
     ap.add_argument("--no-trace", action="store_true", help="diagnostic: do not record trace rows")
     ap.add_argument("--stats", action="store_true", help="diagnostic: accumulate the in-kernel streaming statistics "
                                                          "(arp_hmc_io.stats) instead of writing trace rows")
@@ -348,8 +377,10 @@ def main():
         # anything in this process has touched the GPU (never an exec), relay the child's output (rank 0's one JSON
         # line goes to the inherited stdout) and leave with its return code
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
-    # stdout carries the ONE JSON line and nothing else: what the CLI flows print on the way (fits, tuning runs) goes to stderr
-    json_out, sys.stdout = sys.stdout, sys.stderr
+    # stdout carries the ONE short JSON line and nothing else, and stderr stays quiet, so that the line is also the last
+    # line of the combined stream: what the CLI flows print on the way (fits, tuning runs) is dropped (--verbose: to stderr)
+    json_out = sys.stdout
+    sys.stdout = sys.stderr if args.verbose else open(os.devnull, "w")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -402,9 +433,10 @@ def main():
     eps_i = np.full(D, 0.08 / (max(num_ls, 1) / 4.0) ** 2, np.float32)   # interleaved: eps0/(num_ls/4)^2
     eps_i[2] = 0.02 / (max(num_ls, 1) / 4.0) ** 2
 
-    def make_launcher(Tn, thin_n, chains=None, record=True, plain=False, stats=False, lanes=args.lanes):
+    def make_launcher(Tn, thin_n, chains=None, record=True, plain=False, stats=False, lanes=args.lanes, offset=None, q_init=None):
         """A closure that advances a fresh population by Tn sampler steps per call, with its own trace ring."""
-        qq = q0 if chains is None else q0[:chains]
+        qq = q_init if q_init is not None else (q0 if chains is None else q0[:chains])
+        off = chain_offset if offset is None else offset
         Cn = qq.shape[0]
         st = engine.ChainState(qq)
         rows = (Tn + thin_n - 1) // thin_n
@@ -415,36 +447,42 @@ def main():
         def launch():
             # rows cycle through a bounded buffer (n_burnin = steps done: row 0 is this launch's first sample)
             if inter and not plain:
-                eng.interleaved_run(st, eps_i, eps_i, num_ls, num_ls, Tn, seed=7, chain_offset=chain_offset,
+                eng.interleaved_run(st, eps_i, eps_i, num_ls, num_ls, Tn, seed=7, chain_offset=off,
                                     adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=10 ** 9, adapt_target=0.75, adapt_rate=0.05,
                                     n_burnin=st.step if not stats else 0, thin=thin_n, trace=trace,
                                     trace_centered=False, lanes=lanes, **skw)
             else:
-                eng.hmc_run(st, eps0, L, Tn, seed=7, chain_offset=chain_offset, adapt_kind=_lib.ADAPT_DUAL,
+                eng.hmc_run(st, eps0, L, Tn, seed=7, chain_offset=off, adapt_kind=_lib.ADAPT_DUAL,
                             n_adapt=10 ** 9, n_burnin=st.step if not stats else 0, thin=thin_n, trace=trace,
                             trace_centered=True, lanes=lanes, **skw)
         return launch, st
 
     rec = not args.no_trace
+
+    def timed_leg(launch):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; returns this
+        rank's wall time and its per-launch HIP-event times."""
+        for _ in range(args.warmup):
+            launch()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            ev[k][0].record()
+            launch()
+            ev[k][1].record()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return dt, [float(a.elapsed_time(b)) for a, b in ev]
+
     launch, st = make_launcher(T, thin, record=rec, stats=args.stats)
-    for _ in range(args.warmup):
-        launch()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        launch()
-        ev[k][1].record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    per_launch_ms = [float(a.elapsed_time(b)) for a, b in ev]
+    elapsed, per_launch_ms = timed_leg(launch)
     kern_ms = float(np.mean(per_launch_ms))
     try:
         relay_segments = eng.relay_geometry()["segments"]     # of the last timed launch (arp_relay_geometry)
@@ -482,6 +520,36 @@ def main():
     LL = 2 * num_ls if inter else L
     extras = {}
     secondary = world == 1 and not args.headline_only
+
+    # N > 1: the OTHER reading of the job, timed in the same run (same W and K, same barriers).  The headline leg is
+    # `--scaling` (default weak: --chains per GPU); the second leg is strong (--chains in total, C/N per rank: BASELINE
+    # configs[3] read literally) or, under --scaling strong, weak.  In the weak leg every GPU runs exactly the 1-GPU job,
+    # so weak_rate / N is this node's own 1-GPU rate and the strong leg's speed-up over it needs no second run.
+    other_leg = None
+    if world > 1:
+        if args.scaling == "weak":
+            lo2, hi2 = parallel.shard_bounds(args.chains, rank, world)
+            C2, off2, C2_total = hi2 - lo2, lo2, args.chains
+        else:
+            C2, off2, C2_total = args.chains, rank * args.chains, world * args.chains
+        if C2 > 0:
+            q2 = q0[:C2] if C2 <= q0.shape[0] else (0.1 * torch.randn(C2, D, generator=g)).to(dev)
+            launch2, st2 = make_launcher(T, thin, record=rec, offset=off2, q_init=q2)
+            el2, ms2 = timed_leg(launch2)
+            del launch2, st2, q2
+        else:                                                  # a rank that owns no chain still meets the barriers
+            el2, ms2 = timed_leg(lambda: None)
+        tm2 = torch.tensor([el2], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
+        el2 = float(tm2.item())
+        rate_main = C_total * T * args.steps * LL / elapsed
+        rate2 = C2_total * T * args.steps * LL / el2
+        weak_rate, strong_rate = (rate_main, rate2) if args.scaling == "weak" else (rate2, rate_main)
+        other_leg = {"chains_per_gpu": C2, "chains_total": C2_total, "leapfrog_steps_per_s": rate2,
+                     "ms_per_step": 1e3 * el2 / args.steps, "kernel_ms_this_rank": float(np.mean(ms2)) if ms2 else None,
+                     # strong leg over this node's 1-GPU rate (= weak rate / N; projected only in that the 1-GPU job ran
+                     # on N GPUs at once rather than alone)
+                     "speedup_vs_1gpu_projected": strong_rate / (weak_rate / world)}
     if secondary and inter:
         # round 1's workload for continuity: a trace row EVERY step, 32 steps per launch
         l32, _ = make_launcher(32, 1)
@@ -494,7 +562,7 @@ def main():
         if D == 71 and num_ls == 4 and args.lanes in (0, 4):
             # the same instruction mix minus the row stores (~ 20 instructions per step): how much of the launch the rows
             # account for beyond their instructions
-            extras["no_trace"]["issue_bound_frac"] = extras["no_trace"]["leapfrog_steps_per_s"] / headline_issue_bound(2.4)[0]
+            extras["no_trace"]["issue_bound_frac"] = extras["no_trace"]["leapfrog_steps_per_s"] / headline_issue_bound(2.4, mix=headline_mix()[0])[0]
         lst, _ = make_launcher(T, thin, stats=True)
         ms = _time_launches(lst, 5, 2)
         extras["in_kernel_stats"] = {"transitions_per_launch": T, "thin": thin, "stats_batch": 64, "kernel_ms": ms,
@@ -809,10 +877,6 @@ def main():
                         "note": "the byte model charges every transition a state load/store the fused kernel performs "
                                 "once per launch segment (the launch hands its chains from workgroup to workgroup up to eight "
                                 "times: DESIGN.md section 3, relay segments); the measured figure is what crosses HBM"}}
-        if dist is not None and dist.get_backend() == "nccl":
-            out_rccl = world
-        else:
-            out_rccl = None
         roof["relay_segments"] = relay_segments
         roof["clock_ghz_live"] = clock_live
         roof["clock_live_note"] = ("shader clock held under 10 ms of packed FMAs on every SIMD right after the timed region "
@@ -831,55 +895,85 @@ def main():
         if inter and D == 71 and num_ls == 4 and args.lanes in (0, 4):
             # how close the launch comes to issuing its own instruction mix back to back (<= 1 by construction)
             rate1 = C * T * LL / (kern_ms * 1e-3)
-            ib24, cyc = headline_issue_bound(2.4)
+            mix, mix_src = headline_mix()
+            ib24, cyc = headline_issue_bound(2.4, mix=mix)
             roof["issue_bound"] = {"frac": rate1 / ib24, "leapfrog_steps_per_s": ib24,
-                                   "cycles_per_wave_step_at_2.4GHz": cyc, "mix_per_wave_step": HEADLINE_MIX,
+                                   "cycles_per_wave_step_at_2.4GHz": cyc, "mix_per_wave_step": mix,
                                    "cost_cycles_at_2.4GHz": HEADLINE_COST,
-                                   "source": "profiles/r04_headline_ledger.txt (ISA ledger), tools/pk_vs_fma_2waves.hip (costs)",
+                                   "source": "%s (ISA ledger), tools/pk_vs_fma_2waves.hip (costs)" % mix_src,
                                    "note": "time based: the costs are times measured on this chip at two resident waves per SIMD "
                                            "(quoted as cycles at 2.4 GHz), so frac = priced time / measured time whatever clock "
                                            "the chip holds; <= 1 by construction"}
-        out = {
+        backend = dist.get_backend() if dist is not None else None
+        workload = (("radon --dataset=%s --method=i --inference=HMC (interleaved CP/NCP), %d chains%s, num_ls=%d+%d leapfrogs, "
+                     "%d interleaved steps per launch, simple step-size adaptation, CP trace row every %s step" % (
+                         args.dataset, args.chains, "/GPU" if args.scaling == "weak" else " total", num_ls, num_ls, T,
+                         {1: "", 2: "2nd"}.get(thin, "%d-th" % thin))) if inter else
+                    ("radon --dataset=%s --method=CP --inference=HMC, %d chains%s, L=%d, %d transitions per launch, "
+                     "dual-averaging adaptation, centred trace row every %d transition(s)" % (
+                         args.dataset, args.chains, "/GPU" if args.scaling == "weak" else " total", L, T, thin)))
+        cpu, cpu_shaped = None, None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(spec, num_ls if inter else L, 8192, 64, eps_i if inter else eps0, 8, inter)
+            except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
+                cpu = {"value": None, "error": repr(e)}
+            if not args.headline_only:
+                try:
+                    cpu_shaped = cpu_baseline_reference_shaped(spec, L)
+                except Exception as e:
+                    cpu_shaped = {"value": None, "error": repr(e)}
+        # ---- the ONE stdout line: the contract's keys, `roofline`, `cpu_baseline`, nothing long (< 4 KB) ----
+        hbm = roof["hbm"]
+        line = {
             "metric": "leapfrog-steps/sec (all chains) + ESS/sec, radon(%s) %d chains%s" % (
                 args.dataset, args.chains, " per GPU" if args.scaling == "weak" else " in total"),
             "value": value, "unit": "leapfrog-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "ess_per_sec": ess_info.get("ess_per_sec") if ess_info else None,
-            "config": {"workload": ("radon --dataset=%s --method=i --inference=HMC (interleaved CP/NCP), %d chains%s, "
-                                    "num_ls=%d+%d leapfrog steps, %d interleaved steps per launch, simple step-size "
-                                    "adaptation on both kernels, CP trace row every %s step" % (
-                                        args.dataset, args.chains, "/GPU" if args.scaling == "weak" else " total",
-                                        num_ls, num_ls, T, {1: "", 2: "2nd"}.get(thin, "%d-th" % thin))) if inter else
-                                   ("radon --dataset=%s --method=CP --inference=HMC, %d chains%s, L=%d, "
-                                    "%d transitions per launch, dual-averaging adaptation, centred trace row "
-                                    "every %d transition(s)" % (args.dataset, args.chains,
-                                                                 "/GPU" if args.scaling == "weak" else " total", L, T, thin)),
-                       "chains_per_gpu": C, "chains_total": C_total, "num_leapfrog_steps": LL, "transitions_per_step": T,
-                       "trace_thin": thin if rec else 0, "D": D, "lanes_per_chain": args.lanes,
+            "config": {"workload": workload, "chains_per_gpu": C, "chains_total": C_total, "num_leapfrog_steps": LL,
+                       "transitions_per_step": T, "trace_thin": thin if rec else 0, "D": D, "lanes_per_chain": args.lanes,
                        "parallelism": "chains sharded, %d rank(s), %s scaling" % (world, args.scaling)},
-            "roofline": roof,
+            "roofline": {"bound": roof["bound"], "achieved": roof["achieved"], "peak": roof["peak"], "unit": roof["unit"],
+                         "frac": roof["frac"], "traffic": roof["traffic"], "kernel": roof["kernel"], "kernel_ms": kern_ms,
+                         "algorithmic_flop_per_leapfrog": flop_lf,
+                         "hbm": {k: hbm[k] for k in ("algorithmic_bytes_per_launch", "algorithmic_frac_of_8TBps",
+                                                     "measured_bytes_per_launch", "measured_frac_of_8TBps")},
+                         "clock_ghz_live": clock_live, "frac_of_peak_at_live_clock": roof["frac_of_peak_at_live_clock"],
+                         "issue_bound_frac": roof.get("issue_bound", {}).get("frac"), "relay_segments": relay_segments},
             "accept_rate": accept_rate, "ranks": world,
             # the transport the end-of-run exchange actually ran on: "nccl" is RCCL; "gloo" only in the tests that put
             # two ranks on one GPU; None for a single rank (no process group)
-            "dist_backend": dist.get_backend() if dist is not None else None,
-            "stats_allgather_s": t_coll,
-            "kernel_ms_per_rank": rank_ms, "rank_imbalance_max_over_min": max(rank_ms) / min(rank_ms), "ess": ess_info,
+            "dist_backend": backend, "stats_allgather_s": t_coll,
+            "kernel_ms_per_rank": [round(v, 4) for v in rank_ms], "rank_imbalance_max_over_min": max(rank_ms) / min(rank_ms),
         }
-        if out_rccl is not None:
-            out["rccl_ranks"] = out_rccl      # only when the collectives really ran over RCCL
-        out.update(extras)
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(spec, num_ls if inter else L, 8192, 64, eps_i if inter else eps0, 8,
-                                                   inter)
-            except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
-                out["cpu_baseline"] = {"value": None, "error": repr(e)}
-            try:
-                out["cpu_baseline_reference_shaped"] = cpu_baseline_reference_shaped(spec, L)
-            except Exception as e:
-                out["cpu_baseline_reference_shaped"] = {"value": None, "error": repr(e)}
-        print(json.dumps(out), file=json_out, flush=True)
+        if backend == "nccl":
+            line["rccl_ranks"] = world           # only when the collectives really ran over RCCL
+        if other_leg is not None:
+            line["scaling_strong" if args.scaling == "weak" else "scaling_weak"] = other_leg
+        if cpu is not None:
+            line["cpu_baseline"] = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "sample", "error") if k in cpu}
+        # ---- everything else: bench_extras.json ----
+        full = dict(line)
+        full["roofline"] = roof
+        full["ess"] = ess_info
+        full.update(extras)
+        if cpu is not None:
+            full["cpu_baseline"] = cpu
+        if cpu_shaped is not None:
+            full["cpu_baseline_reference_shaped"] = cpu_shaped
+        try:
+            with open(args.extras, "w") as f:
+                json.dump(full, f, indent=1)
+            line["extras"] = os.path.relpath(args.extras, ROOT) if args.extras.startswith(ROOT) else args.extras
+        except OSError as e:
+            line["extras"] = None
+            line["extras_error"] = repr(e)
+        text = json.dumps(line)
+        assert len(text) < 4096 and "\n" not in text, len(text)
+        sys.stderr.flush()
+        print(text, file=json_out, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -25,7 +25,7 @@ def test_bench_reports_the_transport_it_used():
     s = _src()
     assert '"dist_backend"' in s and '"ranks"' in s
     # rccl_ranks is only emitted under the nccl backend
-    assert re.search(r'get_backend\(\) == "nccl"', s)
+    assert re.search(r'if backend == "nccl":\n\s+line\["rccl_ranks"\]', s)
 
 
 def test_oracle_only_in_the_cpu_baseline_leg():
@@ -54,3 +54,32 @@ def test_bench_launches_its_own_ranks_when_asked_for_more_than_one_gpu():
     if not torch.cuda.is_available():
         assert "No HIP GPUs are available" in r.stderr or "Found no NVIDIA driver" in r.stderr or "no GPU" in r.stderr.lower(), r.stderr[-1500:]
         assert "torch.distributed.elastic" in r.stderr or "ChildFailedError" in r.stderr      # the failure came from the children
+
+
+def test_stdout_line_is_short_and_the_rest_goes_to_the_extras_file():
+    """Round 5's line grew past what the driver's parser reads (BENCH_r05.json: parsed null).  The line is built from a
+    fixed short key set and bench.py refuses to print one of 4 KB or more; the long figures go to --extras; nothing the CLI
+    flows print reaches either stream by default.  (tests/test_gpu_scaling.py::test_bench_stdout_is_one_json_line runs it.)"""
+    s = _src()
+    assert "assert len(text) < 4096" in s
+    assert 'add_argument("--extras"' in s and 'add_argument("--verbose"' in s
+    assert 'sys.stdout = sys.stderr if args.verbose else open(os.devnull, "w")' in s
+    line_block = s[s.index("        line = {"):s.index("        # ---- everything else: bench_extras.json")]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "workload", "roofline", "ess_per_sec", "ranks", "dist_backend",
+              "cpu_baseline", "bound", "achieved", "peak", "frac", "traffic", "kernel_ms"):
+        assert '"%s"' % k in line_block, k
+    for k in ("other_models", "vi_kernel", "german_credit", "election", "strong_shard", '"profile"', '"note"'):
+        assert k not in line_block, k
+    # exactly one print to the real stdout
+    assert len(re.findall(r"file=json_out", s)) == 1
+
+
+def test_issue_mix_comes_from_the_newest_ledger():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    mix, src = b.headline_mix()
+    assert src.startswith("profiles/r") and src.endswith("_headline_ledger.txt")
+    assert set(mix) == set(b.HEADLINE_COST) and 1400 < sum(mix.values()) < 1700

@@ -124,8 +124,12 @@ def test_two_rank_bench_line(scaling):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    j = json.loads(lines[0])
+    j = check_driver_line("\n".join(lines))
     assert j["n_gpus"] == 2 and j["ranks"] == 2 and j["scaling"] == scaling and j["steps"] == 3
+    # the other reading of the job, timed in the same run: strong (4 096 chains in total) beside weak and the reverse
+    o = j["scaling_strong" if scaling == "weak" else "scaling_weak"]
+    assert o["chains_per_gpu"] == (2048 if scaling == "weak" else 4096) and o["chains_total"] == 2 * o["chains_per_gpu"]
+    assert o["leapfrog_steps_per_s"] > 0 and o["speedup_vs_1gpu_projected"] > 0
     # the transport is reported as what it was: RCCL on a two-GPU box, gloo when both ranks share the test box's GPU
     if torch.cuda.device_count() >= 2:
         assert j["dist_backend"] == "nccl" and j["rccl_ranks"] == 2
@@ -209,18 +213,55 @@ def test_one_rank_bench_under_the_launcher_reports_rccl():
     assert j["stats_allgather_s"] > 0 and 0.3 < j["accept_rate"] < 1.0
 
 
-def test_bench_stdout_is_one_json_line():
-    """`python bench.py` the way the driver runs the N = 1 bench: the CLI flows it drives (VI fits, tuning runs, the ESS run)
-    print their progress to stderr; stdout holds the one JSON line and nothing else."""
+REQUIRED_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                      "vs_baseline", "dtype", "data", "config", "roofline", "ess_per_sec", "ranks", "dist_backend")
+REQUIRED_ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
+                          "algorithmic_flop_per_leapfrog", "hbm")
+
+
+def check_driver_line(stdout, combined=None):
+    """What the round-end driver needs from `python bench.py`: stdout is ONE line, shorter than 4 KB, JSON, with the
+    contract's keys; and it is also the last line of stdout + stderr read as one stream."""
+    lines = stdout.splitlines()
+    assert len(lines) == 1, stdout[:2000]
+    assert len(lines[0]) < 4096, len(lines[0])
+    j = json.loads(lines[0])
+    for k in REQUIRED_LINE_KEYS:
+        assert k in j, k
+    for k in REQUIRED_ROOFLINE_KEYS:
+        assert k in j["roofline"], k
+    assert "workload" in j["config"] and "model" not in j["config"]
+    if combined is not None:
+        last = [l for l in combined.splitlines() if l.strip()][-1]
+        assert json.loads(last) == j
+    return j
+
+
+def test_bench_stdout_is_one_json_line(tmp_path):
+    """`python bench.py` the way the driver runs the N = 1 bench: stdout holds the one short JSON line and nothing else; the
+    CLI flows it drives (VI fits, tuning runs, the ESS run) are silent, so the line is also the last line of the combined
+    stream; the long secondary figures are in the extras file the line names."""
     env = dict(os.environ, PYTHONPATH=ROOT)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
+    ex = str(tmp_path / "extras.json")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--chains", "4096", "--transitions", "32",
-           "--no-cpu-baseline"]
+           "--extras", ex]
     r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = r.stdout.splitlines()
-    assert len(lines) == 1, r.stdout[:2000]
-    j = json.loads(lines[0])
-    assert j["n_gpus"] == 1 and j["ess_per_sec"] > 0 and "roofline" in j
-    assert "finished optimization" in r.stderr          # the flow's chatter went there
+    j = check_driver_line(r.stdout)
+    assert j["n_gpus"] == 1 and j["ess_per_sec"] > 0
+    assert "finished optimization" not in r.stderr and "ESS" not in r.stderr
+    cb = j["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["unit"] == "leapfrog-steps/s" and cb["sample"]
+    full = json.load(open(ex))
+    assert j["extras"] == ex
+    for k in ("other_models", "vi_kernel", "german_credit", "election", "strong_shard", "ess", "ess_kernel"):
+        assert k in full, k
+    assert "profile" not in j["roofline"]
+    # both streams as the driver's log has them
+    r2 = subprocess.run(cmd + ["--no-cpu-baseline", "--headline-only"], env=env, cwd=ROOT, timeout=900, stdout=subprocess.PIPE,
+                        stderr=subprocess.STDOUT, text=True)
+    assert r2.returncode == 0
+    last = [l for l in r2.stdout.splitlines() if l.strip()][-1]
+    assert json.loads(last)["n_gpus"] == 1 and len(last) < 4096
