@@ -439,7 +439,17 @@ int arp_model_create(const arp_dataset* data, arp_model** out) {
   m->model = data->model;
   m->host_only = host_only();
   if (m->host_only) m->device = -1;
-  else ARP_HIP_OK(hipGetDevice(&m->device));
+  else {
+    ARP_HIP_OK(hipGetDevice(&m->device));
+    hipDeviceProp_t prop;
+    ARP_HIP_OK(hipGetDeviceProperties(&prop, m->device));
+    m->cus = prop.multiProcessorCount;
+    int coop = 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, m->device) == hipSuccess) m->coop_ok = coop != 0;
+    ARP_HIP_OK(hipHostMalloc((void**)&m->relay_err, sizeof(unsigned), hipHostMallocMapped));
+    *m->relay_err = 0u;
+    ARP_HIP_OK(hipHostGetDevicePointer((void**)&m->relay_err_dev, m->relay_err, 0));
+  }
   int rc;
   switch (data->model) {
     case ARP_MODEL_RADON: rc = build_radon(m.get(), data); break;
@@ -491,6 +501,7 @@ int arp_model_destroy(arp_model* m) {
   if (m->dev_tables) (void)hipFree(m->dev_tables);
   for (int w = 0; w < 2; ++w) if (m->dev_ab[w]) (void)hipFree(m->dev_ab[w]);
   if (m->vi_ws) (void)hipFree(m->vi_ws);
+  if (m->relay_err) (void)hipHostFree(m->relay_err);
   delete m;
   return 0;
 }
@@ -507,6 +518,15 @@ int arp_model_set_option(arp_model* m, const char* key, const char* value) {
       if (!m->german.Xb) { set_error("arp_model_set_option: this design matrix has more than 8 columns that need three bf16 pieces"); return 1; }
       m->german_math = 2;
     } else { set_error("arp_model_set_option: german_math is one of auto, f32, bf16x3"); return 1; }
+    return 0;
+  }
+  if (!strcmp(key, "vi_launch")) {
+    // how arp_vi_run starts a kernel whose workgroups wait for each other: "cooperative" (hipLaunchCooperativeKernel),
+    // "plain" (ordinary launch, one at a time per process) or "auto" (cooperative where the device supports it)
+    if (!strcmp(value, "auto")) m->vi_launch = 0;
+    else if (!strcmp(value, "plain")) m->vi_launch = 1;
+    else if (!strcmp(value, "cooperative")) m->vi_launch = 2;
+    else { set_error("arp_model_set_option: vi_launch is one of auto, plain, cooperative"); return 1; }
     return 0;
   }
   set_error("arp_model_set_option: unknown key");
@@ -603,27 +623,40 @@ static int check_adapt(const arp_hmc_config* cfg) {
 // -1 (the launcher decides with its kernel's occupancy), a forced count (ARP_DEBUG=1 ARP_SEGMENTS=n) or 1 (`allowed` false).
 static int relay_prepare(arp_model* m, const arp_hmc_config* cfg, int K, bool allowed, hipStream_t stream, HmcParams* P) {
   P->segs = 1; P->seg_len = cfg->n_steps; P->seg_blocks = 0; P->seg_epoch = 0; P->seg_flags = nullptr;
+  P->seg_ctrl = nullptr; P->seg_err_host = nullptr; P->seg_timeout = 6000000000ull; P->seg_fault = 0;
+  arp::relay_device_cus() = m->cus;
   if (!allowed || cfg->n_steps < 256) return 0;
   int segs = -1, dbg = 0;
   if (debug_int("ARP_SEGMENTS", &dbg) && dbg >= 1 && dbg <= 64) segs = dbg;
   if (segs == 1) return 0;
   const long long blocks = ((long long)cfg->n_chains * K + kBlock - 1) / kBlock;
-  if (segs == -1) {
-    // no kernel gets segments below one round of two workgroups per CU (relay_plan): spare those launches the allocation
-    static thread_local int cus_of[64] = {0};
-    int& cus = cus_of[m->device & 63];
-    if (cus <= 0) {
-      hipDeviceProp_t prop;
-      ARP_HIP_OK(hipGetDeviceProperties(&prop, m->device));
-      cus = prop.multiProcessorCount;
-    }
-    if (blocks < 2LL * cus) return 0;
-  }
+  // no kernel gets segments below one round of two workgroups per CU (relay_plan): spare those launches the allocation
+  if (segs == -1 && blocks < 2LL * m->cus) return 0;
+  // one zeroed flag word per chain block, then the launch's ticket counter and its failure word
   void* flags = nullptr;
-  ARP_HIP_OK(hipMallocAsync(&flags, (size_t)blocks * sizeof(unsigned), stream));
-  ARP_HIP_OK(hipMemsetAsync(flags, 0, (size_t)blocks * sizeof(unsigned), stream));
+  const size_t bytes = ((size_t)blocks + 2) * sizeof(unsigned);
+  ARP_HIP_OK(hipMallocAsync(&flags, bytes, stream));
+  const hipError_t zeroed = hipMemsetAsync(flags, 0, bytes, stream);
+  if (zeroed != hipSuccess) {
+    (void)hipFreeAsync(flags, stream);
+    ARP_HIP_OK(zeroed);
+  }
   P->segs = segs; P->seg_blocks = (int)blocks; P->seg_epoch = 0u; P->seg_flags = (unsigned*)flags;
+  P->seg_ctrl = (unsigned*)flags + blocks;
+  P->seg_err_host = m->relay_err_dev;
+  // test hooks (ARP_DEBUG=1 only): a short time-out, and segments that never raise their flag -- the failure path on demand
+  if (debug_int("ARP_RELAY_TIMEOUT_MS", &dbg) && dbg > 0) P->seg_timeout = 100000ull * (unsigned long long)dbg;
+  if (debug_int("ARP_RELAY_FAULT", &dbg) && dbg == 1) P->seg_fault = 1;
   return 0;
+}
+// a relay launch of this handle whose hand-over timed out (kernels.h: relay_begin) since the last look: report it once
+static int relay_failed(arp_model* m, const char* where) {
+  if (!m || !m->relay_err) return 0;
+  if (__atomic_load_n(m->relay_err, __ATOMIC_ACQUIRE) == 0u) return 0;
+  __atomic_store_n(m->relay_err, 0u, __ATOMIC_RELEASE);
+  set_error(std::string(where) + ": a relay hand-over inside an earlier chain launch of this handle timed out (was the device "
+            "taken away for a minute?); that launch left its chains partly advanced -- discard them");
+  return 1;
 }
 static int relay_release(const HmcParams& P, hipStream_t stream) {
   if (P.seg_flags) ARP_HIP_OK(hipFreeAsync(P.seg_flags, stream));
@@ -677,11 +710,18 @@ static int fill_params(arp_model* m, const arp_hmc_config* cfg, const arp_hmc_io
   P.L1 = 0; P.adapt1 = nullptr; P.accept_count1 = nullptr; P.eps0_1 = nullptr; P.trace_accept1 = nullptr;
   P.rec_accept1 = nullptr;
   P.segs = 1; P.seg_len = cfg->n_steps; P.seg_blocks = 0; P.seg_epoch = 0; P.seg_flags = nullptr;
+  P.seg_ctrl = nullptr; P.seg_err_host = nullptr; P.seg_timeout = 6000000000ull; P.seg_fault = 0;
   return 0;
+}
+
+int arp_model_check(arp_model* m) {
+  if (!m) { set_error("arp_model_check: null argument"); return 1; }
+  return relay_failed(m, "arp_model_check");
 }
 
 int arp_hmc_run(arp_model* m, int which, const arp_hmc_config* cfg, const arp_hmc_io* io, void* stream) {
   if (!m || !cfg || !io || which < 0 || which > 1) { set_error("arp_hmc_run: null argument"); return 1; }
+  if (relay_failed(m, "arp_hmc_run")) return 1;
   HmcParams P;
   if (fill_params(m, cfg, io, true, &P)) return 1;
   if (cfg->n_steps == 0) return 0;
@@ -712,6 +752,7 @@ int arp_interleaved_run(arp_model* m, const arp_hmc_config* cfg, int n_leapfrog_
     set_error("arp_interleaved_run: k0.logp is required whenever k0.grad is given (pass both or neither)");
     return 1;
   }
+  if (relay_failed(m, "arp_interleaved_run")) return 1;
   HmcParams P;
   if (fill_params(m, cfg, &io->k0, false, &P)) return 1;
   if (io->trace_accept1 && !P.n_samples) P.n_samples = cfg->n_samples;
@@ -802,14 +843,12 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   int dbg = 0;
   if (debug_int("ARP_VI_G", &dbg) && dbg > 0 && !o->vi_parts) G = std::min(G, dbg);      // experiments (ARP_DEBUG=1 only)
   if (debug_int("ARP_VI_R", &dbg) && dbg > 0 && o->vi_parts) R = dbg;
-  hipDeviceProp_t prop;
-  ARP_HIP_OK(hipGetDeviceProperties(&prop, m->device));
   int occ = o->vi_occ ? o->vi_occ() : 0;
   if (occ <= 0) { set_error("arp_vi_run: the VI kernel does not fit on this device (occupancy query)"); return 1; }
   // every workgroup of a group has to be resident together (they wait for each other twice per step).  One or two per
   // CU is an LDS or register-file limit, which the query gets right; at more than that it can be one workgroup per CU
   // high (MI355X_MICROARCH.md, residency: the scalar-register edge), so one is given away
-  const long long capacity = (long long)(occ > 2 ? occ - 1 : occ) * prop.multiProcessorCount;
+  const long long capacity = (long long)(occ > 2 ? occ - 1 : occ) * m->cus;
   while ((long long)G * R > capacity && R > 1) R = (R + 1) / 2;
   if ((long long)G * R > capacity && o->vi_parts) {
     set_error("arp_vi_run: n_mc draws of this model do not fit on the device in one pass");   // 4 096 draws: 128 workgroups
@@ -832,15 +871,19 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   P.err = (int*)m->vi_ws;
   P.xch = GR > 1 ? (unsigned long long*)((char*)m->vi_ws + 256) : nullptr;
   g_vi_geometry = {B, G, R, groups_per_launch, (int)std::min<long long>((long long)cfg->n_lr * GR, capacity), occ};
+  // A group's workgroups wait for each other, so all of them must be resident.  Cooperative launch (the default where the
+  // device has it): the runtime guarantees it or refuses the launch, also against other launches of this process.  Plain
+  // launch: residency rests on the occupancy arithmetic above plus one such launch at a time in this process (the mutex).
+  const bool coop = GR > 1 && (m->vi_launch == 2 || (m->vi_launch == 0 && m->coop_ok));
+  if (m->vi_launch == 2 && !m->coop_ok) { set_error("arp_vi_run: vi_launch=cooperative but the device does not support cooperative launches"); return 1; }
   std::unique_lock<std::mutex> one_at_a_time(g_vi_launch_mutex, std::defer_lock);
-  if (GR > 1) one_at_a_time.lock();
+  if (GR > 1 && !coop) one_at_a_time.lock();
   for (int lr0 = 0; lr0 < cfg->n_lr; lr0 += groups_per_launch) {
     const int ng = std::min(groups_per_launch, cfg->n_lr - lr0);
     // every polled word starts at zero (epochs start at 1): the flag and this launch's granules
     ARP_HIP_OK(hipMemsetAsync(m->vi_ws, 0, need, (hipStream_t)stream));
     P.lr0 = lr0;
-    o->vi(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, ng, (hipStream_t)stream);
-    ARP_HIP_OK(hipGetLastError());
+    ARP_HIP_OK(o->vi(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, ng, coop, (hipStream_t)stream));
     if (GR > 1) {
       // the hand-offs' waits are bounded: a group that was not resident together reports it here instead of hanging
       int err = 0;

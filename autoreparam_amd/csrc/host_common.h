@@ -48,7 +48,9 @@ struct LaneOps {
   void (*interleaved)(const void* args, const float* a0, const float* b0, const float* a1, const float* b1,
                       const HmcParams& P, hipStream_t s);
   // mean-field VI: `n_groups` learning rates x (P.G x P.R) workgroups of vi_block threads (kernels.h: vi_kernel)
-  void (*vi)(const void* args, const float* a, const float* b, const ViParams& P, int n_groups, hipStream_t s);
+  // coop: hipLaunchCooperativeKernel -- the runtime itself guarantees that every workgroup of the grid is resident (or
+  // refuses the launch), which is what the in-launch hand-offs of a learning rate's group need
+  hipError_t (*vi)(const void* args, const float* a, const float* b, const ViParams& P, int n_groups, bool coop, hipStream_t s);
   // compile-time parameterisations (nullptr when the lane model has none): hmc for CP / NCP,
   // interleaved for the (CP, NCP) pair
   void (*hmc_cp)(const void* args, const float* a, const float* b, const HmcParams& P, hipStream_t s);
@@ -76,16 +78,10 @@ template <class L> struct lane_vi_block<L, std::void_t<decltype(L::VI_BLOCK)>> {
 // decided), a forced count (experiments) or 1 (not allowed); the launcher knows its kernel and decides with its occupancy:
 // segments pay where the chain blocks are at least one round of resident workgroups (profiles/r05_relay_segments.txt) --
 // 8 from 512 steps per launch on, 4 from 256.
-inline int relay_device_cus() {
-  static thread_local int cus_of[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 0;
-  int& cus = cus_of[dev & 63];
-  if (cus <= 0) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    cus = prop.multiProcessorCount;
-  }
+// CUs of the device the calling thread's launch goes to: relay_prepare sets it from the handle (its device, cached at
+// arp_model_create) right before the launcher runs on the same thread
+inline int& relay_device_cus() {
+  static thread_local int cus = 0;
   return cus;
 }
 // what the calling thread's last chain launch did (arp_relay_geometry, a measurement hook): segments, chain blocks, workgroups of
@@ -162,10 +158,16 @@ struct Launch {
                        *(const typename Lane::Args*)args, a0, b0, a1, b1, Q);
   }
   static constexpr int kViB = lane_vi_block<Lane>::value;
-  static void vi(const void* args, const float* a, const float* b, const ViParams& P, int n_groups, hipStream_t s) {
-    if constexpr (Lane::HAS_VI)
+  static hipError_t vi(const void* args, const float* a, const float* b, const ViParams& P, int n_groups, bool coop, hipStream_t s) {
+    if constexpr (Lane::HAS_VI) {
+      if (coop) {
+        void* kargs[] = {const_cast<void*>(args), (void*)&a, (void*)&b, const_cast<ViParams*>(&P)};
+        return hipLaunchCooperativeKernel((const void*)vi_kernel<Lane, kViB>, dim3(n_groups * P.G * P.R), dim3(kViB), kargs, 0, s);
+      }
       hipLaunchKernelGGL((vi_kernel<Lane, kViB>), dim3(n_groups * P.G * P.R), dim3(kViB), 0, s,
                          *(const typename Lane::Args*)args, a, b, P);
+    }
+    return hipGetLastError();
   }
   static int vi_occ() {
     int n = 0;
@@ -339,6 +341,12 @@ struct arp_model {
   // hand-off workspace of the VI kernel (granules + the error flag in its first 256 bytes), grown on demand
   void* vi_ws = nullptr;
   size_t vi_ws_bytes = 0;
+  // pinned, device-visible word a relay launch sets when a hand-over timed out (kernels.h: relay_begin; arp_model_check)
+  unsigned* relay_err = nullptr;
+  unsigned* relay_err_dev = nullptr;
+  bool coop_ok = false;      // the device supports cooperative launches (hipDeviceAttributeCooperativeLaunch)
+  int vi_launch = 0;         // 0 auto (cooperative where supported), 1 plain launch + process-wide mutex, 2 cooperative (arp_model_set_option "vi_launch")
+  int cus = 0;               // CUs of `device` (relay decisions are made for the handle's device, not the current one)
   double const_base = 0.0;                       // parameterisation independent part of the dropped constant
   std::vector<std::pair<int, double>> top_scale; // (flattened index, log prior scale) of top-level latents
 };

@@ -41,24 +41,49 @@ struct HmcParams {
   int segs, seg_len, seg_blocks;
   unsigned seg_epoch;
   unsigned* seg_flags;
+  // seg_ctrl[0]: the launch's ticket counter (relay_begin), seg_ctrl[1]: set when a hand-over timed out (every waiter leaves);
+  // seg_err_host: the handle's pinned host word the same event is reported through (arp_model_check), or nullptr
+  unsigned* seg_ctrl;
+  unsigned* seg_err_host;
+  unsigned long long seg_timeout;   // ticks of the 100 MHz clock a segment waits for the one before it
+  int seg_fault;                    // test hook (ARP_DEBUG=1 ARP_RELAY_FAULT=1): segments never raise their flag
 };
 
 
 // ---------------------------------------------------------------------------
 // Relay.  The workgroups of a launch that are resident together (one or two per CU) are often exactly one or two rounds,
 // and then every CU does the same work however fast it runs: the launch ends with the slowest.  With P.segs > 1 the grid is
-// segs x seg_blocks workgroups, segment-major, each taking seg_len of the launch's steps for one block of chains; the
+// segs x seg_blocks workgroups, each taking seg_len of the launch's steps for one block of chains; the
 // state travels from a block's segment to the next through the HBM rows a chunked run uses between launches (q, grad,
-// logp, adapt, rng, counters, statistics), so the result is bit for bit the unsegmented launch's, and a CU that is free
+// logp, adapt, rng, counters, statistics), so the chain state is bit for bit the unsegmented launch's, and a CU that is free
 // takes the next (segment, block) in line whoever ran the block before (profiles/r05_relay_segments.txt).
+//
+// Which (segment, block) a workgroup takes is decided by a TICKET it draws when it starts (atomicAdd on the launch's own
+// counter), segment-major: ticket t = segment t / seg_blocks of block t % seg_blocks.  A workgroup behind segment 0 waits for
+// the flag its block's previous segment raises after its stores -- that is ticket t - seg_blocks, and every ticket below t
+// was drawn by a workgroup that started before this one: it is running or done, whatever order the dispatcher hands
+// workgroups out in and whatever else shares the device.  The lowest unfinished ticket never waits on an unfinished one, so
+// the launch always advances (no reliance on in-order dispatch: round 5's form indexed with blockIdx).
 // relay_begin rewrites the kernel's OWN copy of the parameters to the segment's view (steps, first transition, recording
-// schedule -- the arithmetic of arp_api.hip: fill_params) and, behind a segment, waits for the flag the segment before
-// raised after its stores (workgroups are handed out in index order, so that one is running or done); relay_end raises it.
+// schedule -- the arithmetic of arp_api.hip: fill_params); relay_end raises the flag.  A wait is bounded (seg_timeout):
+// on expiry the launch is marked failed -- device word for the other waiters, pinned host word for arp_model_check -- and
+// every workgroup still waiting leaves without touching the state (seg < 0: the kernels return at once).
 // ---------------------------------------------------------------------------
 struct RelayId { unsigned bid; int seg; };
 ARP_DEV RelayId relay_begin(HmcParams& P) {
   RelayId r{blockIdx.x, 0};
   if (P.segs > 1) {
+    __shared__ unsigned s_relay[2];      // ticket, abort
+    if (threadIdx.x == 0) {
+#ifdef ARP_EXP_RELAY_BLOCKIDX            // timing A/B only (tools/ab_lib.sh): round 5's index-ordered form
+      s_relay[0] = blockIdx.x;
+#else
+      s_relay[0] = __hip_atomic_fetch_add(P.seg_ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+      s_relay[1] = 0u;
+    }
+    __syncthreads();
+    r.bid = (unsigned)__builtin_amdgcn_readfirstlane((int)s_relay[0]);     // uniform: the segment's view stays in SGPRs
     r.seg = (int)(r.bid / (unsigned)P.seg_blocks);
     r.bid -= (unsigned)r.seg * (unsigned)P.seg_blocks;
     const int start = r.seg * P.seg_len;
@@ -78,13 +103,20 @@ ARP_DEV RelayId relay_begin(HmcParams& P) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
           __builtin_amdgcn_s_sleep(8);
-          // a minute of the 100 MHz clock (a segment is milliseconds; another process may hold the device for a while): if the
-          // hand-out order ever failed, stop loudly instead of hanging
-          if (__builtin_amdgcn_s_memrealtime() - t0 > 6000000000ull) __builtin_trap();
+          // a segment is milliseconds and the one waited for is resident, so this only expires if the device was taken away
+          // for the whole time-out (a minute unless the host says otherwise) -- or in the fault-injection test
+          bool failed = __hip_atomic_load(P.seg_ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+          if (!failed && __builtin_amdgcn_s_memrealtime() - t0 > P.seg_timeout) {
+            __hip_atomic_store(P.seg_ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (P.seg_err_host) __hip_atomic_store(P.seg_err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            failed = true;
+          }
+          if (failed) { s_relay[1] = 1u; break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // this CU's L1 (and stale L2 lines of other XCDs' data)
       }
       __syncthreads();
+      if (__builtin_amdgcn_readfirstlane((int)s_relay[1])) r.seg = -1;
     }
   }
   return r;
@@ -93,7 +125,7 @@ ARP_DEV void relay_end(const HmcParams& P, RelayId r) {
   if (P.segs > 1) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every storing wave drains its stores
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !P.seg_fault) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // the XCD's L2 written back
       __hip_atomic_store(P.seg_flags + r.bid, P.seg_epoch + (unsigned)r.seg + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -591,6 +623,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void hmc_kernel(
     typename Lane::Args A, const float* __restrict__ av, const float* __restrict__ bv, HmcParams P) {
   constexpr int K = Lane::K, ND = Lane::ND;
   const RelayId rid = relay_begin(P);
+  if (rid.seg < 0) return;                 // a hand-over timed out: leave the state as it is (kernels.h: relay_begin)
   long long t = (long long)rid.bid * kBlock + threadIdx.x;
   const int slot = (int)(t % K);
   long long c = t / K;
@@ -732,6 +765,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
     const float* __restrict__ av1, const float* __restrict__ bv1, HmcParams P) {
   constexpr int K = Lane::K, ND = Lane::ND;
   const RelayId rid = relay_begin(P);
+  if (rid.seg < 0) return;                 // a hand-over timed out: leave the state as it is (kernels.h: relay_begin)
   long long t = (long long)rid.bid * kBlock + threadIdx.x;
   const int slot = (int)(t % K);
   long long c = t / K;

@@ -452,11 +452,11 @@ struct GermanLane {
   //   log2 of the Bernoulli term  y eta - softplus(eta)  =  log2(rc) - y z + min(z, 0)
   // accumulated in log2 units in two packed accumulators (lp2; scaled by ln 2 once per gradient).  MASK: the tile ends
   // inside the block range (last tile of the data set), rows >= `rows` are padding and must not count.
-  // ASM_MIN = false (the bf16 x 3 path): min(z, 0) as a compiler-visible v_med3_f32.  The inline-asm v_min_f32 reads the
+  // min(z, 0) is a compiler-visible v_med3_f32 in every path.  (Rounds 3 - 5 had an inline-asm v_min_f32 here; it reads the
   // matrix-core result directly, and the hazard recogniser pads nothing in front of an asm statement: scheduled right
-  // behind a v_mfma_f32_16x16x32_bf16 it read the accumulator's OLD contents in the lanes written last (seen as a log
-  // density that was wrong in lanes 0 - 15 only and right again as soon as a printf moved the code).
-  template <bool LOGP, bool MASK, bool ASM_MIN = true>
+  // behind a v_mfma_f32_16x16x32_bf16 it read the accumulator's OLD contents in the lanes written last -- a log density
+  // wrong in lanes 0 - 15 only.  The f32 matrix-core path never showed it, but nothing kept the scheduler from it.)
+  template <bool LOGP, bool MASK>
   static ARP_DEV void residuals(const v4f& z, const v4f& yv, int row, int rows, float (&w)[4], v2f (&lp2)[2]) {
     float ex[4], rc[4];
     const v2f one = v2f{1.0f, 1.0f};
@@ -470,10 +470,8 @@ struct GermanLane {
 #pragma unroll
       for (int r_ = 0; r_ < 4; ++r_) lg[r_] = __builtin_amdgcn_logf(rc[r_]);   // log2(1 / (1 + ex)) = -log2(1 + ex)
 #pragma unroll
-      for (int r_ = 0; r_ < 4; ++r_) {  // min(z, 0); fminf() would add a v_max to quiet NaNs first
-        if constexpr (ASM_MIN) asm("v_min_f32 %0, 0, %1" : "=v"(mz[r_]) : "v"(z[r_]));
-        else mz[r_] = __builtin_amdgcn_fmed3f(z[r_], 0.0f, -3.4028234663852886e38f);
-      }
+      for (int r_ = 0; r_ < 4; ++r_)    // min(z, 0); fminf() would add a v_max to quiet NaNs first
+        mz[r_] = __builtin_amdgcn_fmed3f(z[r_], 0.0f, -3.4028234663852886e38f);
       const v2f y01 = v2f{yv[0], yv[1]}, y23 = v2f{yv[2], yv[3]};
       v2f t01 = vfma(-y01, v2f{z[0], z[1]}, v2f{mz[0], mz[1]}) + v2f{lg[0], lg[1]};
       v2f t23 = vfma(-y23, v2f{z[2], z[3]}, v2f{mz[2], mz[3]}) + v2f{lg[2], lg[3]};
@@ -965,7 +963,7 @@ struct GermanLane {
             v4f e = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int i = 0; i < 7; ++i) e = fmm(b, i, e);
-            residuals<LOGP, MASK, false>(e, __builtin_bit_cast(v4f, Y[b]), 16 * b + 4 * g, rows, w[b], lp2);
+            residuals<LOGP, MASK>(e, __builtin_bit_cast(v4f, Y[b]), 16 * b + 4 * g, rows, w[b], lp2);
           }
         };
         if (rows == kBf3Rows) forward(std::false_type{});

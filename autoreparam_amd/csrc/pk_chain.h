@@ -445,6 +445,7 @@ __global__ __launch_bounds__(kBlock, (STATS || MODE == ARP_PK_VIP_MINW2) && T::M
   constexpr int K = T::K, NP = T::NP, ND = T::ND, NG = T::NG;
   // chain of this lane (a launch holds fewer than 2^31 / K chains: 32-bit lane arithmetic)
   const RelayId rid = relay_begin(P);
+  if (rid.seg < 0) return;                 // a hand-over timed out: leave the state as it is (kernels.h: relay_begin)
   const unsigned t = rid.bid * (unsigned)kBlock + threadIdx.x;
   const int slot = (int)(t % K);
   int c = (int)(t / K);
@@ -580,6 +581,7 @@ __global__ __launch_bounds__(kBlock, STATS && T::MINW > 2 ? 2 : T::MINW) void pk
     typename T::Args A, const float* __restrict__ av0, const float* __restrict__ bv0, HmcParams P) {
   constexpr int K = T::K, NP = T::NP, ND = T::ND, NG = T::NG;
   const RelayId rid = relay_begin(P);
+  if (rid.seg < 0) return;                 // a hand-over timed out: leave the state as it is (kernels.h: relay_begin)
   const unsigned t = rid.bid * (unsigned)kBlock + threadIdx.x;
   const int slot = (int)(t % K);
   int c = (int)(t / K);

@@ -243,6 +243,7 @@ template <class T, bool STATS = false>
 __global__ __launch_bounds__(kBlock, T::MINW) void radon_interleaved_kernel(RadonArgs A, HmcParams P) {
   constexpr int K = T::K, NP = T::NP, ND = T::ND;
   const RelayId rid = relay_begin(P);      // kernels.h: the launch's steps in segments, a workgroup per (segment, chain block)
+  if (rid.seg < 0) return;                 // a hand-over timed out: leave the state as it is (kernels.h: relay_begin)
   const unsigned bid = rid.bid;
   const unsigned t = bid * (unsigned)kBlock + threadIdx.x;
   const int slot = (int)(t % K);

@@ -234,6 +234,11 @@ class Engine(object):
         """Per-handle option (arp_model_set_option), e.g. ("german_math", "f32" | "bf16x3" | "auto")."""
         _lib.check(self._L.arp_model_set_option(self._h, key.encode(), value.encode()))
 
+    def check(self):
+        """Deferred status of this handle's asynchronous chain launches (arp_model_check): raises if a relay hand-over
+        inside one of them timed out.  Call it after synchronising the stream the launches went to."""
+        _lib.check(self._L.arp_model_check(self._h))
+
     def relay_geometry(self):
         """What this thread's last hmc_run / interleaved_run launch did (arp_relay_geometry): relay segments, chain blocks,
         workgroups of the kernel per CU."""

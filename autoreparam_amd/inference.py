@@ -15,8 +15,12 @@ from . import util
 from .flags import FLAGS
 
 HmcInnerResults = collections.namedtuple("HmcInnerResults", ["is_accepted"])
-KernelResults = collections.namedtuple("KernelResults", ["inner_results", "new_step_size", "step"])
-InterleavedKernelResults = collections.namedtuple("InterleavedKernelResults", ["cp_results", "ncp_results"])
+# ess_info (EssInfo: which estimator the returned ESS is, over how many chains) and moments (per-chain mean / variance from
+# the in-kernel accumulators of a streaming run, else None) belong to the call that produced them and travel with its result
+KernelResults = collections.namedtuple("KernelResults", ["inner_results", "new_step_size", "step", "ess_info", "moments"],
+                                       defaults=(None, None))
+InterleavedKernelResults = collections.namedtuple("InterleavedKernelResults", ["cp_results", "ncp_results", "ess_info", "moments"],
+                                                  defaults=(None, None))
 
 # transitions per launch: keeps a single launch well under a second at any size
 _MAX_STEPS_PER_LAUNCH = 4096
@@ -38,8 +42,8 @@ class DiscretePrior(object):
 def find_best_learning_rate(elbo, variational_parameters, learnable_parameters_prior=None,
                             learnable_parameters=None, flags=FLAGS):
     """Optimise the ELBO with every learning rate of the sweep and keep the best run
-    (reference inference.py:26-154).  All learning rates run concurrently, one
-    workgroup each, inside one kernel launch."""
+    (reference inference.py:26-154).  All learning rates run concurrently inside one kernel launch, each on a group of
+    G x R workgroups that share its Monte-Carlo draws (and, German credit, its observations' row parts)."""
     if learnable_parameters_prior is not None and not isinstance(learnable_parameters_prior, DiscretePrior):
         raise NotImplementedError("the only prior on the learnable parameterisation the engine evaluates is "
                                   "inference.DiscretePrior (the reference's --discrete_prior mixture)")
@@ -299,6 +303,9 @@ def _sample(run_segment, st, S, B, thin, C, D, dev, keep_chains, n_acc, chunk_ro
     moments = (mean, var) [C, D] float64 from the in-kernel accumulators in streaming mode, None with a whole trace."""
     rows, streaming = _trace_plan(S, C, D, dev, chunk_rows)
     total = 1 + B + thin * (S - 1)
+    if C == 0:
+        # a rank of a job with fewer chains than ranks: nothing to launch, empty blocks for the end-of-run gathers
+        total = 0
     if not streaming:
         trace = torch.empty(rows, C, D, dtype=torch.float32, device=dev)
         accs = [torch.empty(rows, C, dtype=torch.uint8, device=dev) for _ in range(n_acc)]
@@ -307,7 +314,7 @@ def _sample(run_segment, st, S, B, thin, C, D, dev, keep_chains, n_acc, chunk_ro
             n = min(_MAX_STEPS_PER_LAUNCH, total - done)
             run_segment(n, B, trace, accs)
             done += n
-        ess = util.effective_sample_size(trace)
+        ess = util.effective_sample_size(trace) if C > 0 else torch.empty(0, D, dtype=torch.float32, device=dev)
         # the whole trace is returned: moments are the caller's to take
         return trace, None, [_DeviceAccept(a) for a in accs], ess, EssInfo("autocorrelation", C), None
     batch = max(8, min(rows, S) // 8)
@@ -357,7 +364,8 @@ def _initial_rows(spec, parts, dev):
         t = t.to(device=dev, dtype=torch.float32)
         cols.append(t.reshape(t.shape[0], -1))
     q0 = torch.cat(cols, dim=1).contiguous()
-    assert q0.shape[1] == spec.D, "initial states do not have the model's parts"
+    if q0.shape[1] != spec.D:
+        raise ValueError("initial states do not have the model's parts: %d columns, the model has D = %d" % (q0.shape[1], spec.D))
     return q0
 
 
@@ -388,14 +396,14 @@ def hmc(target, model_config, step_size_init, initial_states, reparam, flags=FLA
                     lanes=flags.lanes_per_chain, rec_accept=rec_accept0, **extra)
 
     keep = max(1, int(flags.num_chains_to_save))
-    hmc.last_ess_estimator = hmc.last_moments = hmc.last_ess_info = None      # nothing stale survives a run that raises
     trace, kept, accs, ess_flat, info, moments = _sample(run_segment, st, S, B, thin, C, spec.D, dev, min(keep, C), 1,
                                                         getattr(flags, "trace_chunk_rows", None), chain_offset,
                                                         getattr(flags, "ess_chains", 1024))
     torch.cuda.synchronize(dev)
+    eng.check()                                   # a relay hand-over that timed out inside a launch surfaces here
     ess = spec.unpack(ess_flat.cpu().numpy())
     step_mult = st.adapt[:, 0].cpu().numpy()
-    kernel_results = KernelResults(HmcInnerResults(accs[0]), step_mult, st.step)
+    kernel_results = KernelResults(HmcInnerResults(accs[0]), step_mult, st.step, info, moments)
     if trace is not None:
         states_transformed = _device_parts(spec, trace)
         states_orig = _LazyOriginalStates(eng, spec, trace, 0)
@@ -405,9 +413,6 @@ def hmc(target, model_config, step_size_init, initial_states, reparam, flags=FLA
         # autocorrelation ESS of those chains (EssInfo; the batch-means figure of all chains rides along in it)
         states_transformed = _device_parts(spec, kept)
         states_orig = None
-    hmc.last_ess_estimator = info.estimator
-    hmc.last_ess_info = info
-    hmc.last_moments = moments
     return states_orig, kernel_results, states_transformed, ess
 
 
@@ -438,17 +443,15 @@ def hmc_interleaved(model_config, target_cp, target_ncp, num_leapfrog_steps_cp, 
                             trace_centered=False, lanes=flags.lanes_per_chain, **extra)
 
     keep = max(1, int(flags.num_chains_to_save))
-    hmc_interleaved.last_ess_estimator = hmc_interleaved.last_moments = hmc_interleaved.last_ess_info = None
     trace, kept, accs, ess_flat, info, moments = _sample(run_segment, st, S, B, thin, C, spec.D, dev, min(keep, C), 2,
                                                         getattr(flags, "trace_chunk_rows", None), chain_offset,
                                                         getattr(flags, "ess_chains", 1024))
     torch.cuda.synchronize(dev)
+    eng.check()
     states = _device_parts(spec, trace if trace is not None else kept)
     ess = spec.unpack(ess_flat.cpu().numpy())
     kr = InterleavedKernelResults(
         cp_results=KernelResults(HmcInnerResults(accs[0]), st.adapt[:, 0].cpu().numpy(), st.step),
-        ncp_results=KernelResults(HmcInnerResults(accs[1]), st.adapt1[:, 0].cpu().numpy(), st.step))
-    hmc_interleaved.last_ess_estimator = info.estimator
-    hmc_interleaved.last_ess_info = info
-    hmc_interleaved.last_moments = moments
+        ncp_results=KernelResults(HmcInnerResults(accs[1]), st.adapt1[:, 0].cpu().numpy(), st.step),
+        ess_info=info, moments=moments)
     return states, kr, ess

@@ -226,7 +226,7 @@ def _settle_leapfrog_count(fit, tuning, flags):
     return True
 
 
-def run_hmc(model_config, results_dir, file_path, tuning=False, flags=FLAGS):
+def run_hmc(model_config, results_dir, file_path, tuning=False, flags=FLAGS, out=None):
     """One HMC run (or one HMCtuning run) of a fitted method: the reference's run_hmc (main.py:296-398) -- same inputs,
     files and keys; chains sharded over the ranks of the job, statistics combined at the end."""
     fit = _read_vi_fit(file_path)
@@ -242,9 +242,11 @@ def run_hmc(model_config, results_dir, file_path, tuning=False, flags=FLAGS):
         target, model_config, fit["initial_step_size"], initial_states=initial_states, reparam=reparam, flags=flags,
         chain_offset=chain_offset)
     mcmc_time = time.time() - clock
+    if out is not None:
+        out["kernel_results"] = kernel_results      # .ess_info, .moments: what the run knows beyond the reference's tuple
     per_1000_gradients = 1000.0 / (flags.num_samples * flags.num_leapfrog_steps)
     normalized_ess_final = [e * per_1000_gradients for e in ess_final]
-    info = getattr(inference.hmc, "last_ess_info", None)
+    info = kernel_results.ess_info
     dev = flags.device if ws > 1 else None
     n_ess = _ess_chain_count(info, model_config, flags)          # None: a chain subset (streaming run)
     ess_min, sem_min, acceptance_rate, _ = parallel.summarize(
@@ -255,6 +257,9 @@ def run_hmc(model_config, results_dir, file_path, tuning=False, flags=FLAGS):
     if ws > 1 and not tuning:
         # _ess.npz / _ess.txt hold every chain's per-element ESS: collect the other ranks' blocks (a collective: all ranks)
         normalized_ess_final = parallel.gather_parts(normalized_ess_final, n_ess, flags.device)
+        if flags.num_chains_to_save > 0:
+            # _traces.npz holds the JOB's first chains, whichever ranks own them (rank 0's block may be shorter)
+            samples = parallel.gather_leading_chains(samples, flags.num_chains_to_save, chain_offset, flags.device)
     summary = (ess_min, sem_min, acceptance_rate, mcmc_time)
     if rank != 0:
         return summary
@@ -291,7 +296,7 @@ def run_interleaved_hmc_with_leapfrog_steps(model_config, results_dir, num_leapf
     is_accepted_ncp = kernel_results.ncp_results.inner_results.is_accepted
     normalized_ess_final = [1000 * e / (flags.num_samples * flags.num_leapfrog_steps) for e in ess_final]
     dev = flags.device if ws > 1 else None
-    info = getattr(inference.hmc_interleaved, "last_ess_info", None)
+    info = kernel_results.ess_info
     n_ess = _ess_chain_count(info, model_config, flags)
     ess_min, sem_min, acc_cp, _ = parallel.summarize(normalized_ess_final, is_accepted_cp, flags.num_samples,
                                                      flags.num_chains, device=dev, ess_chains_total=n_ess)
@@ -305,7 +310,10 @@ def run_interleaved_hmc_with_leapfrog_steps(model_config, results_dir, num_leapf
     # releases the [S, C, D] device trace before the next candidate leapfrog count allocates its own (two 18.6 GB traces
     # alive at once at the headline size, and a fresh device allocation of that size can cost half a second).
     k = max(0, int(flags.num_chains_to_save))
-    states = [np.asarray(s[:, :k]) for s in states] if k > 0 else [np.zeros((flags.num_samples, 0), np.float32) for _ in states]
+    if k > 0:
+        states = parallel.gather_leading_chains(states, k, chain_offset, flags.device if ws > 1 else None)
+    else:
+        states = [np.zeros((flags.num_samples, 0), np.float32) for _ in states]
     del kernel_results, is_accepted_cp, is_accepted_ncp
     return (ess_min, sem_min, acc_cp, acc_ncp, mcmc_time, states, normalized_ess_final, extra)
 
@@ -403,8 +411,8 @@ def save_ess(file_path_base, samples, normalized_ess_final, param_names, num_cha
                  **{name: x[:, :num_chains_to_save] for name, x in zip(param_names, samples)})
 
 
-def main(argv=None, flags=FLAGS):
-    """reference main.py:190-231"""
+def main(argv=None, flags=FLAGS, out=None):
+    """reference main.py:190-231.  `out`: an optional dict a plain HMC run leaves its kernel results in (tests, tools)."""
     if argv is not None:
         flags.parse(list(argv))
     if flags.reparameterise_variational:
@@ -458,7 +466,7 @@ def main(argv=None, flags=FLAGS):
         if flags.inference == "HMC":
             if flags.method == "i":
                 return run_interleaved_hmc(model_config, results_dir, file_path, flags)
-            return run_hmc(model_config, results_dir, file_path, tuning=False, flags=flags)
+            return run_hmc(model_config, results_dir, file_path, tuning=False, flags=flags, out=out)
         return run_hmc(model_config, results_dir, file_path, tuning=True, flags=flags)
     finally:
         # Every rank reads the result file at the top of a sampling phase (step sizes, tuning_runs -> the leapfrog count)

@@ -121,6 +121,22 @@ def gather_parts(parts, num_chains_total, device=None):
     return [all_gather_chains(torch.as_tensor(np.asarray(p)), num_chains_total, device).cpu().numpy() for p in parts]
 
 
+def gather_leading_chains(samples, k, chain_offset, device=None):
+    """Every rank's [S, C_local, *event] sample arrays -> [S, min(k, C), *event]: the traces of the JOB's first k chains
+    (global id < k), which rank 0 writes to _traces.npz (--num_chains_to_save) -- the same chains however many ranks share
+    the job, also when rank 0's own block is shorter than k.  A collective: every rank calls it (most contribute nothing)."""
+    k = max(0, int(k))
+    if not live():
+        return [np.asarray(s[:, :k]) for s in samples]
+    out = []
+    for s in samples:
+        kl = max(0, min(int(s.shape[1]), k - int(chain_offset)))
+        mine = np.ascontiguousarray(np.moveaxis(np.asarray(s[:, :kl]), 1, 0))            # chain-major: [kl, S, *event]
+        got = all_gather_chains(torch.as_tensor(mine), None, device).cpu().numpy()
+        out.append(np.ascontiguousarray(np.moveaxis(got, 0, 1)))
+    return out
+
+
 def mean_sem(x):
     x = np.asarray(x, np.float64)
     return float(np.mean(x)), float(np.std(x) / np.sqrt(len(x)))

@@ -136,7 +136,10 @@ int arp_model_dim(const arp_model* m);                 /* D */
  * per chain -- "f32" = f32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32 products), "bf16x3" = bf16 matrix cores with every
  * operand as three bf16 pieces (six leading cross products: f32-equivalent, error ~ 2^-23 per product; needs a design matrix
  * with at most 8 columns that are not exact in one bf16 piece -- the reference's data have 7), "auto" (default) = bf16x3 where
- * the data allow it.  Returns non-zero for an unknown key / value or a model the key does not apply to. */
+ * the data allow it.  "vi_launch": how arp_vi_run starts a launch whose workgroups wait for each other inside the launch --
+ * "cooperative" = hipLaunchCooperativeKernel (the runtime guarantees that the whole grid is resident, or refuses), "plain" =
+ * an ordinary launch sized by an occupancy query, one such launch at a time per process, "auto" (default) = cooperative where
+ * the device supports it.  Returns non-zero for an unknown key / value or a model the key does not apply to. */
 int arp_model_set_option(arp_model* m, const char* key, const char* value);
 /* Additive constant dropped from logp for parameterisation `which` (so callers can
  * report the reference-valued target_log_prob / ELBO): logp_ref = logp + const. */
@@ -159,7 +162,11 @@ int arp_transform(arp_model* m, int which, int dir, const float* in, int n_chain
 
 /* HMC segment (mcmc.HamiltonianMonteCarlo + step-size adaptation + sample_chain): `cfg->n_steps` transitions in ONE
  * launch.  (Internally a launch of 256 steps or more may hand its chains from workgroup to workgroup a few times -- DESIGN.md
- * section 3, relay segments --; the result is bit for bit that of one workgroup per chain block, the call stays asynchronous.) */
+ * section 3, relay segments --; chain state, counters and trace rows are bit for bit those of one workgroup per chain block.
+ * The streaming statistics in io->stats are the exception: their partial-batch accumulators fold at every segment end, so
+ * the sums are grouped differently and agree to float rounding only (~1e-6 relative), and the segment count follows the
+ * device's CU count.  The call stays asynchronous; the hand-over waits are bounded, and a launch whose hand-over timed out
+ * leaves the chains where they were and is reported by the next call on the handle or by arp_model_check.) */
 int arp_hmc_run(arp_model* m, int which, const arp_hmc_config* cfg,
                 const arp_hmc_io* io, void* stream);
 
@@ -219,6 +226,12 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
  * sample groups G, row parts R (workgroups per learning rate = G x R), learning rates per launch, workgroups resident
  * together (= CUs in use when one fits per CU), workgroups of the kernel one CU holds}.  (bench.py: vi_kernel.) */
 int arp_vi_geometry(int32_t* out6);
+
+/* Deferred status of the handle's asynchronous launches: 0 if none failed; non-zero (and arp_last_error set) if a relay
+ * hand-over inside an arp_hmc_run / arp_interleaved_run launch timed out since the last check -- the chains of that launch
+ * were left partly advanced and must be discarded.  Reads a pinned host word: call it after synchronising the stream(s) the
+ * launches went to.  Reports once (the word is cleared).  The same word is checked on entry to the next chain launch. */
+int arp_model_check(arp_model* m);
 
 /* Measurement hook: what the calling thread's last arp_hmc_run / arp_interleaved_run launch did -- out3 = {relay segments
  * the launch's steps were cut into (1 = one workgroup per chain block), chain blocks, workgroups of

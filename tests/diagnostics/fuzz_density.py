@@ -1,7 +1,7 @@
 """Randomised density / gradient / converter parity of the HIP lanes against the float64 oracle:
 every model x lanes-per-chain x several seeds of (a, b) and states at two scales."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import helpers, oracle

@@ -1,6 +1,6 @@
 """How accurate are the chain kernels' cached log densities?  HIP (float32) and the float32 oracle against the float64 oracle."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import helpers, oracle

@@ -7,6 +7,11 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# every way a Python file can pull in the oracle package: `import oracle`, `import x, oracle`, `from oracle[.x] import ...`,
+# importlib.import_module("oracle") / __import__("oracle")
+ORACLE_IMPORT = re.compile(r"^[ \t]*import[ \t]+(?:[\w.]+(?:[ \t]+as[ \t]+\w+)?[ \t]*,[ \t]*)*oracle\b(?![\w])"
+                           r"|^[ \t]*from[ \t]+oracle(?:\.[\w.]+)?[ \t]+import\b"
+                           r"|(?:import_module|__import__)\([ \t]*['\"]oracle['\"]", re.M)
 
 
 @pytest.fixture(scope="module")
@@ -62,8 +67,17 @@ def test_product_path_does_not_import_oracle():
         for f in files:
             if f.endswith((".py", ".h", ".hip")):
                 txt = open(os.path.join(dirpath, f)).read()
-                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), (dirpath, f)
+                assert not ORACLE_IMPORT.search(txt), (dirpath, f)
                 assert "liboracle" not in txt, (dirpath, f)
+
+
+def test_the_import_guard_sees_every_spelling():
+    for line in ("import oracle", "  import oracle as o", "import helpers, oracle", "import a, oracle.x, b", "from oracle import build",
+                 "from oracle.ess_ref import ess", "m = importlib.import_module('oracle')", 'x = __import__("oracle")'):
+        assert ORACLE_IMPORT.search(line), line
+    for line in ("import oracle_free_module", "# import oracle", "import helpers, oracles", "from oracles import x",
+                 "the oracle is imported elsewhere"):
+        assert not ORACLE_IMPORT.search(line), line
 
 
 def test_only_the_checkers_import_the_oracle():
@@ -76,7 +90,7 @@ def test_only_the_checkers_import_the_oracle():
         for f in files:
             if f.endswith(".py") or f.endswith(".sh"):
                 txt = open(os.path.join(dirpath, f)).read()
-                if re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M):
+                if ORACLE_IMPORT.search(txt):
                     hits.append(os.path.relpath(os.path.join(dirpath, f), ROOT))
     assert sorted(hits) == ["__graft_entry__.py", "bench.py"], hits
     src = open(os.path.join(ROOT, "bench.py")).read()

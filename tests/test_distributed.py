@@ -87,8 +87,8 @@ def _fake_engine(monkeypatch_target):
         acc = ((np.arange(S)[:, None] + g[None, :]) % 3 != 0)
         samples = [np.broadcast_to(g.reshape((1, Cl) + (1,) * len(sh)).astype(np.float32), (S, Cl) + tuple(sh)).copy()
                    for sh in spec.part_shapes]
-        kr = inference.KernelResults(inference.HmcInnerResults(acc), np.ones(Cl, np.float32), S)
-        fake_hmc.last_ess_info = inference.EssInfo("autocorrelation", Cl)
+        kr = inference.KernelResults(inference.HmcInnerResults(acc), np.ones(Cl, np.float32), S,
+                                     inference.EssInfo("autocorrelation", Cl))
         ess = _ess_parts(spec, g)
         if getattr(flags, "trace_chunk_rows", None):
             # a streaming run: the autocorrelation ESS covers the chains with GLOBAL id < --ess_chains (this rank's block
@@ -97,27 +97,26 @@ def _fake_engine(monkeypatch_target):
             k = int(min(Cl, max(int(flags.ess_chains) - chain_offset, 0)))
             ess = [e[:k] for e in ess]
             samples = [x[:, :max(k, int(flags.num_chains_to_save))] for x in samples]
-            bm = torch.as_tensor(np.concatenate([e.reshape(Cl, -1) for e in _ess_parts(spec, g)], axis=1) * 0.5)
-            fake_hmc.last_ess_info = inference.EssInfo("autocorrelation", k, batch_means=bm, batch=4)
+            bm = torch.as_tensor(np.concatenate([e.reshape(Cl, int(np.prod(e.shape[1:]))) for e in _ess_parts(spec, g)], axis=1) * 0.5)
+            kr = kr._replace(ess_info=inference.EssInfo("autocorrelation", k, batch_means=bm, batch=4))
         return None, kr, samples, ess
 
     def fake_inter(model_config, target_cp, target_ncp, num_leapfrog_steps_cp, num_leapfrog_steps_ncp, step_size_cp,
                    step_size_ncp, initial_states_cp, flags=None, chain_offset=0):
         _, kr, samples, ess = fake_hmc(target_cp, model_config, step_size_cp, initial_states_cp, None, flags, chain_offset)
         acc1 = ~np.asarray(kr.inner_results.is_accepted)
-        fake_inter.last_ess_info = fake_hmc.last_ess_info
-        return samples, inference.InterleavedKernelResults(kr, inference.KernelResults(
-            inference.HmcInnerResults(acc1), kr.new_step_size, kr.step)), ess
+        return samples, inference.InterleavedKernelResults(kr._replace(ess_info=None), inference.KernelResults(
+            inference.HmcInnerResults(acc1), kr.new_step_size, kr.step), ess_info=kr.ess_info), ess
 
     inference.find_best_learning_rate = fake_vi
     inference.hmc = fake_hmc
     inference.hmc_interleaved = fake_inter
 
 
-def _cli_sequence(results_dir):
+def _cli_sequence(results_dir, chains=7, ess_small=3, ess_mid=5):
     from autoreparam_amd import main as cli
     from autoreparam_amd.flags import FLAGS
-    base = ["--model=8schools", "--results_dir=%s" % results_dir, "--seed=3", "--num_chains=7", "--num_samples=12",
+    base = ["--model=8schools", "--results_dir=%s" % results_dir, "--seed=3", "--num_chains=%d" % chains, "--num_samples=12",
             "--num_burnin_steps=4", "--num_adaptation_steps=3", "--num_chains_to_save=2"]
     out = {}
 
@@ -134,14 +133,16 @@ def _cli_sequence(results_dir):
             phase(["--inference=HMCtuning", "--method=" + m, "--num_leapfrog_steps=%d" % L])
     out["hmc"] = phase(["--inference=HMC", "--method=CP"])
     out["inter"] = phase(["--inference=HMC", "--method=i"])
-    # streaming runs: the ESS chain subset lies on rank 0 alone (3 of 7 chains) / on both ranks (5 = 4 + 1)
-    out["hmc_s3"] = phase(["--inference=HMC", "--method=CP", "--trace_chunk_rows=8", "--ess_chains=3"])
-    out["hmc_s5"] = phase(["--inference=HMC", "--method=NCP", "--trace_chunk_rows=8", "--ess_chains=5"])
-    out["inter_s5"] = phase(["--inference=HMC", "--method=i", "--trace_chunk_rows=8", "--ess_chains=5"])
+    # streaming runs: the ESS chain subset lies on rank 0 alone (3 of 7 chains) / on the first two ranks (5 = 4 + 1); at
+    # world size 8 every other rank owns NONE of the subset (inference._ess_subset -> k_local = 0: empty blocks in the
+    # variable-length gathers)
+    out["hmc_s3"] = phase(["--inference=HMC", "--method=CP", "--trace_chunk_rows=8", "--ess_chains=%d" % ess_small])
+    out["hmc_s5"] = phase(["--inference=HMC", "--method=NCP", "--trace_chunk_rows=8", "--ess_chains=%d" % ess_mid])
+    out["inter_s5"] = phase(["--inference=HMC", "--method=i", "--trace_chunk_rows=8", "--ess_chains=%d" % ess_mid])
     return out
 
 
-def _cli_worker(rank, ws, port, results_dir):
+def _cli_worker(rank, ws, port, results_dir, chains=7, ess_small=3, ess_mid=5):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(ws), RANK=str(rank), LOCAL_RANK=str(rank))
     _fake_engine(None)
     # VI first, BEFORE any process group exists: ranks != 0 must leave on RANK alone, rank 0 runs without one
@@ -151,7 +152,7 @@ def _cli_worker(rank, ws, port, results_dir):
     assert (r is None) == (rank != 0) and not dist.is_initialized()
     dist.init_process_group("gloo", rank=rank, world_size=ws)     # main() keeps an initialised group (RCCL on the GPU box)
     dist.barrier()
-    out = _cli_sequence(results_dir)
+    out = _cli_sequence(results_dir, chains, ess_small, ess_mid)
     assert (out["vi_NCP"] is None) == (rank != 0)
     np.save(os.path.join(results_dir, "ret%d.npy" % rank), np.array([out["hmc"][0], out["hmc"][1], out["hmc"][2],
                                                                       out["inter"][0], out["inter"][2], out["inter"][3],
@@ -178,7 +179,16 @@ def _results(d):
     return out
 
 
-def test_cli_rank_logic_two_ranks_equal_one(tmp_path):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("ws,chains,ess_small,ess_mid", [
+    (2, 7, 3, 5),            # 4 + 3 chains
+    (8, 1003, 3, 130),       # what the round-end 8-GPU run looks like: shards of 126 and 125 chains; the ESS subset on rank 0
+                             # alone / on ranks 0 and 1 (126 + 4), six or seven ranks contributing empty blocks
+    (8, 5, 3, 5),            # fewer chains than ranks: ranks 5 - 7 own no chain at all
+])
+def test_cli_rank_logic_n_ranks_equal_one(tmp_path, ws, chains, ess_small, ess_mid):
     one, two = str(tmp_path / "one"), str(tmp_path / "two")
     os.makedirs(one); os.makedirs(two)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
@@ -188,10 +198,10 @@ def test_cli_rank_logic_two_ranks_equal_one(tmp_path):
     saved = (inference.find_best_learning_rate, inference.hmc, inference.hmc_interleaved)
     try:
         _fake_engine(None)
-        ref = _cli_sequence(one)
+        ref = _cli_sequence(one, chains, ess_small, ess_mid)
     finally:
         inference.find_best_learning_rate, inference.hmc, inference.hmc_interleaved = saved
-    mp.spawn(_cli_worker, args=(2, _free_port(), two), nprocs=2, join=True)
+    mp.spawn(_cli_worker, args=(ws, _free_port(), two, chains, ess_small, ess_mid), nprocs=ws, join=True)
     a, b = _results(one), _results(two)
     assert sorted(a) == sorted(b) and any(k.endswith("_ess.npz") for k in a)
     for k in a:
@@ -206,11 +216,11 @@ def test_cli_rank_logic_two_ranks_equal_one(tmp_path):
     # the streaming runs' extra keys: estimator, subset size, the batch-means figure of all 7 chains
     import json
     r = json.load(open(os.path.join(two, "CP_tied.json")))
-    assert r["ess_estimator"] == ["autocorrelation", "autocorrelation"] and r["ess_chains"] == [7, 3]
+    assert r["ess_estimator"] == ["autocorrelation", "autocorrelation"] and r["ess_chains"] == [chains, ess_small]
     # one entry per run in every list: None for the whole-trace run, the figure for the streaming one
     assert r["ess_min_batch_means"][0] is None and r["ess_min_batch_means"][1] > 0 and r["batch_means_batch"] == [None, 4]
     assert len(r["ess_min"]) == len(r["ess_estimator"]) == len(r["sem_min_batch_means"]) == 2
-    assert a["CP_tied_ess.npz"]["theta"].shape == (3, 8)             # the last run's: the 3-chain subset
-    assert a["NCP_tied_ess.npz"]["theta"].shape == (5, 8) and np.array_equal(a["NCP_tied_ess.npz"]["theta"], b["NCP_tied_ess.npz"]["theta"])
-    for r in range(2):   # every rank returns the statistics over ALL chains
+    assert a["CP_tied_ess.npz"]["theta"].shape == (ess_small, 8)             # the last run's: the 3-chain subset
+    assert a["NCP_tied_ess.npz"]["theta"].shape == (ess_mid, 8) and np.array_equal(a["NCP_tied_ess.npz"]["theta"], b["NCP_tied_ess.npz"]["theta"])
+    for r in range(ws):   # every rank returns the statistics over ALL chains
         np.testing.assert_allclose(np.load(os.path.join(two, "ret%d.npy" % r)), want, rtol=1e-6)

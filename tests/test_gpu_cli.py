@@ -10,11 +10,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(args):
+def _run(args, out=None):
     from autoreparam_amd import flags as flags_mod
     from autoreparam_amd import main as cli
     f = flags_mod.FlagValues()
-    return cli.main(args, flags=f)
+    return cli.main(args, flags=f, out=out)
 
 
 def test_config1_eight_schools_cp(gpu, tmp_path):
@@ -98,11 +98,11 @@ def test_streaming_trace_mode_equals_whole_trace(gpu):
     init = [0.1 * rs.randn(96, *s).astype(np.float32) for s in sp.part_shapes]
     step = [0.15] * 3 + [np.full(85, 0.3)]
     _, kr_a, st_a, ess_a = inference.hmc(target, cfg, step, init, "CP", flags=f)
-    assert inference.hmc.last_ess_estimator == "autocorrelation" and inference.hmc.last_ess_info.chains == 96
+    assert kr_a.ess_info.estimator == "autocorrelation" and kr_a.ess_info.chains == 96 and kr_a.moments is None
     for k_ess in (1024, 70, 0):
         f2 = f.copy(); f2.trace_chunk_rows = 96; f2.ess_chains = k_ess
         so, kr_b, st_b, ess_b = inference.hmc(target, cfg, step, init, "CP", flags=f2)
-        info = inference.hmc.last_ess_info
+        info = kr_b.ess_info
         assert so is None and info.batch_means.shape == (96, sp.D) and info.batch == 12
         k = min(k_ess, 96)
         for a, b in zip(st_a, st_b):
@@ -133,7 +133,7 @@ def test_batch_means_agree_with_autocorrelation_where_both_fit(gpu):
     init = [0.1 * rs.randn(C, *s).astype(np.float32) for s in sp.part_shapes]
     step = [0.15] * 3 + [np.full(85, 0.3)]
     _, kr, st, ess = inference.hmc(target, cfg, step, init, "CP", flags=f)
-    info = inference.hmc.last_ess_info
+    info = kr.ess_info
     assert info.estimator == "autocorrelation" and info.chains == C and info.batch == 256
     ac = torch.as_tensor(sp.pack([np.asarray(e) for e in ess])).double()      # [C, D]
     bm = info.batch_means.cpu().double()
@@ -159,12 +159,13 @@ def test_config3_full_size_german_dvip(gpu, tmp_path):
     S, burn = 400, 1500
     hm = ["--num_samples=%d" % S, "--num_burnin_steps=%d" % burn, "--num_adaptation_steps=1200", "--num_leapfrog_steps=8",
           "--trace_chunk_rows=64", "--num_chains_to_save=4"]
-    res = _run(base + ["--inference=HMC", "--method=dVIP"] + hm)
-    info = inference.hmc.last_ess_info
+    sink = {}
+    res = _run(base + ["--inference=HMC", "--method=dVIP"] + hm, out=sink)
+    info = sink["kernel_results"].ess_info
     assert info.estimator == "autocorrelation" and info.chains == 1024 and info.batch_means.shape == (16384, 125)
     ess_min, sem_min, acc, mcmc_time = res
     assert 55 < acc < 95 and ess_min > 0
-    mean_c, var_c = inference.hmc.last_moments                 # [C, D] per-chain moments from the kernels' accumulators
+    mean_c, var_c = sink["kernel_results"].moments             # [C, D] per-chain moments from the kernels' accumulators
     assert mean_c.shape == (16384, 125) and torch.isfinite(mean_c).all()
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "posterior_golden.npz"))
     mean_g, sd_g, mcse_g = gold["german/mean"], gold["german/sd"], gold["german/mcse"]
@@ -250,13 +251,14 @@ def test_config5_full_size_election_cvip(gpu, tmp_path):
     tried = sorted(t["num_leapfrog_steps"] for t in r["tuning_runs"])
     assert tried == [2, 4, 8]
     S, burn = 300, 1500
+    sink = {}
     res = _run(base + ["--inference=HMC", "--num_samples=%d" % S, "--num_burnin_steps=%d" % burn, "--num_adaptation_steps=1200",
-                       "--trace_chunk_rows=64", "--num_chains_to_save=2"])
+                       "--trace_chunk_rows=64", "--num_chains_to_save=2"], out=sink)
     ess_min, sem_min, acc, mcmc_time = res
     assert 55 < acc < 95 and ess_min > 0
-    info = inference.hmc.last_ess_info
+    info = sink["kernel_results"].ess_info
     assert info.estimator == "autocorrelation" and info.chains == 1024 and info.batch_means.shape == (131072, 55)
-    mean_c, var_c = inference.hmc.last_moments
+    mean_c, var_c = sink["kernel_results"].moments
     assert mean_c.shape == (131072, 55) and torch.isfinite(mean_c).all()
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "posterior_golden.npz"))
     mean_g, sd_g, mcse_g = gold["election/mean"], gold["election/sd"], gold["election/mcse"]

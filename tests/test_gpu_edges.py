@@ -300,3 +300,29 @@ def test_trace_past_two_to_the_32_elements(gpu, sampler):
     assert not (tr[k - 1:k + 2] == -7.0).any() and not torch.equal(tr[k], tr[k + 1])
     del tr, acc, tr_t, acc_t
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("streaming", [False, True])
+def test_a_rank_without_chains_returns_empty_blocks(gpu, streaming):
+    """A job with fewer chains than ranks (8 GPUs, --num_chains=5) leaves some ranks no chain: inference.hmc /
+    hmc_interleaved launch nothing there and hand back empty [S, 0, ...] / [0, ...] blocks for the end-of-run gathers
+    (tests/test_distributed.py drives main.py's side of it at world size 8)."""
+    from autoreparam_amd import flags as flags_mod, graphs, inference, models
+    cfg = models.get_model_by_name("radon", "MN")
+    sp = cfg.model
+    f = flags_mod.FlagValues()
+    f.num_chains, f.num_samples, f.num_burnin_steps, f.num_adaptation_steps, f.num_leapfrog_steps = 5, 40, 10, 8, 3
+    f.device = str(gpu)
+    if streaming:
+        f.trace_chunk_rows, f.ess_chains = 16, 4
+    target, *_ = graphs.make_cp_graph(cfg, flags=f)
+    init = [np.zeros((0,) + tuple(s), np.float32) for s in sp.part_shapes]
+    step = [0.15] * 3 + [np.full(85, 0.3)]
+    _, kr, st, ess = inference.hmc(target, cfg, step, init, "CP", flags=f, chain_offset=5)
+    assert kr.ess_info.chains == 0 and np.sum(kr.inner_results.is_accepted) == 0
+    assert all(np.asarray(e).shape[0] == 0 for e in ess) and all(s.shape[1] == 0 for s in st)
+    if streaming:
+        assert kr.ess_info.batch_means.shape == (0, sp.D)
+    t_cp, t_ncp = target, graphs.make_ncp_graph(cfg, flags=f)[0]
+    st_i, kr_i, ess_i = inference.hmc_interleaved(cfg, t_cp, t_ncp, 2, 2, step, step, init, flags=f, chain_offset=5)
+    assert kr_i.ess_info.chains == 0 and all(np.asarray(e).shape[0] == 0 for e in ess_i)

@@ -71,16 +71,20 @@ def test_handles_driven_from_concurrent_threads(gpu):
                     assert np.array_equal(x, y, equal_nan=True), job
 
 
-def test_one_handle_two_streams_overlapping_launches(gpu):
+@pytest.mark.parametrize("C", [65536, 70001])
+def test_one_handle_two_streams_overlapping_launches(gpu, C):
     """One handle, launches enqueued back to back on TWO streams for two different chain populations (calls serialised by the
-    caller, the work overlaps on the device): the relay segments of a launch use flag words of their own (a stream-ordered
-    allocation per launch), so each population's run is bit for bit the one it gets alone."""
+    caller, the work overlaps on the device): the relay segments of a launch use flag words and a ticket counter of their own
+    (a stream-ordered allocation per launch), so each population's run is bit for bit the one it gets alone.  A workgroup's
+    (segment, block) comes from the ticket it draws when it starts, so the block it waits for was started before it whatever
+    the dispatcher interleaves from the other launch -- 70 001 chains: a block count that is no multiple of the XCD count,
+    the case round 5's blockIdx-ordered form could deadlock on."""
     from autoreparam_amd import engine, _lib
     sp = helpers.spec("radon_PA")
     eng = engine.Engine(sp, gpu)
     eng.set_param(0, "CP"); eng.set_param(1, "NCP")
     e = np.full(sp.D, 0.05, np.float32); e[2] = 0.012
-    C, T = 65536, 384
+    T = 384
     q0 = [helpers.states(sp, C, seed=s, scale=0.1) for s in (1, 2)]
 
     def go(st, seed):
@@ -100,7 +104,53 @@ def test_one_handle_two_streams_overlapping_launches(gpu):
             with torch.cuda.stream(streams[k]):
                 go(sts[k], 40 + k)
     torch.cuda.synchronize()
+    eng.check()
     for k in range(2):
         got = [t.cpu().numpy() for t in (sts[k].q, sts[k].grad, sts[k].rng, sts[k].accept_count, sts[k].accept_count1)]
         for x, y in zip(alone[k], got):
             assert np.array_equal(x, y)
+
+
+def test_relay_hand_over_time_out_is_an_error_code_not_a_trap(gpu, monkeypatch):
+    """kernels.h: relay_begin bounds its wait.  With segments that never raise their flag (ARP_RELAY_FAULT, a test hook) and a
+    20 ms time-out, the waiting workgroups mark the launch failed and leave; the process and its GPU context live on, the
+    failure is reported ONCE -- by arp_model_check, or by the next chain launch on the handle -- with a message, and the
+    handle then works as before (round 5 ended such a wait with __builtin_trap after a minute)."""
+    import time
+    from autoreparam_amd import engine, _lib
+    sp = helpers.spec("radon_PA")
+    eng = engine.Engine(sp, gpu)
+    eng.set_param(0, "CP"); eng.set_param(1, "NCP")
+    e = np.full(sp.D, 0.05, np.float32); e[2] = 0.012
+    C, T = 8192, 256
+    q0 = helpers.states(sp, C, seed=5, scale=0.1)
+
+    def go(st):
+        eng.interleaved_run(st, e, e, 3, 3, T, seed=3, adapt_kind=_lib.ADAPT_SIMPLE, n_adapt=500)
+
+    ref = engine.ChainState(torch.as_tensor(q0, device=gpu))
+    go(ref); torch.cuda.synchronize(); eng.check()
+    monkeypatch.setenv("ARP_DEBUG", "1")
+    monkeypatch.setenv("ARP_SEGMENTS", "4")
+    for how in ("check", "next_launch"):
+        monkeypatch.setenv("ARP_RELAY_FAULT", "1")
+        monkeypatch.setenv("ARP_RELAY_TIMEOUT_MS", "20")
+        st = engine.ChainState(torch.as_tensor(q0, device=gpu))
+        t0 = time.time()
+        go(st)
+        torch.cuda.synchronize()
+        assert time.time() - t0 < 10.0                      # every waiter left at the first time-out, not one after another
+        assert eng.relay_geometry()["segments"] == 4
+        monkeypatch.delenv("ARP_RELAY_FAULT"); monkeypatch.delenv("ARP_RELAY_TIMEOUT_MS")
+        st2 = engine.ChainState(torch.as_tensor(q0, device=gpu))
+        if how == "check":
+            with pytest.raises(RuntimeError, match="relay hand-over"):
+                eng.check()
+        else:
+            with pytest.raises(RuntimeError, match="relay hand-over"):
+                go(st2)
+            assert st2.step == 0 or np.array_equal(st2.q.cpu().numpy(), q0)     # the refused call launched nothing
+            st2 = engine.ChainState(torch.as_tensor(q0, device=gpu))
+        eng.check()                                         # reported once
+        go(st2); torch.cuda.synchronize(); eng.check()      # the handle and the context are intact: 4 segments, same bits
+        assert np.array_equal(st2.q.cpu().numpy(), ref.q.cpu().numpy())

@@ -59,6 +59,59 @@ def test_vi_fit_is_bitwise_reproducible(gpu, mname):
             assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("mname", ["radon_PA", "election", "german"])
+def test_vi_cooperative_and_plain_launch_give_the_same_fit(gpu, mname):
+    """arp_model_set_option("vi_launch"): the same kernel started by hipLaunchCooperativeKernel (the default where the device
+    supports it: the runtime guarantees that the groups' workgroups are resident together) and by an ordinary launch (one at
+    a time per process, residency by the occupancy arithmetic) -- same geometry, same bits; two threads fitting at once
+    under the cooperative launch (no process-wide mutex there) each get the fit they get alone."""
+    import threading
+    from autoreparam_amd import engine
+    sp = helpers.spec(mname)
+    rs = np.random.RandomState(0)
+    loc0 = (1e-2 * rs.randn(5, sp.D)).astype(np.float32)
+    lrs = [0.02, 0.05, 0.1, 0.2, 0.4]
+
+    def fit(eng, seed, stream=None):
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream(gpu))
+        with ctx:
+            loc = torch.as_tensor(loc0.copy(), device=gpu); rho = torch.full((5, sp.D), -2.0, device=gpu)
+            elbo = eng.vi_run(lrs, loc, rho, 150, 256, seed=seed)
+            out = [t.cpu().numpy() for t in (elbo, loc, rho)]
+        return out, eng.vi_geometry()
+
+    res = {}
+    for mode in ("plain", "cooperative", "auto"):
+        eng = engine.Engine(sp, gpu)
+        eng.set_param(0, "NCP")
+        eng.set_option("vi_launch", mode)
+        res[mode] = fit(eng, 11)
+    assert res["plain"][1] == res["cooperative"][1] == res["auto"][1]
+    assert res["plain"][1]["sample_groups"] * res["plain"][1]["row_parts"] > 1        # the hand-offs are really in play
+    for mode in ("cooperative", "auto"):
+        for x, y in zip(res["plain"][0], res[mode][0]):
+            assert np.array_equal(x, y, equal_nan=True), mode
+    with pytest.raises(RuntimeError, match="vi_launch"):
+        eng.set_option("vi_launch", "sometimes")
+    # two threads, one handle and one stream each, cooperative launches in flight together
+    alone = [fit(engine.Engine(sp, gpu), 20 + k)[0] for k in range(2)]
+    got, errs = [None, None], []
+
+    def work(k):
+        try:
+            e = engine.Engine(sp, gpu)
+            got[k] = fit(e, 20 + k, torch.cuda.Stream(device=gpu))[0]
+        except Exception as ex:     # noqa: BLE001
+            errs.append(repr(ex))
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join(timeout=300)
+    assert not any(t.is_alive() for t in ts) and not errs, errs
+    for k in range(2):
+        for x, y in zip(alone[k], got[k]):
+            assert np.array_equal(x, y, equal_nan=True)
+
+
 @pytest.mark.parametrize("mname", ["8schools", "radon_MN"])
 def test_cvip_learns_parameterisation(oracle_lib, gpu, mname):
     from autoreparam_amd import engine

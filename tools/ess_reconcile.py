@@ -21,12 +21,12 @@ for m in ("cVIP", "dVIP"):
 L = 4
 t0 = time.time()
 cli.main(base + ["--inference=HMC", "--method=dVIP", "--num_leapfrog_steps=%d" % L, "--num_samples=%d" % S,
-                 "--trace_chunk_rows=8192", "--ess_chains=%d" % C], flags=flags_mod.FlagValues())
+                 "--trace_chunk_rows=8192", "--ess_chains=%d" % C], flags=flags_mod.FlagValues(), out=(sink := {}))
 print("full schedule: %.1f s" % (time.time() - t0))
 r = json.load(open(os.path.join(d, "dVIP_eig_tied.json")))
 print({k: r[k][-1] for k in ("ess_min", "sem_min", "ess_estimator", "ess_chains", "ess_min_batch_means", "sem_min_batch_means",
                              "batch_means_batch", "acceptance_rate")})
-info = inference.hmc.last_ess_info
+info = sink["kernel_results"].ess_info
 # the run's kept trace is gone with the call; run the sampler once more at the API level to hold the trace here
 from autoreparam_amd import graphs, models
 cfg = models.get_model_by_name("german_credit_lognormalcentered", dataset="")
@@ -35,7 +35,7 @@ target = cli.create_target_graph(cfg, d, f)[0]
 init = list(util.variational_inits_from_params(r["learned_variational_params"], param_names=list(cfg.model.part_names),
                                                num_inits=C, seed=f.seed).values())
 _, kr, st, ess = inference.hmc(target, cfg, r["initial_step_size"], init, None, flags=f)
-assert inference.hmc.last_ess_estimator == "autocorrelation"
+assert kr.ess_info.estimator == "autocorrelation"
 trace = torch.cat([p._t.reshape(S, C, -1) for p in st], dim=2)       # [S, C, D] on the device
 norm = lambda e, s: 1000.0 * e / (s * L)
 print("%-10s %-28s %-14s %-12s %s" % ("prefix S'", "ESS/1000 grads (mean min)", "mean min ESS", "arp_ess ms", "frac of series positive at lag 48"))

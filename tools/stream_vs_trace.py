@@ -26,4 +26,4 @@ for mode in modes:
     torch.cuda.synchronize(); dt = time.time() - t
     acc = 100.0 * np.sum(kr.inner_results.is_accepted) / (S * f.num_chains)
     print("%-5s S=%d: %.2f s  estimator %s  min-ESS %.1f  accept %.1f %%  kept trace %s" % (
-        mode, S, dt, inference.hmc.last_ess_estimator, util.get_min_ess(ess)[0], acc, st[0].shape), flush=True)
+        mode, S, dt, kr.ess_info.estimator, util.get_min_ess(ess)[0], acc, st[0].shape), flush=True)

@@ -2,7 +2,8 @@
 """Time the mean-field VI kernel: 5 learning rates x 3 000 steps x 256 draws (the reference's defaults,
 main.py:88-100) per model, HIP events around arp_vi_run, with the launch geometry the library chose.
 
-    python tools/vi_bench.py [model ...]        (ARP_DEBUG=1 ARP_VI_G=.. / ARP_VI_R=.. to force a geometry)
+    python tools/vi_bench.py [model ...]        (ARP_DEBUG=1 ARP_VI_G=.. / ARP_VI_R=.. to force a geometry;
+                                                 VI_LAUNCH=plain|cooperative: arp_model_set_option "vi_launch")
 """
 import os
 import sys
@@ -23,6 +24,8 @@ n_steps, n_mc = 3000, 256
 for name in names:
     sp = helpers.spec(name)
     eng = engine.Engine(sp, dev)
+    if os.environ.get("VI_LAUNCH"):
+        eng.set_option("vi_launch", os.environ["VI_LAUNCH"])       # plain | cooperative | auto
     for kind, learn in (("NCP", False), ("cVIP", True))[:int(os.environ.get("VI_BENCH_KINDS", "2"))]:
         if learn:
             eng.set_param(0, (np.full(sp.D, 0.5, np.float32), np.ones(sp.D, np.float32)))
