@@ -409,6 +409,341 @@ __global__ __launch_bounds__(256, ARP_ESS_MINB) void ess_kernel(const float* __r
   if (valid) ess[i] = constant ? __builtin_nanf("") : (float)((double)S / (-1.0 + 2.0 * total));
 }
 
+
+// ---------------------------------------------------------------------------
+// One pass, short series (32 <= S <= kTileMaxS = 1 024: the reference flow's 1 000 recorded samples).  The two-sweep
+// kernel above reads every series that is still positive at lag 16 a second time (2.0 - 2.5 x the trace on a sampler's own
+// output: profiles/r05_ess_kernel.json).  Here a workgroup owns a TILE of 32 neighbouring series for their whole length --
+// 32 x S floats, 128 KB at S = 1 000, one workgroup per CU -- reads it from HBM exactly once (row segments of 128 bytes)
+// into LDS and takes every lag a series needs from there, each series only as far as ITS cut:
+//   load     the 512 threads hold the next tile in registers (32 pairs each) while the current one is worked on; the loads
+//            go out eight at a time between the compute blocks (a CU's memory queue holds far fewer than a tile's 256
+//            wave-loads: issued in one go they block the wave until the first ones return) and the workgroup's barriers
+//            wait for LDS only, never for them: persistent workgroups, one per CU, tiles round-robin
+//   lags <= 16   thread (pair of series, 1/32 of the time axis): products about a reference level r (the mean of eight
+//            samples spread over the series), a 16-deep ring of pairs, 17 packed FMAs per row; summed over a wave's four
+//            row slots by permlane swaps and over the eight waves in a fixed order (bitwise reproducible)
+//   finish   wave w owns series 4 w .. 4 w + 3, lane = lag: the raw sums are centred about the mean
+//              sum_{t>=k} (y_t - m')(y_{t-k} - m') = P_k - m' (2 T - head_k - tail_k) + (S - k) m'^2
+//            (T = sum y, head_k / tail_k = the sums of the first / last k values), the first negative lag is a ballot,
+//            the sum up to it a DPP row sum.  No loop over lags, no single-wave section.
+//   further  a series still positive at lag 16 is taken by its wave, 16 lags per round until its cut: lane g forms the
+//            products of rows 17 g .. 17 g + 16 (an odd slice and the row pitch of 33 floats spread the 64 lanes over
+//            the 64 banks), then a DPP/permlane sum over the wave
+// (S - k)/S rho_k = [sum_k / (S - k)] (S - k)/S / [sum_0 / S] = sum_k / sum_0: no divisions per lag, and rho_k < 0 exactly when
+// sum_k < 0.  Algorithmic work follows the data (median cut lag ~ 10, ~ 28 % of the series past 16 on the headline flow's
+// trace) instead of giving every series of a wave 48 lags; HBM traffic is the trace, once.
+// ---------------------------------------------------------------------------
+constexpr bool kEssTileDefault = false; // arp_ess takes 32 <= S <= 1 024 through the tile kernel (see profiles/r06_ess_tile.txt)
+constexpr int kTileNS = 32;             // series per tile
+constexpr int kTilePitch = 34;          // floats per tile row in LDS (even: a pair of series is one aligned 8-byte access)
+constexpr int kTileMaxS = 1024;
+constexpr int kTileMinS = 32;
+constexpr int kTileThreads = 512;
+constexpr int kTileRowsPerThread = kTileMaxS / 32;    // of a PAIR of series
+constexpr int kTilePart = 20;           // floats per (wave, series) of partial sums: lags 0 .. 16, T, r, pad
+
+#ifdef ARP_ESS_PROF
+__device__ unsigned long long g_ess_prof[16];
+#define ARP_PROF_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); g_ess_prof[k] += t_ - prof_t; prof_t = t_; } } while (0)
+#else
+#define ARP_PROF_MARK(k) do { } while (0)
+#endif
+// LDS-only workgroup barrier: the tile prefetch (global loads into registers) stays in flight across it
+#define ARP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// The tile's LDS reads are unconditional (clamped index) and masked afterwards; left alone, the compiler sinks each read
+// under its mask again -- a branch per read.  Passing a batch of read values through one empty asm keeps the reads where
+// they are, at the price of one wait for the whole batch.
+template <int N>
+__device__ __forceinline__ void ess_pin(float (&x)[N]) {
+  static_assert(N == 8 || N == 16 || N == 17, "batches of 8 / 16 / 17");
+  if constexpr (N == 8)
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+  else if constexpr (N == 16)
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                      "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+  else
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                      "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]),
+                      "+v"(x[16]));
+}
+
+__device__ __forceinline__ float ess_row_sum(float v) {        // over the 16 lanes of a row, every lane gets the total
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_mov<0x124>(v);    // row_ror:4
+  v += dpp_mov<0x128>(v);    // row_ror:8
+  return v;
+}
+__device__ __forceinline__ float ess_rows_sum(float v) {       // over the four rows of a wave (lanes l, l^16, l^32, l^48)
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float ess_wave_sum(float v) {       // every lane gets the same total, fixed order
+  v = ess_rows_sum(ess_row_sum(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ double ess_readlane(double x, int lane) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane), lo = (unsigned)__builtin_amdgcn_readlane((int)b, lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(kTileThreads, 1) void ess_tile_kernel(const float* __restrict__ trace, int S, long long n,
+                                                                   long long stride, float* __restrict__ ess, int n_tiles) {
+  __shared__ float s_tile[kTileMaxS * kTilePitch];          // x_t of the tile's series: [t][33]
+  __shared__ float s_part[8 * kTileNS * kTilePart];         // per wave and series: raw sums of lags 0 .. 16, T, r
+  // a thread works on a PAIR of neighbouring series (columns 2 cp, 2 cp + 1: one 8-byte load, packed arithmetic) and one of
+  // 32 row slots: rows rs, rs + 32, ... when loading, the rs-th 1/32 of the time axis when forming lags 0 .. 16
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cp = tid & 15, rs = tid >> 4;
+  v2f v[kTileRowsPerThread];
+
+  // Rows rs + 32 i of a tile into v, eight at a time (a wave's load covers four rows x 128 bytes).  Every load is
+  // unconditional and in range: a row past S reads the thread's last row again (the offset stops advancing), a pair past
+  // the last series reads the last pair -- what lands there is never used, except that the last series of an odd count
+  // arrives in the SECOND half of the clamped pair (`swap`).  `off` is an offset, not a pointer: through the asm below a
+  // pointer would lose its address space and load as FLAT, which the LDS barriers would wait for.
+  long long off = 0;
+  int cnt = 0;
+  bool swap = false, swap_next = false;
+  auto load_begin = [&](int tile) {
+    const long long c = (long long)tile * kTileNS + 2 * cp;
+    swap_next = c == n - 1;
+    off = (long long)rs * stride + (c + 1 < n ? c : n - 2);
+    cnt = (S - rs + 31) / 32;           // rows rs + 32 i < S  <=>  i < cnt: tests against a constant, no row index kept
+    asm volatile("" : "+v"(cnt));       // (and recomputed per tile rather than kept as loop-invariant lane masks)
+  };
+  auto load_chunk = [&](auto chunk) {
+    constexpr int K = decltype(chunk)::value;
+    const long long step = 32 * stride;
+#pragma unroll
+    for (int i = 8 * K; i < 8 * K + 8; ++i) {
+      const float* q = trace + off;
+      v2f x;
+      x[0] = __builtin_nontemporal_load(q); x[1] = __builtin_nontemporal_load(q + 1);      // one global_load_dwordx2
+      v[i] = x;
+      off += (i + 1 < cnt) ? step : 0;
+      asm volatile("" : "+v"(off));     // a running offset: without this the row offsets become loop-invariant registers
+    }
+  };
+  using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+  using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
+
+#ifdef ARP_ESS_PROF
+  unsigned long long prof_t = __builtin_amdgcn_s_memtime();
+#endif
+  // A workgroup takes a CONTIGUOUS run of tiles: the workgroups that are resident together then read columns ~ 70 KB
+  // apart and cover every HBM channel.  (Round-robin tiles put all 256 workgroups on neighbouring 128-byte columns of rows
+  // that are a multiple of 2^18 bytes apart -- a few channels take all the traffic: 3.3 TB/s at best.)
+  const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  int tile = blockIdx.x * per;
+  const int tile_end = tile + per < n_tiles ? tile + per : n_tiles;
+  if (tile < tile_end) { load_begin(tile); load_chunk(C0{}); load_chunk(C1{}); load_chunk(C2{}); load_chunk(C3{}); }
+  const int S_arg = S;
+  for (; tile < tile_end; ++tile) {
+    // everything below derives its row bounds, masks and LDS addresses from this copy: opaque per tile, so that they are
+    // recomputed (a few hundred scalar / vector instructions) instead of living in ~ 100 loop-invariant registers next to
+    // the 64 of the prefetched tile
+    int S = S_arg;
+    asm volatile("" : "+s"(S));
+    const long long col0 = (long long)tile * kTileNS;
+    const int ncol = (int)(n - col0 < kTileNS ? n - col0 : kTileNS);
+    const bool more = tile + 1 < tile_end;
+    swap = swap_next;
+    ARP_LDS_BARRIER();       // every wave has left the previous tile's LDS
+    ARP_PROF_MARK(0);
+    // ---- the tile, as it is (rows S .. 1 023 exist in LDS: written unconditionally, never read)
+#pragma unroll
+    for (int i = 0; i < kTileRowsPerThread; ++i) {
+      v2f x = v[i];
+      if (swap) x[0] = x[1];
+      *reinterpret_cast<v2f*>(s_tile + (rs + 32 * i) * kTilePitch + 2 * cp) = x;
+    }
+    ARP_PROF_MARK(1);
+    // (unconditional: behind the last tile the same tile is loaded once more and dropped -- under `if (more)` the loaded pairs
+    //  meet the old ones in a phi at the end of the branch, and the register allocator copies them there, i.e. waits for them)
+    load_begin(more ? tile + 1 : tile); load_chunk(C0{});
+    ARP_LDS_BARRIER();
+    ARP_PROF_MARK(2);
+    // ---- lags 0 .. 16 of the series pair about r: rows [t0, t1), a 16-deep ring of pairs, 17 packed FMAs per row
+    {
+      const int SL = (S + 31) / 32;
+      const int t0 = rs * SL, t1 = (t0 + SL < S) ? t0 + SL : S;
+      const float* col = s_tile + 2 * cp;
+      v2f r;
+      {
+        float a0[8], a1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const v2f q = *reinterpret_cast<const v2f*>(col + ((S - 1) * k / 7) * kTilePitch); a0[k] = q[0]; a1[k] = q[1]; }
+        ess_pin(a0); ess_pin(a1);
+        r = v2f{((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a0[4] + a0[5]) + (a0[6] + a0[7])),
+                ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]))} * 0.125f;
+      }
+      v2f acc[17], ring[16], sy = v2f{0.0f, 0.0f};
+#pragma unroll
+      for (int j = 0; j <= 16; ++j) acc[j] = v2f{0.0f, 0.0f};
+      {
+        float r0[16], r1[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {                        // ring[m & 15] = y_{t0 + m}, m = -16 .. -1
+          const int t = t0 - 16 + j;
+          const v2f q = *reinterpret_cast<const v2f*>(col + (t < 0 ? 0 : (t < kTileMaxS ? t : kTileMaxS - 1)) * kTilePitch);
+          r0[j] = q[0]; r1[j] = q[1];
+        }
+        ess_pin(r0); ess_pin(r1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const bool in = t0 - 16 + j >= 0 && t0 - 16 + j < t1;
+          ring[j] = in ? v2f{r0[j], r1[j]} - r : v2f{0.0f, 0.0f};
+        }
+      }
+      auto half = [&](int tb, auto hh) {                          // eight rows: ring positions 8 H .. 8 H + 7
+        constexpr int H = decltype(hh)::value;
+        float y0[8], y1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int t = tb + 8 * H + i;                           // (clamped to the tile)
+          const v2f q = *reinterpret_cast<const v2f*>(col + (t < kTileMaxS ? t : kTileMaxS - 1) * kTilePitch);
+          y0[i] = q[0]; y1[i] = q[1];
+        }
+        ess_pin(y0); ess_pin(y1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          constexpr int dummy = 0; (void)dummy;
+          const int p = 8 * H + i;
+          const v2f y = tb + p < t1 ? v2f{y0[i], y1[i]} - r : v2f{0.0f, 0.0f};
+          acc[0] = vfma(y, y, acc[0]);
+          sy += y;
+#pragma unroll
+          for (int j = 1; j <= 16; ++j) acc[j] = vfma(y, ring[(p - j + 32) & 15], acc[j]);
+          ring[p] = y;
+        }
+      };
+
+      if (t0 < t1) { half(t0, C0{}); half(t0, C1{}); }
+      ARP_PROF_MARK(3);
+      load_chunk(C1{});
+      ARP_PROF_MARK(4);
+      if (t0 + 16 < t1) { half(t0 + 16, C0{}); half(t0 + 16, C1{}); }
+      ARP_PROF_MARK(5);
+      load_chunk(C2{});
+      ARP_PROF_MARK(6);
+      // The wave's four row slots (lanes l, l^16, l^32, l^48) are added by permlane SWAPS, two values per swap: with rows
+      // [A0 A1 A2 A3] and [B0 B1 B2 B3], v_permlane16_swap leaves [A0 B0 A2 B2] and [A1 B1 A3 B3], whose sum holds A's pair sums
+      // in rows 0 / 2 and B's in rows 1 / 3; v_permlane32_swap does the same with the wave's halves.  36 values (lags
+      // 0 .. 16 and T, both series) take 27 swaps and 27 adds, and row q ends up with the totals of values 4 m + q -- every
+      // lane stores nine of them, no lane idles.  (Below: the eight waves in order.)
+      float X[36];
+#pragma unroll
+      for (int j = 0; j <= 16; ++j) { X[2 * j] = acc[j][0]; X[2 * j + 1] = acc[j][1]; }
+      X[34] = sy[0]; X[35] = sy[1];
+      float Y[18];
+#pragma unroll
+      for (int m = 0; m < 18; ++m) {         // Y[m]: rows 0, 2 = X[2m] pair sums, rows 1, 3 = X[2m+1] pair sums
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[2 * m]), __float_as_uint(X[2 * m + 1]), false, false);
+        Y[m] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      }
+      const int q4 = l >> 4;
+      float* pa = s_part + (w * kTileNS + 2 * cp) * kTilePart;
+#pragma unroll
+      for (int m = 0; m < 9; ++m) {          // rows 0 .. 3 = totals of X[4m], X[4m+1], X[4m+2], X[4m+3]
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(Y[2 * m]), __float_as_uint(Y[2 * m + 1]), false, false);
+        const float z = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        const int i = 4 * m + q4;            // value index: lag i >> 1 (17 = T), series i & 1 of the pair
+        pa[(i & 1) * kTilePart + (i >> 1)] = z;
+      }
+      if (l < 16) { pa[18] = r[0]; pa[kTilePart + 18] = r[1]; }
+    }
+    ARP_PROF_MARK(7);
+    load_chunk(C3{});
+    ARP_PROF_MARK(8);
+    ARP_LDS_BARRIER();
+    ARP_PROF_MARK(9);
+    // ---- wave w finishes series 4 w + (l >> 4); lane k = l & 15 holds lag k + 1
+    {
+      const int q4 = l >> 4, k = l & 15, u = 4 * w + q4, j = k + 1;
+      double Pj = 0.0, P0 = 0.0, T = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) {
+        const float* pp = s_part + (ww * kTileNS + u) * kTilePart;
+        Pj += (double)pp[j]; P0 += (double)pp[0]; T += (double)pp[17];
+      }
+      const float r = s_part[u * kTilePart + 18];
+      const float* colu = s_tile + u;
+      float hd = 0.0f, tl = 0.0f;            // sums of the first / last j values of y
+      {
+        float h[16], g[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { h[i] = colu[(i < S ? i : 0) * kTilePitch]; g[i] = colu[(S - 1 - i > 0 ? S - 1 - i : 0) * kTilePitch]; }
+        ess_pin(h); ess_pin(g);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { hd += (i < j && i < S) ? h[i] - r : 0.0f; tl += (i < j && i < S) ? g[i] - r : 0.0f; }
+      }
+      const double mp = T / (double)S;
+      const double cj = Pj - mp * (2.0 * T - (double)hd - (double)tl) + (double)(S - j) * mp * mp;
+      const double sum0 = P0 - (double)S * mp * mp;
+      const bool constant = !(sum0 > 0.0);
+      const unsigned long long neg = __ballot(cj < 0.0 || j >= S);
+      const unsigned mine = (unsigned)(neg >> (16 * q4)) & 0xffffu;
+      const int first = mine ? __builtin_ctz(mine) : 16;          // lags 1 .. first are taken
+      const float part = ess_row_sum(k < first ? (float)(cj / sum0) : 0.0f);
+      double total = 1.0 + (double)part;
+      const bool valid = u < ncol;
+      const bool open = first == 16 && S > 17 && valid && !constant;
+      if (k == 0 && valid && !open) ess[col0 + u] = constant ? __builtin_nanf("") : (float)((double)S / (-1.0 + 2.0 * total));
+      ARP_PROF_MARK(10);
+      // ---- the wave's series that go on, one after the other: 16 lags per round by all 64 lanes
+      const unsigned long long open_m = __ballot(open && k == 0);
+      const float mu = r + (float)mp;                              // the series' mean
+      const int SLd = ((S + 63) / 64) | 1;                         // odd slice: lane g's rows are 17 g .. 17 g + 16 at S = 1 000 (pitch 34: 32 banks)
+      for (int qq = 0; qq < 4; ++qq) {
+        if (!((open_m >> (16 * qq)) & 1ull)) continue;
+        const int uu = 4 * w + qq;
+        const double inv = 1.0 / ess_readlane(sum0, 16 * qq);
+        double tot = ess_readlane(total, 16 * qq);
+        const float mu_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mu), 16 * qq));
+        const float* cu = s_tile + uu;
+        const int t0 = l * SLd;
+        bool done = false;
+        for (int kb = 16; !done; kb += 16) {
+          float acc[17], ring[16];
+#pragma unroll
+          for (int jj = 1; jj <= 16; ++jj) acc[jj] = 0.0f;
+          auto at = [&](int t) { return cu[(t < 0 ? 0 : (t < kTileMaxS ? t : kTileMaxS - 1)) * kTilePitch]; };
+#pragma unroll
+          for (int jj = 0; jj < 16; ++jj) ring[jj] = at(t0 - 16 + jj - kb);      // ring[m & 15] = y_{t0 + m - kb}, m = -16 .. -1
+          float ya[17], yl[17];
+#pragma unroll
+          for (int i = 0; i < 17; ++i) { ya[i] = at(t0 + i); yl[i] = at(t0 + i - kb); }
+          ess_pin(ring); ess_pin(ya); ess_pin(yl);
+#pragma unroll
+          for (int jj = 0; jj < 16; ++jj) { const int t = t0 - 16 + jj - kb; ring[jj] = (t >= 0 && t < S) ? ring[jj] - mu_u : 0.0f; }
+#pragma unroll
+          for (int i = 0; i < 17; ++i) {
+            const int t = t0 + i;
+            const bool in = i < SLd && t < S;
+            const float y = in ? ya[i] - mu_u : 0.0f;
+#pragma unroll
+            for (int jj = 1; jj <= 16; ++jj) acc[jj] = fmaf(y, ring[(i - jj + 32) & 15], acc[jj]);
+            ring[i & 15] = (in && t - kb >= 0) ? yl[i] - mu_u : 0.0f;
+          }
+#pragma unroll
+          for (int jj = 1; jj <= 16; ++jj) {
+            const float c = ess_wave_sum(acc[jj]);
+            done = done || kb + jj >= S || c < 0.0f;
+            tot += done ? 0.0 : (double)c * inv;
+          }
+        }
+        if (l == 0) ess[col0 + uu] = (float)((double)S / (-1.0 + 2.0 * tot));
+      }
+    }
+    ARP_PROF_MARK(11);
+  }
+}
+
 }  // namespace arp
 
 namespace arp {
@@ -426,6 +761,14 @@ struct EssWsLayout {
   }
 };
 }  // namespace arp
+
+#ifdef ARP_ESS_PROF
+extern "C" int arp_debug_ess_prof(unsigned long long* out16, int reset) {
+  if (out16) ARP_HIP_OK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(arp::g_ess_prof), 16 * sizeof(unsigned long long)));
+  if (reset) { unsigned long long z[16] = {0}; ARP_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(arp::g_ess_prof), z, sizeof(z))); }
+  return 0;
+}
+#endif
 
 extern "C" int64_t arp_ess_workspace_bytes(int64_t n_samples, int64_t n_series) {
   using namespace arp;
@@ -465,6 +808,29 @@ extern "C" int arp_ess_ws(const float* trace, int64_t n_samples, int64_t n_serie
     D = EssDefer{(unsigned*)w, (unsigned*)(w + Lw.off_idx), (float*)(w + Lw.off_mean), (double*)(w + Lw.off_c0),
                  (double*)(w + Lw.off_total), (int*)(w + Lw.off_from)};
     ARP_HIP_OK(hipMemsetAsync(w, 0, 256, st));
+  }
+  // short series: the one-pass tile kernel (the trace is read once; every lag from LDS)
+  bool tile_path = n_samples >= kTileMinS && n_samples <= kTileMaxS && n_series >= 2 && row_stride < (1ll << 29);
+  {
+    // which kernel takes short series: the library default below, or (experiments, ARP_DEBUG=1) ARP_ESS_TILE=0 / 1
+    const char* e = getenv("ARP_ESS_TILE");
+    const char* d = getenv("ARP_DEBUG");
+    const bool dbg = e && d && d[0] == '1' && d[1] == 0;
+    if (!kEssTileDefault) tile_path = tile_path && dbg && e[0] == '1';
+    else if (dbg && e[0] == '0') tile_path = false;
+  }
+  if (tile_path) {
+    static thread_local int cus_of[64] = {0};
+    int dev = 0;
+    ARP_HIP_OK(hipGetDevice(&dev));
+    int& cus = cus_of[dev & 63];
+    if (cus <= 0) ARP_HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const long long n_tiles = (n_series + kTileNS - 1) / kTileNS;
+    const unsigned grid = (unsigned)std::min<long long>(n_tiles, cus > 0 ? cus : 256);
+    hipLaunchKernelGGL(ess_tile_kernel, dim3(grid), dim3(kTileThreads), 0, st, trace, (int)n_samples, (long long)n_series,
+                       (long long)row_stride, ess, (int)n_tiles);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
   }
   hipLaunchKernelGGL(ess_kernel, dim3((unsigned)blocks), dim3(256), 0, st, trace, (long long)n_samples,
                      (long long)n_series, (long long)row_stride, ess, D);

@@ -362,7 +362,7 @@ def _initial_rows(spec, parts, dev):
     for p in parts:
         t = p if torch.is_tensor(p) else torch.from_numpy(np.ascontiguousarray(p, np.float32))
         t = t.to(device=dev, dtype=torch.float32)
-        cols.append(t.reshape(t.shape[0], -1))
+        cols.append(t.reshape(t.shape[0], int(np.prod(t.shape[1:], dtype=np.int64))))     # (-1 is ambiguous for a rank without chains)
     q0 = torch.cat(cols, dim=1).contiguous()
     if q0.shape[1] != spec.D:
         raise ValueError("initial states do not have the model's parts: %d columns, the model has D = %d" % (q0.shape[1], spec.D))

@@ -326,3 +326,50 @@ def test_a_rank_without_chains_returns_empty_blocks(gpu, streaming):
     t_cp, t_ncp = target, graphs.make_ncp_graph(cfg, flags=f)[0]
     st_i, kr_i, ess_i = inference.hmc_interleaved(cfg, t_cp, t_ncp, 2, 2, step, step, init, flags=f, chain_offset=5)
     assert kr_i.ess_info.chains == 0 and all(np.asarray(e).shape[0] == 0 for e in ess_i)
+
+
+def _ar1(rs, S, n, rho):
+    x = np.empty((S, n), np.float32)
+    prev = rs.randn(n)
+    rho = np.broadcast_to(np.asarray(rho, np.float64), (n,))
+    for t in range(S):
+        prev = rho * prev + np.sqrt(1 - rho * rho) * rs.randn(n)
+        x[t] = prev
+    return x
+
+
+@pytest.mark.parametrize("S,n", [(32, 1), (33, 31), (100, 33), (999, 1000), (1000, 4097), (1024, 64), (1000, 65)])
+def test_one_pass_tile_ess_matches_oracle_and_the_two_sweep_kernel(gpu, monkeypatch, S, n):
+    """ess.hip: ess_tile_kernel (32 <= S <= 1 024: a workgroup keeps 32 series in LDS for their whole length, the trace is
+    read once) against the oracle's float64 tfp.mcmc.effective_sample_size restatement (oracle/ess_ref.py; inference.py:240)
+    and against the two-sweep kernel (ARP_ESS_TILE=0): fast and slowly mixing series side by side (cuts from lag 1 to
+    several hundred), an offset 10^4 standard deviations from zero, a constant series (NaN as in the FFT form), a trending one,
+    ragged tile widths, a strided view of a wider trace, and the same bits run after run."""
+    from oracle import ess_ref
+    from autoreparam_amd import util
+    rs = np.random.RandomState(S * 7 + n)
+    rho = rs.choice([0.0, 0.3, 0.6, 0.9, 0.97, 0.995], size=n)
+    x = _ar1(rs, S, n, rho)
+    x[:, 0] += 1e4 * 1.0                                   # far from zero: the mean is taken about each thread's first value
+    if n > 5:
+        x[:, 3] = 2.5                                     # constant
+        x[:, 4] += np.linspace(0, 20, S)                   # trend: positive at every lag up to ~ S / 3
+    xd = torch.as_tensor(x).to(gpu).reshape(S, n, 1)
+    monkeypatch.setenv("ARP_DEBUG", "1"); monkeypatch.setenv("ARP_ESS_TILE", "1")
+    got = util.effective_sample_size(xd).cpu().numpy().reshape(n)
+    got2 = util.effective_sample_size(xd).cpu().numpy().reshape(n)
+    assert np.array_equal(got, got2, equal_nan=True)
+    want = ess_ref.ess_fft(x.astype(np.float64).reshape(S, n, 1)).reshape(n)
+    if n > 5:
+        assert np.isnan(got[3]) and np.isnan(want[3])
+    ok = ~np.isnan(want)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=2e-3)
+    monkeypatch.setenv("ARP_ESS_TILE", "0")
+    old = util.effective_sample_size(xd).cpu().numpy().reshape(n)
+    monkeypatch.setenv("ARP_ESS_TILE", "1")
+    np.testing.assert_allclose(got[ok], old[ok], rtol=2e-3)
+    # a leading block of a wider trace, in place (row stride > series count)
+    if n >= 33:
+        k = 17
+        sub = util.effective_sample_size(xd.reshape(S, n, 1)[:, :k, :]).cpu().numpy().reshape(k)
+        assert np.array_equal(sub, got[:k], equal_nan=True)

@@ -40,6 +40,8 @@ gb = trace.numel() * 4 / 1e9
 trace.normal_()
 ms, _ = timeit(trace)
 print("white noise          : %.3f ms  %.2f TB/s (one pass over %.1f GB)" % (ms, gb / ms, gb), flush=True)
+if os.environ.get("ESS_ONLY_WHITE"):
+    sys.exit(0)
 # (2) AR(1), rho = 0.75 on 3 of 71 elements (the top-level scalars), 0.3 elsewhere
 rho = torch.full((D,), 0.3, device=dev); rho[:3] = 0.75
 e = trace.clone() if False else None
