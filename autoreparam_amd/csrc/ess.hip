@@ -441,7 +441,6 @@ constexpr int kTileMaxS = 1024;
 constexpr int kTileMinS = 32;
 constexpr int kTileThreads = 512;
 constexpr int kTileRowsPerThread = kTileMaxS / 32;    // of a PAIR of series
-constexpr int kTilePart = 20;           // floats per (wave, series) of partial sums: lags 0 .. 16, T, r, pad
 
 #ifdef ARP_ESS_PROF
 __device__ unsigned long long g_ess_prof[16];
@@ -492,12 +491,17 @@ __device__ __forceinline__ double ess_readlane(double x, int lane) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// physical LDS row of tile row t: one row of padding behind every 32, so that the 32 time slots of a series (32 rows
+// apart) start 33 physical rows apart -- with the even pitch of 34 floats that spreads them over 32 different bank pairs
+__device__ __forceinline__ int ess_prow(int t) { return (t + (t >> 5)) * kTilePitch; }
+
 __global__ __launch_bounds__(kTileThreads, 1) void ess_tile_kernel(const float* __restrict__ trace, int S, long long n,
                                                                    long long stride, float* __restrict__ ess, int n_tiles) {
-  __shared__ float s_tile[kTileMaxS * kTilePitch];          // x_t of the tile's series: [t][33]
-  __shared__ float s_part[8 * kTileNS * kTilePart];         // per wave and series: raw sums of lags 0 .. 16, T, r
-  // a thread works on a PAIR of neighbouring series (columns 2 cp, 2 cp + 1: one 8-byte load, packed arithmetic) and one of
-  // 32 row slots: rows rs, rs + 32, ... when loading, the rs-th 1/32 of the time axis when forming lags 0 .. 16
+  __shared__ __attribute__((aligned(16))) float s_tile[(kTileMaxS + kTileMaxS / 32) * kTilePitch];   // x_t of the tile's series
+  // LOADING: a thread takes a pair of neighbouring series (columns 2 cp, 2 cp + 1: one 8-byte load) and rows rs + 32 i.
+  // WORKING: wave w owns series 4 w .. 4 w + 3 for their whole length -- lanes 0 - 31 the pair (4 w, 4 w + 1), lanes 32 - 63
+  // the pair (4 w + 2, 4 w + 3), lane & 31 = the 1/32 of the time axis it forms products for.  Nothing is combined
+  // between waves.
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cp = tid & 15, rs = tid >> 4;
   v2f v[kTileRowsPerThread];
 
@@ -536,8 +540,7 @@ __global__ __launch_bounds__(kTileThreads, 1) void ess_tile_kernel(const float* 
   unsigned long long prof_t = __builtin_amdgcn_s_memtime();
 #endif
   // A workgroup takes a CONTIGUOUS run of tiles: the workgroups that are resident together then read columns ~ 70 KB
-  // apart and cover every HBM channel.  (Round-robin tiles put all 256 workgroups on neighbouring 128-byte columns of rows
-  // that are a multiple of 2^18 bytes apart -- a few channels take all the traffic: 3.3 TB/s at best.)
+  // apart, spread over the HBM channels
   const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
   int tile = blockIdx.x * per;
   const int tile_end = tile + per < n_tiles ? tile + per : n_tiles;
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(kTileThreads, 1) void ess_tile_kernel(const float* 
     for (int i = 0; i < kTileRowsPerThread; ++i) {
       v2f x = v[i];
       if (swap) x[0] = x[1];
-      *reinterpret_cast<v2f*>(s_tile + (rs + 32 * i) * kTilePitch + 2 * cp) = x;
+      *reinterpret_cast<v2f*>(s_tile + (rs + 33 * i) * kTilePitch + 2 * cp) = x;        // physical row of rs + 32 i (rs < 32)
     }
     ARP_PROF_MARK(1);
     // (unconditional: behind the last tile the same tile is loaded once more and dropped -- under `if (more)` the loaded pairs
@@ -568,32 +571,30 @@ __global__ __launch_bounds__(kTileThreads, 1) void ess_tile_kernel(const float* 
     load_begin(more ? tile + 1 : tile); load_chunk(C0{});
     ARP_LDS_BARRIER();
     ARP_PROF_MARK(2);
-    // ---- lags 0 .. 16 of the series pair about r: rows [t0, t1), a 16-deep ring of pairs, 17 packed FMAs per row
+    // ---- lags 0 .. 16 of the lane's series pair about r: rows [t0, t1), a 16-deep ring of pairs, 17 packed FMAs per row
+    const int hp = l >> 5, slot = l & 31, q4 = l >> 4;
+    const float* col = s_tile + 4 * w + 2 * hp;
+    auto pair_at = [&](int t) { return *reinterpret_cast<const v2f*>(col + ess_prow(t)); };
+    v2f r;
+    float X[36];             // raw sums: X[2 j + c] = lag j of the pair's series c, X[34 + c] = T
     {
-      const int SL = (S + 31) / 32;
-      const int t0 = rs * SL, t1 = (t0 + SL < S) ? t0 + SL : S;
-      const float* col = s_tile + 2 * cp;
-      v2f r;
-      {
-        float a0[8], a1[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const v2f q = *reinterpret_cast<const v2f*>(col + ((S - 1) * k / 7) * kTilePitch); a0[k] = q[0]; a1[k] = q[1]; }
-        ess_pin(a0); ess_pin(a1);
-        r = v2f{((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a0[4] + a0[5]) + (a0[6] + a0[7])),
-                ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]))} * 0.125f;
-      }
+      const int t0 = 32 * slot, t1 = (t0 + 32 < S) ? t0 + 32 : S;
       v2f acc[17], ring[16], sy = v2f{0.0f, 0.0f};
 #pragma unroll
       for (int j = 0; j <= 16; ++j) acc[j] = v2f{0.0f, 0.0f};
       {
-        float r0[16], r1[16];
+        float a0[8], a1[8], r0[16], r1[16];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const v2f q = pair_at((S - 1) * k / 7); a0[k] = q[0]; a1[k] = q[1]; }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {                        // ring[m & 15] = y_{t0 + m}, m = -16 .. -1
           const int t = t0 - 16 + j;
-          const v2f q = *reinterpret_cast<const v2f*>(col + (t < 0 ? 0 : (t < kTileMaxS ? t : kTileMaxS - 1)) * kTilePitch);
+          const v2f q = pair_at(t < 0 ? 0 : (t < kTileMaxS ? t : kTileMaxS - 1));
           r0[j] = q[0]; r1[j] = q[1];
         }
-        ess_pin(r0); ess_pin(r1);
+        ess_pin(a0); ess_pin(a1); ess_pin(r0); ess_pin(r1);
+        r = v2f{((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a0[4] + a0[5]) + (a0[6] + a0[7])),
+                ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]))} * 0.125f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const bool in = t0 - 16 + j >= 0 && t0 - 16 + j < t1;
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(kTileThreads, 1) void ess_tile_kernel(const float* 
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int t = tb + 8 * H + i;                           // (clamped to the tile)
-          const v2f q = *reinterpret_cast<const v2f*>(col + (t < kTileMaxS ? t : kTileMaxS - 1) * kTilePitch);
+          const v2f q = pair_at(t < kTileMaxS ? t : kTileMaxS - 1);
           y0[i] = q[0]; y1[i] = q[1];
         }
         ess_pin(y0); ess_pin(y1);
@@ -622,7 +623,6 @@ __global__ __launch_bounds__(kTileThreads, 1) void ess_tile_kernel(const float* 
           ring[p] = y;
         }
       };
-
       if (t0 < t1) { half(t0, C0{}); half(t0, C1{}); }
       ARP_PROF_MARK(3);
       load_chunk(C1{});
@@ -631,88 +631,72 @@ __global__ __launch_bounds__(kTileThreads, 1) void ess_tile_kernel(const float* 
       ARP_PROF_MARK(5);
       load_chunk(C2{});
       ARP_PROF_MARK(6);
-      // The wave's four row slots (lanes l, l^16, l^32, l^48) are added by permlane SWAPS, two values per swap: with rows
-      // [A0 A1 A2 A3] and [B0 B1 B2 B3], v_permlane16_swap leaves [A0 B0 A2 B2] and [A1 B1 A3 B3], whose sum holds A's pair sums
-      // in rows 0 / 2 and B's in rows 1 / 3; v_permlane32_swap does the same with the wave's halves.  36 values (lags
-      // 0 .. 16 and T, both series) take 27 swaps and 27 adds, and row q ends up with the totals of values 4 m + q -- every
-      // lane stores nine of them, no lane idles.  (Below: the eight waves in order.)
-      float X[36];
 #pragma unroll
       for (int j = 0; j <= 16; ++j) { X[2 * j] = acc[j][0]; X[2 * j + 1] = acc[j][1]; }
       X[34] = sy[0]; X[35] = sy[1];
-      float Y[18];
+    }
+    // ---- the 32 time slots of a pair: over the 16 lanes of a row by DPP, then the pair's two rows by a permlane swap that
+    // leaves series 0's totals in the even row and series 1's in the odd row -- row q4 of the wave now holds series
+    // 4 w + q4, every lane of the row the same 18 numbers
+    // (the swap first -- it halves what the DPP row sums have to add: 18 values instead of 36)
+    float Y[18];
 #pragma unroll
-      for (int m = 0; m < 18; ++m) {         // Y[m]: rows 0, 2 = X[2m] pair sums, rows 1, 3 = X[2m+1] pair sums
-        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[2 * m]), __float_as_uint(X[2 * m + 1]), false, false);
-        Y[m] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-      }
-      const int q4 = l >> 4;
-      float* pa = s_part + (w * kTileNS + 2 * cp) * kTilePart;
-#pragma unroll
-      for (int m = 0; m < 9; ++m) {          // rows 0 .. 3 = totals of X[4m], X[4m+1], X[4m+2], X[4m+3]
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(Y[2 * m]), __float_as_uint(Y[2 * m + 1]), false, false);
-        const float z = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        const int i = 4 * m + q4;            // value index: lag i >> 1 (17 = T), series i & 1 of the pair
-        pa[(i & 1) * kTilePart + (i >> 1)] = z;
-      }
-      if (l < 16) { pa[18] = r[0]; pa[kTilePart + 18] = r[1]; }
+    for (int m = 0; m < 18; ++m) {
+      const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[2 * m]), __float_as_uint(X[2 * m + 1]), false, false);
+      Y[m] = ess_row_sum(__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
     }
     ARP_PROF_MARK(7);
     load_chunk(C3{});
     ARP_PROF_MARK(8);
-    ARP_LDS_BARRIER();
-    ARP_PROF_MARK(9);
-    // ---- wave w finishes series 4 w + (l >> 4); lane k = l & 15 holds lag k + 1
+    // ---- centre about the mean and cut at the first negative lag (every lane of the row does the same arithmetic)
     {
-      const int q4 = l >> 4, k = l & 15, u = 4 * w + q4, j = k + 1;
-      double Pj = 0.0, P0 = 0.0, T = 0.0;
-#pragma unroll
-      for (int ww = 0; ww < 8; ++ww) {
-        const float* pp = s_part + (ww * kTileNS + u) * kTilePart;
-        Pj += (double)pp[j]; P0 += (double)pp[0]; T += (double)pp[17];
-      }
-      const float r = s_part[u * kTilePart + 18];
+      const int u = 4 * w + q4;
+      const float ru = (q4 & 1) ? r[1] : r[0];
       const float* colu = s_tile + u;
-      float hd = 0.0f, tl = 0.0f;            // sums of the first / last j values of y
-      {
-        float h[16], g[16];
+      float h[16], g[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { h[i] = colu[(i < S ? i : 0) * kTilePitch]; g[i] = colu[(S - 1 - i > 0 ? S - 1 - i : 0) * kTilePitch]; }
-        ess_pin(h); ess_pin(g);
+      for (int i = 0; i < 16; ++i) { h[i] = colu[ess_prow(i)]; g[i] = colu[ess_prow(S - 1 - i)]; }     // (S >= 32)
+      ess_pin(h); ess_pin(g);
+      // float throughout: r sits within about a standard deviation of the mean, so the correction terms are of the size of the
+      // sums they correct (|m'|^2 <~ c_0) and their rounding is that of the sums themselves (~ 1e-6 relative)
+      const float T = Y[17], Sf = (float)S, mp = T / Sf;
+      const float sum0 = fmaf(-Sf * mp, mp, Y[0]);
+      const bool constant = !(sum0 > 0.0f);
+      const float inv_f = 1.0f / sum0;
+      const double inv = (double)inv_f;
+      float tsum = 0.0f, ht = 0.0f;            // ht = head_j + tail_j: the sums of the first and the last j values of y
+      bool done = constant;
+      const float twoT = 2.0f * T, mp2 = mp * mp;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { hd += (i < j && i < S) ? h[i] - r : 0.0f; tl += (i < j && i < S) ? g[i] - r : 0.0f; }
+      for (int j = 1; j <= 16; ++j) {
+        ht += (h[j - 1] - ru) + (g[j - 1] - ru);
+        const float cj = fmaf(Sf - (float)j, mp2, fmaf(-mp, twoT - ht, Y[j]));
+        done = done || cj < 0.0f;
+        tsum += done ? 0.0f : cj * inv_f;
       }
-      const double mp = T / (double)S;
-      const double cj = Pj - mp * (2.0 * T - (double)hd - (double)tl) + (double)(S - j) * mp * mp;
-      const double sum0 = P0 - (double)S * mp * mp;
-      const bool constant = !(sum0 > 0.0);
-      const unsigned long long neg = __ballot(cj < 0.0 || j >= S);
-      const unsigned mine = (unsigned)(neg >> (16 * q4)) & 0xffffu;
-      const int first = mine ? __builtin_ctz(mine) : 16;          // lags 1 .. first are taken
-      const float part = ess_row_sum(k < first ? (float)(cj / sum0) : 0.0f);
-      double total = 1.0 + (double)part;
+      const double total = 1.0 + (double)tsum;
       const bool valid = u < ncol;
-      const bool open = first == 16 && S > 17 && valid && !constant;
-      if (k == 0 && valid && !open) ess[col0 + u] = constant ? __builtin_nanf("") : (float)((double)S / (-1.0 + 2.0 * total));
-      ARP_PROF_MARK(10);
+      const bool open = !done && S > 17 && valid;
+      if ((l & 15) == 0 && valid && !open) ess[col0 + u] = constant ? __builtin_nanf("") : (float)((double)S / (-1.0 + 2.0 * total));
+      ARP_PROF_MARK(9);
       // ---- the wave's series that go on, one after the other: 16 lags per round by all 64 lanes
-      const unsigned long long open_m = __ballot(open && k == 0);
-      const float mu = r + (float)mp;                              // the series' mean
-      const int SLd = ((S + 63) / 64) | 1;                         // odd slice: lane g's rows are 17 g .. 17 g + 16 at S = 1 000 (pitch 34: 32 banks)
+      const unsigned long long open_m = __ballot(open && (l & 15) == 0);
+      const float mu = ru + (float)mp;                             // the series' mean
+      const int SLd = ((S + 63) / 64) | 1;                         // odd slice: lane g's rows are 17 g .. 17 g + 16 at S = 1 000
       for (int qq = 0; qq < 4; ++qq) {
         if (!((open_m >> (16 * qq)) & 1ull)) continue;
         const int uu = 4 * w + qq;
-        const double inv = 1.0 / ess_readlane(sum0, 16 * qq);
+        const double inv_u = ess_readlane(inv, 16 * qq);
         double tot = ess_readlane(total, 16 * qq);
         const float mu_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mu), 16 * qq));
         const float* cu = s_tile + uu;
         const int t0 = l * SLd;
-        bool done = false;
-        for (int kb = 16; !done; kb += 16) {
+        bool fin = false;
+        for (int kb = 16; !fin; kb += 16) {
           float acc[17], ring[16];
 #pragma unroll
           for (int jj = 1; jj <= 16; ++jj) acc[jj] = 0.0f;
-          auto at = [&](int t) { return cu[(t < 0 ? 0 : (t < kTileMaxS ? t : kTileMaxS - 1)) * kTilePitch]; };
+          auto at = [&](int t) { return cu[ess_prow(t < 0 ? 0 : (t < kTileMaxS ? t : kTileMaxS - 1))]; };
 #pragma unroll
           for (int jj = 0; jj < 16; ++jj) ring[jj] = at(t0 - 16 + jj - kb);      // ring[m & 15] = y_{t0 + m - kb}, m = -16 .. -1
           float ya[17], yl[17];
@@ -733,14 +717,14 @@ __global__ __launch_bounds__(kTileThreads, 1) void ess_tile_kernel(const float* 
 #pragma unroll
           for (int jj = 1; jj <= 16; ++jj) {
             const float c = ess_wave_sum(acc[jj]);
-            done = done || kb + jj >= S || c < 0.0f;
-            tot += done ? 0.0 : (double)c * inv;
+            fin = fin || kb + jj >= S || c < 0.0f;
+            tot += fin ? 0.0 : (double)c * inv_u;
           }
         }
         if (l == 0) ess[col0 + uu] = (float)((double)S / (-1.0 + 2.0 * tot));
       }
     }
-    ARP_PROF_MARK(11);
+    ARP_PROF_MARK(10);
   }
 }
 

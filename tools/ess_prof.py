@@ -19,9 +19,9 @@ out = (C.c_ulonglong * 16)()
 L.arp_debug_ess_prof(out, 1)
 util.effective_sample_size(x); torch.cuda.synchronize()
 L.arp_debug_ess_prof(out, 0)
-names = ["barrier C (tile free)", "tile write", "prefetch 0 + barrier A", "ring + block 0", "prefetch 1", "block 1", "prefetch 2", "wave sums", "prefetch 3", "barrier B", "finish (lane = lag)", "further lags"]
+names = ["barrier C (tile free)", "tile write", "prefetch 0 + barrier A", "r + ring + block 0", "prefetch 1", "block 1", "prefetch 2", "sums over the slots", "prefetch 3", "centre + cut", "further lags"]
 tiles = (Cn * D + 31) // 32 // 256
-tot = sum(out[:12])
+tot = sum(out[:11])
 for k, nm in enumerate(names):
     print("%-22s %8d ticks  %6.2f us/tile  %5.1f %%" % (nm, out[k], out[k] / 100.0 / tiles, 100.0 * out[k] / max(tot, 1)))
 print("total %.2f us/tile over %d tiles = %.2f ms" % (tot / 100.0 / tiles, tiles, tot / 1e5))

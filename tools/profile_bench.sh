@@ -7,7 +7,7 @@ OUT="$R/gpurun_out/prof"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 HL="--steps 20 --warmup 5 --no-cpu-baseline --headline-only ${BENCH_ARGS:-}"
-python3 "$R/bench.py" ${BENCH_ARGS:-} > "$OUT/bench.json" 2> "$OUT/bench.err"
+python3 "$R/bench.py" ${BENCH_ARGS:-} --extras "$OUT/bench_extras.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
 # headline kernel alone: every launch in the trace is a warm-up or timed step
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" $HL > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$R/bench.py" $HL > "$OUT/pmc_fetch.log" 2>&1
@@ -25,4 +25,4 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_full_fetch" -- python3 "$R/bench.py" $FULL > "$OUT/pmc_full_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_full_write" -- python3 "$R/bench.py" $FULL > "$OUT/pmc_full_write.log" 2>&1
 find "$OUT" -name '*.csv' | head -60
-cat "$OUT/bench.json" | cut -c1-600
+cat "$OUT/bench.json"; wc -c "$OUT/bench.json" "$OUT/bench.err" "$OUT/bench_extras.json"

@@ -69,6 +69,9 @@ kname = dom["Name"]
 ks = short(kname)
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 open(os.path.join(dst, "%s_bench.json" % tag), "w").write(json.dumps(bench) + "\n")
+if os.path.exists(os.path.join(src, "bench_extras.json")):      # the long secondary figures of the same run
+    import shutil
+    shutil.copy(os.path.join(src, "bench_extras.json"), os.path.join(dst, "%s_bench_extras.json" % tag))
 
 vg = [r for r in csv.DictReader(open(one("trace/*/*_kernel_trace.csv"))) if ks in r["Kernel_Name"]][0]
 fetch = counters("pmc_fetch/*/*_counter_collection.csv", ks).get(ks, {}).get("FETCH_SIZE")
@@ -103,13 +106,13 @@ if "GRBM_GUI_ACTIVE" in sq:
         derived["valu_insts_per_wave_per_sampler_step"] = sq["SQ_INSTS_VALU"] / sq.get("SQ_WAVES", 1) / steps_per_wave
     derived["clock_ghz_estimate"] = cyc / avg_ns
     try:
-        sys.path.insert(0, ROOT)
         import importlib.util
         spec_ = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
-        src_b = open(os.path.join(ROOT, "bench.py")).read()
-        ns = {}
-        exec(src_b[src_b.index("ISSUE_COST_2W ="):src_b.index("def headline_issue_bound")], ns)
-        priced = sum(ns["HEADLINE_COST"][k] * v for k, v in ns["HEADLINE_MIX"].items())     # SIMD cycles per wave and step
+        bm = importlib.util.module_from_spec(spec_)
+        spec_.loader.exec_module(bm)
+        mix, mix_src = bm.headline_mix()                 # the `weighted` row of the newest profiles/rNN_headline_ledger.txt
+        derived["issue_mix_source"] = mix_src
+        priced = sum(bm.HEADLINE_COST[k] * v for k, v in mix.items())     # SIMD cycles per wave and step
         waves_per_simd_total = sq.get("SQ_WAVES", 0) / n_simd
         derived["issue_bound_cycles_at_2.4GHz_per_wave_step"] = priced
         # time based (the costs are times quoted at 2.4 GHz): priced time / this profiled pass's measured time
