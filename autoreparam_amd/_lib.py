@@ -74,7 +74,7 @@ class ViIO(C.Structure):
 # every symbol include/autoreparam.h declares
 SYMBOLS = ["arp_version", "arp_last_error", "arp_model_create", "arp_model_destroy", "arp_model_dim",
            "arp_model_logp_const", "arp_model_set_param", "arp_model_set_option", "arp_logp_grad", "arp_transform",
-           "arp_hmc_run", "arp_interleaved_run", "arp_model_check", "arp_vi_run", "arp_vi_geometry", "arp_relay_geometry", "arp_ess", "arp_ess_ws", "arp_ess_workspace_bytes",
+           "arp_hmc_run", "arp_interleaved_run", "arp_model_check", "arp_vi_run", "arp_vi_geometry", "arp_vi_attempts", "arp_relay_geometry", "arp_ess", "arp_ess_ws", "arp_ess_workspace_bytes",
            "arp_adapt_probe", "arp_clock_probe"]
 
 _lib = None
@@ -107,6 +107,7 @@ def lib():
                                       C.POINTER(InterleavedIO), C.c_void_p]
     L.arp_vi_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(ViConfig), C.POINTER(ViIO), C.c_void_p]
     L.arp_vi_geometry.argtypes = [C.POINTER(C.c_int32)]
+    L.arp_vi_attempts.argtypes = [C.POINTER(C.c_int32)]
     L.arp_relay_geometry.argtypes = [C.POINTER(C.c_int32)]
     L.arp_model_check.argtypes = [C.c_void_p]
     L.arp_ess.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]

@@ -17,6 +17,7 @@ static const double kHalfLog2Pi = 0.9189385332046727;
 // geometry of the last arp_vi_run of this thread (arp_vi_geometry: a measurement hook)
 struct ViGeometry { int v[6]; };
 static thread_local ViGeometry g_vi_geometry = {{0, 0, 0, 0, 0, 0}};
+static thread_local int g_vi_attempts = 0;      // launches the calling thread's last arp_vi_run needed per chunk, at most (arp_vi_attempts)
 // arp_vi_run launches whose workgroups wait for each other hold this from the launch to the end of the launch: two such
 // launches from two threads of a process would share the device's workgroup slots, and a group that is only partly
 // resident waits for slots the other launch's waiting groups hold
@@ -501,6 +502,7 @@ int arp_model_destroy(arp_model* m) {
   if (m->dev_tables) (void)hipFree(m->dev_tables);
   for (int w = 0; w < 2; ++w) if (m->dev_ab[w]) (void)hipFree(m->dev_ab[w]);
   if (m->vi_ws) (void)hipFree(m->vi_ws);
+  if (m->vi_snap) (void)hipFree(m->vi_snap);
   if (m->relay_err) (void)hipHostFree(m->relay_err);
   delete m;
   return 0;
@@ -872,30 +874,77 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
   P.xch = GR > 1 ? (unsigned long long*)((char*)m->vi_ws + 256) : nullptr;
   g_vi_geometry = {B, G, R, groups_per_launch, (int)std::min<long long>((long long)cfg->n_lr * GR, capacity), occ};
   // A group's workgroups wait for each other, so all of them must be resident.  Cooperative launch (the default where the
-  // device has it): the runtime guarantees it or refuses the launch, also against other launches of this process.  Plain
-  // launch: residency rests on the occupancy arithmetic above plus one such launch at a time in this process (the mutex).
+  // device has it): the runtime checks the grid against the device's capacity and serialises such launches of the process.
+  // Plain launch: the occupancy arithmetic above plus one such launch at a time in this process (the mutex).  Neither holds
+  // against kernels of other queues or processes: see the retry below.
   const bool coop = GR > 1 && (m->vi_launch == 2 || (m->vi_launch == 0 && m->coop_ok));
   if (m->vi_launch == 2 && !m->coop_ok) { set_error("arp_vi_run: vi_launch=cooperative but the device does not support cooperative launches"); return 1; }
   std::unique_lock<std::mutex> one_at_a_time(g_vi_launch_mutex, std::defer_lock);
   if (GR > 1 && !coop) one_at_a_time.lock();
+  // A launch whose hand-offs ran into their bound (the device was shared with kernels of other queues or processes for
+  // that long: no launch mode guarantees residency against THOSE) is not an error yet: the parameters it started from are
+  // kept, and it is taken again with four times the bound -- 2 s, 8 s, 32 s -- before the call gives up.  A fit under
+  // contention is slower, not failed; an undisturbed one never takes the second launch.
+  const size_t rowf = (size_t)m->D;
+  const int n_keep = 2 + (io->w ? 1 : 0) + (io->wb && cfg->learn_a ? 1 : 0);
+  if (GR > 1 && m->vi_snap_floats < (size_t)n_keep * groups_per_launch * rowf) {
+    if (m->vi_snap) { ARP_HIP_OK(hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(m->vi_snap); m->vi_snap = nullptr; m->vi_snap_floats = 0; }
+    ARP_HIP_OK(hipMalloc((void**)&m->vi_snap, (size_t)n_keep * groups_per_launch * rowf * sizeof(float)));
+    m->vi_snap_floats = (size_t)n_keep * groups_per_launch * rowf;
+  }
+  int fault_attempts = 0;               // test hook (ARP_DEBUG=1): treat the first n launches of every chunk as timed out
+  if (debug_int("ARP_VI_FAULT_ATTEMPTS", &dbg) && dbg > 0) fault_attempts = dbg;
+  g_vi_attempts = 0;
   for (int lr0 = 0; lr0 < cfg->n_lr; lr0 += groups_per_launch) {
     const int ng = std::min(groups_per_launch, cfg->n_lr - lr0);
-    // every polled word starts at zero (epochs start at 1): the flag and this launch's granules
-    ARP_HIP_OK(hipMemsetAsync(m->vi_ws, 0, need, (hipStream_t)stream));
-    P.lr0 = lr0;
-    ARP_HIP_OK(o->vi(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, ng, coop, (hipStream_t)stream));
+    float* rows[4] = {io->loc, io->rho, io->w, (io->wb && cfg->learn_a) ? io->wb : nullptr};
+    const size_t chunk = (size_t)ng * rowf;
     if (GR > 1) {
+      size_t k = 0;
+      for (float* r : rows)
+        if (r) ARP_HIP_OK(hipMemcpyAsync(m->vi_snap + (k++) * chunk, r + (size_t)lr0 * rowf, chunk * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    P.lr0 = lr0;
+    P.spin_ticks = kViSpinTicks;
+    for (int attempt = 0;; ++attempt) {
+      if (attempt > 0) {
+        size_t k = 0;
+        for (float* r : rows)
+          if (r) ARP_HIP_OK(hipMemcpyAsync(r + (size_t)lr0 * rowf, m->vi_snap + (k++) * chunk, chunk * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        P.spin_ticks *= 4;
+      }
+      // every polled word starts at zero (epochs start at 1): the flag and this launch's granules
+      ARP_HIP_OK(hipMemsetAsync(m->vi_ws, 0, need, (hipStream_t)stream));
+      hipError_t launched = o->vi(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, ng, coop, (hipStream_t)stream);
+      if (coop && m->vi_launch == 0 && (launched == hipErrorCooperativeLaunchTooLarge || launched == hipErrorNotSupported)) {
+        // "auto" only: the runtime counts co-residency more strictly than the occupancy query above (or lacks the feature
+        // after all) -- take the plain launch, one at a time per process, as round 5 did
+        (void)hipGetLastError();
+        if (!one_at_a_time.owns_lock()) one_at_a_time.lock();
+        launched = o->vi(family_args(m), m->dev_ab[which], m->dev_ab[which] + m->D, P, ng, false, (hipStream_t)stream);
+      }
+      ARP_HIP_OK(launched);
+      g_vi_attempts = std::max(g_vi_attempts, attempt + 1);
+      if (GR <= 1) break;
       // the hand-offs' waits are bounded: a group that was not resident together reports it here instead of hanging
       int err = 0;
       ARP_HIP_OK(hipMemcpyAsync(&err, m->vi_ws, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
       ARP_HIP_OK(hipStreamSynchronize((hipStream_t)stream));
-      if (err) {
-        set_error("arp_vi_run: a hand-off between the workgroups of a learning rate timed out (the group was not resident "
-                  "together: is another kernel holding the device?)");
+      if (attempt < fault_attempts) err = 1;
+      if (!err) break;
+      if (attempt == 2) {
+        set_error("arp_vi_run: a hand-off between the workgroups of a learning rate timed out three times (2 s, 8 s, 32 s: the "
+                  "group was never resident together -- is another process holding the device?)");
         return 1;
       }
     }
   }
+  return 0;
+}
+
+int arp_vi_attempts(int32_t* out1) {
+  if (!out1) { set_error("arp_vi_attempts: null argument"); return 1; }
+  *out1 = g_vi_attempts;
   return 0;
 }
 

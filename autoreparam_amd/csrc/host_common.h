@@ -341,6 +341,9 @@ struct arp_model {
   // hand-off workspace of the VI kernel (granules + the error flag in its first 256 bytes), grown on demand
   void* vi_ws = nullptr;
   size_t vi_ws_bytes = 0;
+  // the parameters a VI launch starts from, kept until its hand-offs are known to have gone through (arp_vi_run retries)
+  float* vi_snap = nullptr;
+  size_t vi_snap_floats = 0;
   // pinned, device-visible word a relay launch sets when a hand-over timed out (kernels.h: relay_begin; arp_model_check)
   unsigned* relay_err = nullptr;
   unsigned* relay_err_dev = nullptr;

@@ -937,7 +937,7 @@ __global__ __launch_bounds__(kBlock, Lane::MINW) void interleaved_kernel(
 // program_transformations.py:507-510).
 // ---------------------------------------------------------------------------
 constexpr int kViDmax = kMaxD;
-constexpr unsigned long long kViSpinTicks = 200000000ull;   // 2 s of s_memrealtime per wait
+constexpr unsigned long long kViSpinTicks = 200000000ull;   // 2 s of s_memrealtime per wait: the FIRST attempt's bound (arp_vi_run retries with 4 x)
 
 struct ViParams {
   int n_steps, n_mc, learn_a, tied_b, a_prior, D;
@@ -953,6 +953,7 @@ struct ViParams {
   unsigned long long* xch;     // hand-off granules, zeroed before the launch: per group [2][G R][Tp] partials + [2][Tp] totals
   int xch_tp;                  // Tp: items per workgroup, padded (items: nq x D sums + the ELBO sum)
   int* err;                    // device flag, set when a hand-off wait ran out
+  unsigned long long spin_ticks;   // bound of one hand-off wait, in ticks of the 100 MHz clock
 };
 
 // workspace of one launch, in 8-byte granules (shared with the host)
@@ -1016,7 +1017,7 @@ ARP_DEV unsigned long long vi_get(vi_gu64* g) { return __hip_atomic_load(g, __AT
 // n <= CH granules at g[0], g[stride], ...: all loads of a sweep in flight together, sweeps repeated until every tag is
 // the epoch's; the values, in order, are handed to `take`.  false: the wait ran out (a member of the group is not running).
 template <int CH, class F>
-ARP_DEV bool vi_gather(vi_gu64* g, size_t stride, int n, unsigned epoch, F take) {
+ARP_DEV bool vi_gather(vi_gu64* g, size_t stride, int n, unsigned epoch, unsigned long long bound, F take) {
   unsigned long long x[CH];
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (;;) {
@@ -1026,7 +1027,7 @@ ARP_DEV bool vi_gather(vi_gu64* g, size_t stride, int n, unsigned epoch, F take)
 #pragma unroll
     for (int j = 0; j < CH; ++j) ok = ok && (unsigned)(x[j] >> 32) == epoch;
     if (ok) break;
-    if (__builtin_amdgcn_s_memrealtime() - t0 > kViSpinTicks) return false;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > bound) return false;
     __builtin_amdgcn_s_sleep(2);
   }
 #pragma unroll
@@ -1350,7 +1351,7 @@ __global__ __launch_bounds__(B) void vi_kernel(
         float sum = 0.f;
         bool ok = true;
         for (int src = 0; src < GR && ok; src += 32)
-          ok = vi_gather<32>(p1 + (size_t)src * Tp + t, (size_t)Tp, min(32, GR - src), epoch, [&](float v) { sum += v; });
+          ok = vi_gather<32>(p1 + (size_t)src * Tp + t, (size_t)Tp, min(32, GR - src), epoch, P.spin_ticks, [&](float v) { sum += v; });
         if (!ok) { failed = true; sum = __builtin_nanf(""); }
         vi_put(p2 + t, epoch, sum);
       }
@@ -1361,10 +1362,10 @@ __global__ __launch_bounds__(B) void vi_kernel(
         const int d = tid + u * B;
         if (d < D) {
           int k = 0;
-          if (!vi_gather<4>(p2 + d, (size_t)D, nq, epoch, [&](float v) { tot[u][k++] = v; })) failed = true;
+          if (!vi_gather<4>(p2 + d, (size_t)D, nq, epoch, P.spin_ticks, [&](float v) { tot[u][k++] = v; })) failed = true;
         }
       }
-      if (tid == B - 1 && !vi_gather<1>(p2 + nq * D, 1, 1, epoch, [&](float v) { s_elbo = v; })) failed = true;
+      if (tid == B - 1 && !vi_gather<1>(p2 + nq * D, 1, 1, epoch, P.spin_ticks, [&](float v) { s_elbo = v; })) failed = true;
       if (failed) { s_fail = 1; if (P.err) *P.err = 1; }
       VI_T(9);
     } else if (tid == 0) {

@@ -246,6 +246,12 @@ class Engine(object):
         _lib.check(self._L.arp_relay_geometry(out))
         return dict(zip(("segments", "chain_blocks", "workgroups_per_cu"), [int(v) for v in out]))
 
+    def vi_attempts(self):
+        """Launches this thread's last vi_run needed (arp_vi_attempts): 1 unless a hand-off ran into its bound and the fit was retaken."""
+        out = (C.c_int32 * 1)()
+        _lib.check(self._L.arp_vi_attempts(out))
+        return int(out[0])
+
     def vi_geometry(self):
         """Shape of this thread's last vi_run launch (arp_vi_geometry): threads per workgroup, sample groups G and row
         parts R per learning rate, learning rates per launch, workgroups resident together, workgroups one CU holds."""

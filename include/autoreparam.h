@@ -137,9 +137,11 @@ int arp_model_dim(const arp_model* m);                 /* D */
  * operand as three bf16 pieces (six leading cross products: f32-equivalent, error ~ 2^-23 per product; needs a design matrix
  * with at most 8 columns that are not exact in one bf16 piece -- the reference's data have 7), "auto" (default) = bf16x3 where
  * the data allow it.  "vi_launch": how arp_vi_run starts a launch whose workgroups wait for each other inside the launch --
- * "cooperative" = hipLaunchCooperativeKernel (the runtime guarantees that the whole grid is resident, or refuses), "plain" =
- * an ordinary launch sized by an occupancy query, one such launch at a time per process, "auto" (default) = cooperative where
- * the device supports it.  Returns non-zero for an unknown key / value or a model the key does not apply to. */
+ * "cooperative" = hipLaunchCooperativeKernel (the runtime checks the grid against the device's capacity and serialises such
+ * launches of the process), "plain" = an ordinary launch sized by an occupancy query, one such launch at a time per process,
+ * "auto" (default) = cooperative where the device supports it, plain if the runtime refuses the grid.  (Kernels of other
+ * queues or processes can still keep a group from being resident together: arp_vi_run retakes a launch whose hand-offs timed
+ * out -- arp_vi_attempts.)  Returns non-zero for an unknown key / value or a model the key does not apply to. */
 int arp_model_set_option(arp_model* m, const char* key, const char* value);
 /* Additive constant dropped from logp for parameterisation `which` (so callers can
  * report the reference-valued target_log_prob / ELBO): logp_ref = logp + const. */
@@ -226,6 +228,10 @@ int arp_vi_run(arp_model* m, int which, const arp_vi_config* cfg, const arp_vi_i
  * sample groups G, row parts R (workgroups per learning rate = G x R), learning rates per launch, workgroups resident
  * together (= CUs in use when one fits per CU), workgroups of the kernel one CU holds}.  (bench.py: vi_kernel.) */
 int arp_vi_geometry(int32_t* out6);
+/* Measurement hook: how many launches the calling thread's last arp_vi_run needed for its slowest chunk of learning rates
+ * (1 = every hand-off went through at once; a launch whose in-launch hand-offs ran into their bound -- the device was shared
+ * for seconds -- is taken again from the parameters it started with, with 4 x the bound: 2 s, 8 s, 32 s, then an error). */
+int arp_vi_attempts(int32_t* out1);
 
 /* Deferred status of the handle's asynchronous launches: 0 if none failed; non-zero (and arp_last_error set) if a relay
  * hand-over inside an arp_hmc_run / arp_interleaved_run launch timed out since the last check -- the chains of that launch

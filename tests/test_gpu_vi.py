@@ -112,6 +112,43 @@ def test_vi_cooperative_and_plain_launch_give_the_same_fit(gpu, mname):
             assert np.array_equal(x, y, equal_nan=True)
 
 
+@pytest.mark.parametrize("mname,learn", [("radon_PA", False), ("german", True)])
+def test_vi_launch_that_times_out_is_taken_again_from_its_starting_point(gpu, monkeypatch, mname, learn):
+    """arp_vi_run keeps the parameters a launch starts from until its in-launch hand-offs are known to have gone through: a
+    launch that reports a time-out (here by decree: ARP_VI_FAULT_ATTEMPTS, a test hook) is taken again from them with four
+    times the bound, and the fit that comes out is bit for bit the undisturbed one; after three failures the call returns an
+    error with a message instead of hanging or trapping."""
+    from autoreparam_amd import engine
+    sp = helpers.spec(mname)
+    eng = engine.Engine(sp, gpu)
+    eng.set_param(0, (np.full(sp.D, 0.5, np.float32), np.ones(sp.D, np.float32)) if learn else "NCP")
+    rs = np.random.RandomState(0)
+    loc0 = (1e-2 * rs.randn(7, sp.D)).astype(np.float32)        # seven learning rates: German credit takes them in two launches
+    lrs = [0.01, 0.02, 0.05, 0.1, 0.2, 0.3, 0.4]
+
+    def fit():
+        loc = torch.as_tensor(loc0.copy(), device=gpu); rho = torch.full((7, sp.D), -2.0, device=gpu)
+        w = torch.zeros(7, sp.D, device=gpu) if learn else None
+        elbo = eng.vi_run(lrs, loc, rho, 60, 256, w=w, seed=4)
+        return [t.cpu().numpy() for t in (elbo, loc, rho)] + ([w.cpu().numpy()] if learn else [])
+
+    ref = fit()
+    assert eng.vi_attempts() == 1
+    monkeypatch.setenv("ARP_DEBUG", "1")
+    monkeypatch.setenv("ARP_VI_FAULT_ATTEMPTS", "2")
+    got = fit()
+    assert eng.vi_attempts() == 3
+    for x, y in zip(ref, got):
+        assert np.array_equal(x, y, equal_nan=True)
+    monkeypatch.setenv("ARP_VI_FAULT_ATTEMPTS", "3")
+    with pytest.raises(RuntimeError, match="timed out three times"):
+        fit()
+    monkeypatch.delenv("ARP_VI_FAULT_ATTEMPTS")
+    again = fit()
+    for x, y in zip(ref, again):
+        assert np.array_equal(x, y, equal_nan=True)
+
+
 @pytest.mark.parametrize("mname", ["8schools", "radon_MN"])
 def test_cvip_learns_parameterisation(oracle_lib, gpu, mname):
     from autoreparam_amd import engine

@@ -12,6 +12,10 @@ MODELS = ["8schools", "radon_MN", "radon_PA", "election", "german", "radon_sd_MN
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
 engines = {m: engine.Engine(helpers.spec(m), "cuda:0") for m in MODELS}
+if os.environ.get("VI_LAUNCH"):                      # plain | cooperative | auto (arp_model_set_option "vi_launch")
+    for e_ in engines.values():
+        e_.set_option("vi_launch", os.environ["VI_LAUNCH"])
+retaken = 0
 t0 = time.time(); n = 0; steps_total = 0; shapes = set()
 while time.time() - t0 < budget:
     m = MODELS[rs.randint(len(MODELS))]
@@ -32,6 +36,7 @@ while time.time() - t0 < budget:
         w = torch.zeros(n_lr, sp.D, device="cuda:0") if learn else None
         wb = torch.zeros(n_lr, sp.D, device="cuda:0") if (learn and not tied) else None
         e = eng.vi_run(lrs, loc, rho, n_steps, n_mc, w=w, wb=wb, tied_b=tied, seed=seed)
+        retaken += eng.vi_attempts() > 1
         out.append([t.cpu().numpy() for t in (e, loc, rho) + ((w,) if learn else ())])
     g = eng.vi_geometry()
     shapes.add((m, g["sample_groups"], g["row_parts"], g["learning_rates_per_launch"]))
@@ -41,5 +46,5 @@ while time.time() - t0 < budget:
     # a learning rate of 0.2 may diverge to inf/nan on its own (the reference's search discards those); the first ELBO never does
     assert np.isfinite(out[0][0][:, 0]).all(), ("first ELBO not finite", tag)
     n += 1; steps_total += 2 * n_lr * n_steps
-print("vi soak ok: %d fits (each twice, bitwise equal), %d optimisation steps, %d distinct (model, G, R, learning rates per launch) shapes in %.0f s"
-      % (n, steps_total, len(shapes), time.time() - t0))
+print("vi soak ok: %d fits (each twice, bitwise equal; %d taken again after a hand-off time-out), %d optimisation steps, %d distinct (model, G, R, learning rates per launch) shapes in %.0f s"
+      % (n, retaken, steps_total, len(shapes), time.time() - t0))
