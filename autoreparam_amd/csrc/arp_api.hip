@@ -449,7 +449,12 @@ int arp_model_create(const arp_dataset* data, arp_model** out) {
     if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, m->device) == hipSuccess) m->coop_ok = coop != 0;
     ARP_HIP_OK(hipHostMalloc((void**)&m->relay_err, sizeof(unsigned), hipHostMallocMapped));
     *m->relay_err = 0u;
-    ARP_HIP_OK(hipHostGetDevicePointer((void**)&m->relay_err_dev, m->relay_err, 0));
+    const hipError_t mapped = hipHostGetDevicePointer((void**)&m->relay_err_dev, m->relay_err, 0);
+    if (mapped != hipSuccess) {          // (the handle is not complete yet: nothing else to release)
+      (void)hipHostFree(m->relay_err);
+      m->relay_err = nullptr;
+      ARP_HIP_OK(mapped);
+    }
   }
   int rc;
   switch (data->model) {
