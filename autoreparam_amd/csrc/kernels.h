@@ -113,9 +113,11 @@ ARP_DEV RelayId relay_begin(HmcParams& P) {
           }
           if (failed) { s_relay[1] = 1u; break; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // this CU's L1 (and stale L2 lines of other XCDs' data)
       }
       __syncthreads();
+      // EVERY wave takes the acquire itself, in front of its own loads (this CU's L1, stale L2 lines of other XCDs' data): the
+      // memory model orders a wave's loads behind ITS OWN invalidate, not behind another wave's through a barrier
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       if (__builtin_amdgcn_readfirstlane((int)s_relay[1])) r.seg = -1;
     }
   }
@@ -123,10 +125,14 @@ ARP_DEV RelayId relay_begin(HmcParams& P) {
 }
 ARP_DEV void relay_end(const HmcParams& P, RelayId r) {
   if (P.segs > 1) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every storing wave drains its stores
+    // EVERY storing wave releases its own stores (write-back of the XCD's L2 behind them, then vmcnt(0)) before the barrier.
+    // Round 5 / early round 6 let the waves only drain (`s_waitcnt vmcnt(0)`) and thread 0 alone write L2 back after the
+    // barrier: with the ticket order (consecutive segments of a block on arbitrary XCDs) one run in ten then handed a stale
+    // cache line or two to the next segment (tests/diagnostics/relay_race_probe.py: 14 of 120 repetitions at 8 192 chains;
+    // 0 of 120 with this form) -- a write-back issued by ANOTHER wave does not order behind this wave's stores.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (threadIdx.x == 0 && !P.seg_fault) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // the XCD's L2 written back
       __hip_atomic_store(P.seg_flags + r.bid, P.seg_epoch + (unsigned)r.seg + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

@@ -607,7 +607,9 @@ def test_relay_segments_equal_the_unsegmented_launch(gpu, monkeypatch, chains, l
 
     for T, with_stats in ((333, False), (256, True), (520, False)):     # library's choice: 4, 4 and 8 segments
         ref = run(1, T, with_stats)
-        for segs in (None, 2, 3, 8):
+        # the small launch repeats its 8-segment run: a hand-over that does not publish EVERY wave's stores before the flag goes
+        # up hands over a stale cache line once in ~ 10 such runs (tests/diagnostics/relay_race_probe.py; round 6)
+        for segs in (None, 2, 3, 8) + ((8,) * 24 if chains == 8192 and with_stats else ()):
             got = run(segs, T, with_stats)
             for k, (x, y) in enumerate(zip(ref[:11], got[:11])):
                 assert np.array_equal(x, y, equal_nan=True), (segs, T, with_stats, k)

@@ -19,7 +19,7 @@ while time.time() - t0 < budget:
     sp = helpers.spec(mname)
     if mname not in engines: engines[mname] = engine.Engine(sp, "cuda:0")
     eng = engines[mname]
-    C = int(rs.choice([32768, 40000, 49152, 65536, 65537, 98304, 131072]))
+    C = int(rs.choice([8192, 8200, 16384, 32768, 40000, 49152, 65536, 65537, 98304, 131072]))
     T = int(rs.randint(256, 1200))
     L = int(rs.randint(1, 4))
     if mode == "i": eng.set_param(0, "CP"); eng.set_param(1, "NCP")
